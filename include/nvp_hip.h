@@ -1,0 +1,171 @@
+/*
+ * nvp_hip.h - C ABI of libnvp_hip.so: the MI355X (gfx950) implementation of NVP's
+ * per-coordinate encoding path.
+ *
+ * The reference has no FFI of its own: its boundary is the Python module surface
+ * (modules.NVP, tinycudann.Encoding, sparsegrid.SparseGrid, modulation.*).  The
+ * native half of that surface - what the reference gets from the tiny-cuda-nn CUDA
+ * extension and from ATen kernels - is replaced by the entry points below.  Each one
+ * names the reference call site it stands in for.  nvp_amd/ (Python) binds them with
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *    enqueues work on it, never synchronises, never allocates;
+ *  - return value: 0 on success, otherwise a hipError_t value (launch/config error) or
+ *    NVP_ERR_* (<0) for argument errors; nothing throws;
+ *  - "tiles" are groups of 32 consecutive pixels.  Pixel-tile-major (PTM) tensors are
+ *    laid out [ntiles][rows][32] (row = feature / hidden unit, 32 pixels contiguous),
+ *    ntiles = ceil(N/32); pixels >= N inside the last tile are zero-filled by the
+ *    producers and ignored by the consumers.
+ *  - `accumulate` outputs (parameter gradients of the grids) are ADDED into; the caller
+ *    zero-fills them (that is autograd's dense-grad contract).
+ */
+#ifndef NVP_HIP_H
+#define NVP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVP_MAX_LEVELS 16
+#define NVP_HIDDEN 128          /* network.n_neurons; the kernels are specialised for 128 x 3 layers */
+#define NVP_TILE 32             /* pixels per tile */
+
+#define NVP_ERR_BADARG (-1)
+#define NVP_ERR_UNSUPPORTED (-2)
+
+/* Geometry of one 2D multi-resolution dense grid (one "learnable keyframe" plane).
+ * Built on the host exactly as the reference restates it, eval.py:28-35:
+ *   a = exp(l*log(per_level_scale))*base - 1 (double); res = ceil(a)+1; offset += res^2.
+ * `scale` is `a` rounded once to fp32.  offset[] counts CELLS (multiply by n_features). */
+typedef struct nvp_levels {
+    int32_t n_levels;
+    int32_t n_features;                   /* F: 1, 2, 4 or 8 */
+    float scale[NVP_MAX_LEVELS];
+    int32_t res[NVP_MAX_LEVELS];
+    int32_t offset[NVP_MAX_LEVELS + 1];
+} nvp_levels;
+
+/* Shape of the 3D sparse positional-feature grid, embeddings[T][X][Y][F]
+ * (reference sparsegrid.py:13). */
+typedef struct nvp_sparse_shape {
+    int32_t t_res, x_res, y_res, n_features;
+} nvp_sparse_shape;
+
+/* The 14 MLP tensors in their natural (state_dict) layouts.
+ * mod_w[k]: [128, D] (k=0) / [128, 128+D] (k=1,2)   reference modulation.py:97-107
+ * sir_w[0]: [128,1]; sir_w[1,2]: [128,128]; last_w: [3,128]   modulation.py:61-81 */
+typedef struct nvp_mlp_params {
+    const float* mod_w[3];
+    const float* mod_b[3];
+    const float* sir_w[3];
+    const float* sir_b[3];
+    const float* last_w;
+    const float* last_b;
+} nvp_mlp_params;
+
+/* Same 14 tensors, writable (gradient destinations, natural layouts, OVERWRITTEN). */
+typedef struct nvp_mlp_grads {
+    float* mod_w[3];
+    float* mod_b[3];
+    float* sir_w[3];
+    float* sir_b[3];
+    float* last_w;
+    float* last_b;
+} nvp_mlp_grads;
+
+/* Library / device info ----------------------------------------------------------- */
+const char* nvp_version(void);
+/* Number of floats of each workspace, so the host can allocate with torch.empty. */
+int64_t nvp_packed_fwd_floats(int32_t latent_dim);
+int64_t nvp_packed_bwd_floats(int32_t latent_dim);
+int64_t nvp_dw_partial_floats(int32_t latent_dim, int32_t n_chunks);
+int64_t nvp_mlp_param_floats(int32_t latent_dim);
+int32_t nvp_latent_rows(int32_t latent_dim);   /* rows of a PTM latent tensor (D rounded up to even) */
+
+/* ---- R2/R3: tinycudann.Encoding forward / backward (reference modules.py:65-67) ---
+ * x [N,2] row-major, out/dout [N, n_levels*F] row-major, dparams accumulate. */
+int nvp_dense2d_fwd(const float* params, const float* x, float* out, int64_t n,
+                    const nvp_levels* lv, void* stream);
+int nvp_dense2d_bwd(const float* x, const float* dout, float* dparams, int64_t n,
+                    const nvp_levels* lv, void* stream);
+
+/* ---- R5/R6/R7: SparseGrid.forward / its autograd / forward_inter
+ * (reference sparsegrid.py:23-72, autograd index_put_, :76-156).
+ * coords [N,3]=(t,x,y) row-major, out/dout [N,9F] row-major, demb accumulate. */
+int nvp_sparse3x3_fwd(const float* emb, const float* coords, float* out, int64_t n,
+                      const nvp_sparse_shape* sh, void* stream);
+int nvp_sparse3x3_bwd(const float* coords, const float* dout, float* demb, int64_t n,
+                      const nvp_sparse_shape* sh, void* stream);
+int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, int64_t n,
+                            const nvp_sparse_shape* sh, void* stream);
+
+/* ---- R11 (encoding half of NVP.forward, modules.py:57-78), fused ------------------
+ * coords [N,3] -> PTM latent zt [ntiles][rows][32], rows = nvp_latent_rows(D),
+ * D = sum_p L_p*F_p + 9*F_s, row order xy | yt | xt | sparse (modules.py:69,78).
+ * temporal_interp != 0 selects forward_inter for the sparse part (modules.py:72-73). */
+int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, const float* kf_xt,
+                   const float* emb, float* zt, int64_t n,
+                   const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                   const nvp_sparse_shape* sh, int temporal_interp, void* stream);
+/* dzt PTM -> scatter-add into the four grids' gradients (accumulate). */
+int nvp_encode_bwd(const float* coords, const float* dzt,
+                   float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
+                   const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                   const nvp_sparse_shape* sh, void* stream);
+
+/* Row-major [N,D] <-> PTM [ntiles][rows][32] (used by the stand-alone SirenWrapper). */
+int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream);
+int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream);
+
+/* ---- R8-R10: SirenWrapper.forward = Modulator + modulated SirenNet
+ * (reference modulation.py:138-145, 112-121, 83-92).
+ * pack: re-lays the 14 tensors out as MFMA A-operand streams (call after every
+ *       optimizer step; ~0.5 MB).
+ * fwd : zt PTM latent, steps [N] -> rgb [N,3] row-major; `saved` receives the five
+ *       activations backward needs (h0,h1,h2 post-LeakyReLU, q1,q2 pre-sine), each PTM
+ *       [ntiles][128][32]; pass NULL for inference (nothing is stored). */
+int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t latent_dim, void* stream);
+int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t latent_dim, void* stream);
+int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
+                float* rgb, float* saved, int64_t n, int32_t latent_dim, void* stream);
+
+/* ---- R12: autograd of R8-R10 (reference training.py:74).
+ * bwd_dx: drgb [N,3] -> dzt (PTM latent gradient) + the nine PTM [ntiles][128][32]
+ *         streams the weight-gradient GEMMs consume:
+ *         dy = {dp0,dp1,dp2 (modulator pre-activation grads), dq0s (= 30*dq0), dq1, dq2},
+ *         xs = {x0,x1,x2 (modulated sine outputs)}.
+ * bwd_dw: all 14 parameter gradients = split-K GEMMs over the pixel axis into
+ *         `partials` [n_chunks][nvp_mlp_param_floats], then a deterministic reduction
+ *         into `g` (overwritten). */
+int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved,
+                   const nvp_mlp_params* p, const float* packed_bwd,
+                   float* dy, float* xs, float* dzt, int64_t n, int32_t latent_dim, void* stream);
+int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
+                   const float* dy, const float* xs, float* partials, int32_t n_chunks,
+                   const nvp_mlp_grads* g, int64_t n, int32_t latent_dim, void* stream);
+
+/* ---- R13: image_mse (reference loss_functions.py:1-3 with training.py:47-48) ---------
+ * gt_u8 [N,3] uint8.  loss_sum[0] += sum((rgb-gt)^2) (caller zeroes, divides by 3N);
+ * drgb = 2*(rgb-gt)/(3N) i.e. d(mean)/d(rgb).  drgb may be NULL. */
+int nvp_mse_u8(const float* rgb, const uint8_t* gt_u8, float* drgb, float* loss_sum,
+               int64_t n, void* stream);
+
+/* ---- row H helpers: on-device sampler (reference dataio.py:104-120) -------------------
+ * ti [N], pi [N] int64 indices (drawn by the caller with torch.randint, temporal first,
+ * same order as the reference); video u8 [T][H*W][3] resident on the device;
+ * tcoord_tab = linspace(0,1,T), tstep_tab = linspace(.5/T, 1-.5/T, T) (dataio.py:93-99).
+ * Writes coords [N,3] = (tcoord[ti], row/(H-1), col/(W-1)), steps [N], gt_u8 [N,3]. */
+int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi,
+                      const float* tcoord_tab, const float* tstep_tab,
+                      float* coords, float* steps, uint8_t* gt_u8,
+                      int64_t n, int32_t t_frames, int32_t height, int32_t width, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVP_HIP_H */

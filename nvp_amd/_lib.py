@@ -1,0 +1,173 @@
+"""ctypes binding of libnvp_hip.so (include/nvp_hip.h).
+
+The shared library is built in-tree by nvp_amd/csrc/build.sh (hipcc, gfx950).  There is
+NO fallback: if the library is missing, or a tensor is not a contiguous fp32 HIP tensor,
+the call raises - the product path never silently runs on anything but the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnvp_hip.so")
+
+NVP_MAX_LEVELS = 16
+HIDDEN = 128
+TILE = 32
+
+
+class Levels(C.Structure):
+    """struct nvp_levels - geometry of one 2D multi-resolution dense grid."""
+    _fields_ = [
+        ("n_levels", C.c_int32),
+        ("n_features", C.c_int32),
+        ("scale", C.c_float * NVP_MAX_LEVELS),
+        ("res", C.c_int32 * NVP_MAX_LEVELS),
+        ("offset", C.c_int32 * (NVP_MAX_LEVELS + 1)),
+    ]
+
+
+class SparseShape(C.Structure):
+    _fields_ = [("t_res", C.c_int32), ("x_res", C.c_int32), ("y_res", C.c_int32), ("n_features", C.c_int32)]
+
+
+class MlpParams(C.Structure):
+    _fields_ = [
+        ("mod_w", C.c_void_p * 3), ("mod_b", C.c_void_p * 3),
+        ("sir_w", C.c_void_p * 3), ("sir_b", C.c_void_p * 3),
+        ("last_w", C.c_void_p), ("last_b", C.c_void_p),
+    ]
+
+
+MlpGrads = MlpParams  # identical layout (const-ness only differs in C)
+
+_p, _i64, _i32, _vp = C.c_void_p, C.c_int64, C.c_int32, C.c_void_p
+
+# name -> argtypes; every entry point returns int unless listed in _RESTYPES
+SIGNATURES = {
+    "nvp_dense2d_fwd": [_p, _p, _p, _i64, C.POINTER(Levels), _vp],
+    "nvp_dense2d_bwd": [_p, _p, _p, _i64, C.POINTER(Levels), _vp],
+    "nvp_sparse3x3_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
+    "nvp_sparse3x3_bwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
+    "nvp_sparse3x3_inter_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
+    "nvp_encode_fwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
+                       C.POINTER(SparseShape), C.c_int, _vp],
+    "nvp_encode_bwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
+                       C.POINTER(SparseShape), _vp],
+    "nvp_rows_to_ptm": [_p, _p, _i64, _i32, _i32, _vp],
+    "nvp_ptm_to_rows": [_p, _p, _i64, _i32, _i32, _vp],
+    "nvp_mlp_pack_fwd": [C.POINTER(MlpParams), _p, _i32, _vp],
+    "nvp_mlp_pack_bwd": [C.POINTER(MlpParams), _p, _i32, _vp],
+    "nvp_mlp_fwd": [_p, _p, C.POINTER(MlpParams), _p, _p, _p, _i64, _i32, _vp],
+    "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _i64, _i32, _vp],
+    "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
+    "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
+    "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
+    "nvp_packed_fwd_floats": [_i32],
+    "nvp_packed_bwd_floats": [_i32],
+    "nvp_dw_partial_floats": [_i32, _i32],
+    "nvp_mlp_param_floats": [_i32],
+    "nvp_latent_rows": [_i32],
+    "nvp_version": [],
+}
+_RESTYPES = {
+    "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64,
+    "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libnvp_hip.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run nvp_amd/csrc/build.sh "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+class NvpHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported configuration"}.get(rc, f"hipError {rc}")
+        raise NvpHipError(f"{what} failed: {kind}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor], dtype=torch.float32) -> Optional[int]:
+    """Device pointer of a contiguous HIP tensor; loud errors otherwise."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("nvp_amd kernels need tensors on a HIP device (got a CPU tensor); "
+                           "there is no CPU path in the product - move the module/inputs with .cuda()")
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def ntiles(n: int) -> int:
+    return (n + TILE - 1) // TILE
+
+
+def make_levels(cfg: dict) -> Levels:
+    """Host-side level table, same arithmetic as the reference's eval.py:28-35."""
+    lv = Levels()
+    n_levels = int(cfg["n_levels"])
+    if not 1 <= n_levels <= NVP_MAX_LEVELS:
+        raise ValueError(f"n_levels must be in [1,{NVP_MAX_LEVELS}]")
+    lv.n_levels = n_levels
+    lv.n_features = int(cfg["n_features_per_level"])
+    base = float(cfg.get("base_resolution", 16))
+    pls = float(cfg["per_level_scale"])
+    total = 0
+    for lvl in range(n_levels):
+        a = math.exp(lvl * math.log(pls)) * base - 1.0
+        res = int(math.ceil(a) + 1)
+        lv.scale[lvl] = a            # ctypes rounds the double to fp32 once
+        lv.res[lvl] = res
+        lv.offset[lvl] = total
+        total += res * res
+    lv.offset[n_levels] = total
+    return lv
+
+
+def levels_n_params(lv: Levels) -> int:
+    return int(lv.offset[lv.n_levels]) * int(lv.n_features)
+
+
+def mlp_params_struct(tensors: Sequence[torch.Tensor]) -> MlpParams:
+    """tensors in canonical order: mod_w0,mod_b0,mod_w1,mod_b1,mod_w2,mod_b2,
+    sir_w0,sir_b0,sir_w1,sir_b1,sir_w2,sir_b2,last_w,last_b."""
+    s = MlpParams()
+    for k in range(3):
+        s.mod_w[k] = ptr(tensors[2 * k])
+        s.mod_b[k] = ptr(tensors[2 * k + 1])
+        s.sir_w[k] = ptr(tensors[6 + 2 * k])
+        s.sir_b[k] = ptr(tensors[6 + 2 * k + 1])
+    s.last_w = ptr(tensors[12])
+    s.last_b = ptr(tensors[13])
+    return s

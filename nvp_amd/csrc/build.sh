@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# Build libnvp_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
+OBJS=()
+for f in encode mlp_pack mlp_fwd mlp_bwd mlp_dw harness; do
+  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$f.o" 2>/dev/null)" ] || [ ../../include/nvp_hip.h -nt "$f.o" ]; then
+    "$HIPCC" $FLAGS -c "$f.hip" -o "$f.o" &
+  fi
+  OBJS+=("$f.o")
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o libnvp_hip.so
+echo "built $(pwd)/libnvp_hip.so"

@@ -1,0 +1,499 @@
+// Grid encoders of the NVP hot path for gfx950: the three 2D multi-resolution dense
+// grids ("learnable keyframes", R1-R3) and the 3D sparse positional-feature grid
+// (R4-R7), forward gathers and gradient scatter-adds.
+//
+// These are HBM/L2-bound random-access kernels: no MFMA here.  Lanes are
+// pixels; each thread owns one (pixel, slot) pair where a slot is a group of 4 grid
+// levels of one plane (or the sparse 3x3 patch), so a wavefront works on one small set of
+// levels at a time (coarse levels stay L1/L2 resident) and has 16 independent gathers
+// in flight per lane.  Outputs go either to the reference's row-major [N, C] layout
+// (stand-alone modules) or to the pixel-tile-major (PTM) layout the MFMA MLP consumes,
+// where the 32 pixels of a tile are contiguous -> every store/load is a full 128-B line.
+//
+// Index arithmetic reproduces the reference's separately rounded fp32 ops
+// (sparsegrid.py:44-46): products and sums go through __fmul_rn/__fadd_rn so hipcc cannot
+// contract them into an FMA and flip a cell at a .5 boundary.
+#include "nvp_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLevelsPerSlot = 4;
+
+// ---- index helpers ---------------------------------------------------------------
+// clamp(int64(fp32((res-1)*c) + 0.5), 0, res-1)   reference sparsegrid.py:44-46
+__device__ __forceinline__ int nearest_idx(float c, int res) {
+    float f = __fmul_rn((float)(res - 1), c);
+    int i = (int)__fadd_rn(f, 0.5f);          // cvt truncates toward zero like .type(int64)
+    return min(max(i, 0), res - 1);
+}
+
+struct Bilerp {
+    int cell[4];     // corner cells (level-local), order (0,0),(1,0),(0,1),(1,1)
+    float w[4];
+};
+
+// Dense-grid level lookup, tiny-cuda-nn GridEncoding semantics (oracle: dense_grid_2d):
+// pos = x*scale + 0.5 (two roundings); i = floor(pos); w = pos - i;
+// cell = (ix + iy*res) mod res^2.
+__device__ __forceinline__ Bilerp bilerp_setup(float x0, float x1, float scale, int res) {
+    float p0 = __fadd_rn(__fmul_rn(x0, scale), 0.5f);
+    float p1 = __fadd_rn(__fmul_rn(x1, scale), 0.5f);
+    float f0 = floorf(p0), f1 = floorf(p1);
+    float w0 = __fsub_rn(p0, f0), w1 = __fsub_rn(p1, f1);
+    int i0 = (int)f0, i1 = (int)f1;
+    float u0 = __fsub_rn(1.0f, w0), u1 = __fsub_rn(1.0f, w1);
+    int size = res * res;
+    Bilerp b;
+    b.w[0] = __fmul_rn(u0, u1);
+    b.w[1] = __fmul_rn(w0, u1);
+    b.w[2] = __fmul_rn(u0, w1);
+    b.w[3] = __fmul_rn(w0, w1);
+    int base = i0 + i1 * res;
+    // (i0+c0) + (i1+c1)*res, wrapped into the level like tcnn's `index % hashmap_size`
+    int c00 = base, c10 = base + 1, c01 = base + res, c11 = base + res + 1;
+    b.cell[0] = c00 % size; if (b.cell[0] < 0) b.cell[0] += size;
+    b.cell[1] = c10 % size; if (b.cell[1] < 0) b.cell[1] += size;
+    b.cell[2] = c01 % size; if (b.cell[2] < 0) b.cell[2] += size;
+    b.cell[3] = c11 % size; if (b.cell[3] < 0) b.cell[3] += size;
+    return b;
+}
+
+template <int F>
+struct Vec { float v[F]; };
+
+template <int F>
+__device__ __forceinline__ Vec<F> load_vec(const float* p) {
+    Vec<F> r;
+    if constexpr (F == 2) { float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+    else if constexpr (F == 4) { float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+    else if constexpr (F == 8) {
+        float4 t = *reinterpret_cast<const float4*>(p); float4 u = *reinterpret_cast<const float4*>(p + 4);
+        r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; r.v[4] = u.x; r.v[5] = u.y; r.v[6] = u.z; r.v[7] = u.w;
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) r.v[f] = p[f];
+    }
+    return r;
+}
+
+// Output addressing: row-major [N, C] or PTM [ntiles][rows][32].
+template <bool PTM>
+__device__ __forceinline__ int64_t out_addr(int64_t px, int col, int ncols_or_rows) {
+    if constexpr (PTM) return ((px >> 5) * ncols_or_rows + col) * 32 + (px & 31);
+    else return px * ncols_or_rows + col;
+}
+
+// ---- dense 2D grid: one slot (<= 4 levels) of one plane for one pixel -------------
+template <int F, bool PTM>
+__device__ __forceinline__ void dense_slot_fwd(const float* __restrict__ params, const nvp_levels& lv,
+                                               int lvl0, float x0, float x1, bool valid,
+                                               float* __restrict__ out, int64_t px, int col0, int ncols) {
+#pragma unroll
+    for (int dl = 0; dl < kLevelsPerSlot; ++dl) {
+        int l = lvl0 + dl;
+        if (l >= lv.n_levels) break;
+        float acc[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        if (valid) {
+            Bilerp b = bilerp_setup(x0, x1, lv.scale[l], lv.res[l]);
+            const float* base = params + (int64_t)lv.offset[l] * F;
+            Vec<F> v0 = load_vec<F>(base + (int64_t)b.cell[0] * F);
+            Vec<F> v1 = load_vec<F>(base + (int64_t)b.cell[1] * F);
+            Vec<F> v2 = load_vec<F>(base + (int64_t)b.cell[2] * F);
+            Vec<F> v3 = load_vec<F>(base + (int64_t)b.cell[3] * F);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                float a = __fmul_rn(b.w[0], v0.v[f]);
+                a = __fadd_rn(a, __fmul_rn(b.w[1], v1.v[f]));
+                a = __fadd_rn(a, __fmul_rn(b.w[2], v2.v[f]));
+                a = __fadd_rn(a, __fmul_rn(b.w[3], v3.v[f]));
+                acc[f] = a;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) out[out_addr<PTM>(px, col0 + l * F + f, ncols)] = acc[f];
+    }
+}
+
+template <int F, bool PTM>
+__device__ __forceinline__ void dense_slot_bwd(float* __restrict__ dparams, const nvp_levels& lv,
+                                               int lvl0, float x0, float x1,
+                                               const float* __restrict__ dout, int64_t px, int col0, int ncols) {
+#pragma unroll
+    for (int dl = 0; dl < kLevelsPerSlot; ++dl) {
+        int l = lvl0 + dl;
+        if (l >= lv.n_levels) break;
+        float g[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { g[f] = dout[out_addr<PTM>(px, col0 + l * F + f, ncols)]; any |= (g[f] != 0.f); }
+        if (!any) continue;
+        Bilerp b = bilerp_setup(x0, x1, lv.scale[l], lv.res[l]);
+        float* base = dparams + (int64_t)lv.offset[l] * F;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float* p = base + (int64_t)b.cell[c] * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) nvp_atomic_add(p + f, b.w[c] * g[f]);
+        }
+    }
+}
+
+// ---- sparse 3x3 patch ---------------------------------------------------------------
+struct Patch {
+    int t_lo, t_hi;        // t_hi used by forward_inter only
+    float w_lo, w_hi;
+    int vx[3], vy[3];
+};
+
+__device__ __forceinline__ Patch patch_setup(float t, float x, float y, const nvp_sparse_shape& sh, bool inter) {
+    Patch p;
+    int xi = nearest_idx(x, sh.x_res), yi = nearest_idx(y, sh.y_res);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        p.vx[d] = min(max(xi + d - 1, 0), sh.x_res - 1);
+        p.vy[d] = min(max(yi + d - 1, 0), sh.y_res - 1);
+    }
+    if (!inter) {
+        p.t_lo = p.t_hi = nearest_idx(t, sh.t_res);
+        p.w_lo = 1.f; p.w_hi = 0.f;
+    } else {
+        // reference sparsegrid.py:98-109 (note: lc is divided by the UPDATED uc + lc)
+        float tf = __fmul_rn((float)(sh.t_res - 1), t);
+        int lo = (int)tf;
+        int hi = min(max((int)__fadd_rn(tf, 1.0f), 0), sh.t_res - 1);
+        float uc = __fsub_rn(tf, (float)lo);
+        float lc = __fsub_rn((float)hi, tf);
+        uc = __fdiv_rn(uc, __fadd_rn(uc, lc));
+        lc = __fdiv_rn(lc, __fadd_rn(uc, lc));
+        p.t_lo = min(max(lo, 0), sh.t_res - 1);   // reference indexes E[lo] unclamped; lo is in range for t in [0,1]
+        p.t_hi = hi;
+        p.w_lo = lc; p.w_hi = uc;
+    }
+    return p;
+}
+
+template <bool PTM>
+__device__ __forceinline__ void sparse_fwd(const float* __restrict__ emb, const nvp_sparse_shape& sh, bool inter,
+                                           float t, float x, float y, bool valid,
+                                           float* __restrict__ out, int64_t px, int col0, int ncols) {
+    const int F = sh.n_features;
+    if (!valid) {
+        for (int c = 0; c < 9 * F; ++c) out[out_addr<PTM>(px, col0 + c, ncols)] = 0.f;
+        return;
+    }
+    Patch p = patch_setup(t, x, y, sh, inter);
+    const int64_t plane = (int64_t)sh.x_res * sh.y_res;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            int64_t cell = (int64_t)p.vx[i] * sh.y_res + p.vy[j];
+            const float* lo = emb + ((int64_t)p.t_lo * plane + cell) * F;
+            const float* hi = emb + ((int64_t)p.t_hi * plane + cell) * F;
+            for (int f = 0; f < F; ++f) {
+                float v;
+                if (!inter) v = lo[f];
+                else v = __fadd_rn(__fmul_rn(lo[f], p.w_lo), __fmul_rn(hi[f], p.w_hi));
+                out[out_addr<PTM>(px, col0 + (i * 3 + j) * F + f, ncols)] = v;
+            }
+        }
+    }
+}
+
+template <bool PTM>
+__device__ __forceinline__ void sparse_bwd(float* __restrict__ demb, const nvp_sparse_shape& sh,
+                                           float t, float x, float y,
+                                           const float* __restrict__ dout, int64_t px, int col0, int ncols) {
+    const int F = sh.n_features;
+    Patch p = patch_setup(t, x, y, sh, false);
+    const int64_t plane = (int64_t)sh.x_res * sh.y_res;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            int64_t cell = (int64_t)p.vx[i] * sh.y_res + p.vy[j];
+            float* dst = demb + ((int64_t)p.t_lo * plane + cell) * F;
+            for (int f = 0; f < F; ++f) {
+                float g = dout[out_addr<PTM>(px, col0 + (i * 3 + j) * F + f, ncols)];
+                if (g != 0.f) nvp_atomic_add(dst + f, g);
+            }
+        }
+    }
+}
+
+// ---- kernels ---------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(kThreads) void dense2d_fwd_kernel(const float* __restrict__ params, const float* __restrict__ x,
+                                                               float* __restrict__ out, int64_t n, nvp_levels lv) {
+    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (px >= n) return;
+    float2 c = *reinterpret_cast<const float2*>(x + px * 2);
+    dense_slot_fwd<F, false>(params, lv, blockIdx.y * kLevelsPerSlot, c.x, c.y, true, out, px, 0, lv.n_levels * F);
+}
+
+template <int F>
+__global__ __launch_bounds__(kThreads) void dense2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                               float* __restrict__ dparams, int64_t n, nvp_levels lv) {
+    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (px >= n) return;
+    float2 c = *reinterpret_cast<const float2*>(x + px * 2);
+    dense_slot_bwd<F, false>(dparams, lv, blockIdx.y * kLevelsPerSlot, c.x, c.y, dout, px, 0, lv.n_levels * F);
+}
+
+__global__ __launch_bounds__(kThreads) void sparse_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ coords,
+                                                              float* __restrict__ out, int64_t n, nvp_sparse_shape sh, int inter) {
+    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (px >= n) return;
+    const float* c = coords + px * 3;
+    sparse_fwd<false>(emb, sh, inter != 0, c[0], c[1], c[2], true, out, px, 0, 9 * sh.n_features);
+}
+
+__global__ __launch_bounds__(kThreads) void sparse_bwd_kernel(const float* __restrict__ coords, const float* __restrict__ dout,
+                                                              float* __restrict__ demb, int64_t n, nvp_sparse_shape sh) {
+    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (px >= n) return;
+    const float* c = coords + px * 3;
+    sparse_bwd<false>(demb, sh, c[0], c[1], c[2], dout, px, 0, 9 * sh.n_features);
+}
+
+struct EncodeArgs {
+    nvp_levels lv[3];          // latent order: xy, yt, xt
+    nvp_sparse_shape sh;
+    int col0[4];               // first latent row of xy, yt, xt, sparse
+    int slots[3];              // slots per plane
+    int rows;                  // PTM rows (D rounded up to even)
+    int d;                     // latent dim
+};
+
+// slot decode: blockIdx.y in [0, slots0+slots1+slots2] ; last = sparse (+ pad rows)
+template <int F>
+__global__ __launch_bounds__(kThreads) void encode_fwd_kernel(const float* __restrict__ coords,
+                                                              const float* __restrict__ kf0, const float* __restrict__ kf1,
+                                                              const float* __restrict__ kf2, const float* __restrict__ emb,
+                                                              float* __restrict__ zt, int64_t n, int64_t npad, EncodeArgs a, int inter) {
+    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (px >= npad) return;
+    bool valid = px < n;
+    float t = 0.f, x = 0.f, y = 0.f;
+    if (valid) { const float* c = coords + px * 3; t = c[0]; x = c[1]; y = c[2]; }
+    int s = blockIdx.y;
+    if (s < a.slots[0]) {          // xy plane <- (x, y)            reference modules.py:61
+        dense_slot_fwd<F, true>(kf0, a.lv[0], s * kLevelsPerSlot, x, y, valid, zt, px, a.col0[0], a.rows);
+    } else if ((s -= a.slots[0]) < a.slots[1]) {   // yt plane <- (t, y)   modules.py:63
+        dense_slot_fwd<F, true>(kf1, a.lv[1], s * kLevelsPerSlot, t, y, valid, zt, px, a.col0[1], a.rows);
+    } else if ((s -= a.slots[1]) < a.slots[2]) {   // xt plane <- (t, x)   modules.py:62
+        dense_slot_fwd<F, true>(kf2, a.lv[2], s * kLevelsPerSlot, t, x, valid, zt, px, a.col0[2], a.rows);
+    } else {
+        sparse_fwd<true>(emb, a.sh, inter != 0, t, x, y, valid, zt, px, a.col0[3], a.rows);
+        for (int r = a.d; r < a.rows; ++r) zt[out_addr<true>(px, r, a.rows)] = 0.f;   // even-row padding
+    }
+}
+
+template <int F>
+__global__ __launch_bounds__(kThreads) void encode_bwd_kernel(const float* __restrict__ coords, const float* __restrict__ dzt,
+                                                              float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
+                                                              float* __restrict__ demb, int64_t n, EncodeArgs a) {
+    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (px >= n) return;
+    const float* c = coords + px * 3;
+    float t = c[0], x = c[1], y = c[2];
+    int s = blockIdx.y;
+    if (s < a.slots[0]) {
+        dense_slot_bwd<F, true>(d0, a.lv[0], s * kLevelsPerSlot, x, y, dzt, px, a.col0[0], a.rows);
+    } else if ((s -= a.slots[0]) < a.slots[1]) {
+        dense_slot_bwd<F, true>(d1, a.lv[1], s * kLevelsPerSlot, t, y, dzt, px, a.col0[1], a.rows);
+    } else if ((s -= a.slots[1]) < a.slots[2]) {
+        dense_slot_bwd<F, true>(d2, a.lv[2], s * kLevelsPerSlot, t, x, dzt, px, a.col0[2], a.rows);
+    } else {
+        sparse_bwd<true>(demb, a.sh, t, x, y, dzt, px, a.col0[3], a.rows);
+    }
+}
+
+// row-major [N,D] <-> PTM [ntiles][rows][32]; a block transposes a 32-pixel x 32-column
+// patch through LDS so both sides move full lines.
+__global__ __launch_bounds__(256) void rows_to_ptm_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int64_t n, int d, int rows) {
+    __shared__ float tile[32][33];
+    int64_t t = blockIdx.x;
+    int c0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows of 32
+    for (int p = ty; p < 32; p += 8) {
+        int64_t px = t * 32 + p;
+        int c = c0 + tx;
+        tile[p][tx] = (px < n && c < d) ? src[px * d + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r;
+        if (c < rows) dst[(t * rows + c) * 32 + tx] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void ptm_to_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int64_t n, int d, int rows) {
+    __shared__ float tile[32][33];
+    int64_t t = blockIdx.x;
+    int c0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r;
+        tile[r][tx] = (c < rows) ? src[(t * rows + c) * 32 + tx] : 0.f;
+    }
+    __syncthreads();
+    for (int p = ty; p < 32; p += 8) {
+        int64_t px = t * 32 + p;
+        int c = c0 + tx;
+        if (px < n && c < d) dst[px * d + c] = tile[tx][p];
+    }
+}
+
+bool levels_ok(const nvp_levels* lv) {
+    if (!lv) return false;
+    if (lv->n_levels < 1 || lv->n_levels > NVP_MAX_LEVELS) return false;
+    int f = lv->n_features;
+    return f == 1 || f == 2 || f == 4 || f == 8;
+}
+
+bool shape_ok(const nvp_sparse_shape* sh) {
+    return sh && sh->t_res >= 1 && sh->x_res >= 1 && sh->y_res >= 1 && sh->n_features >= 1 &&
+           (int64_t)sh->t_res * sh->x_res * sh->y_res * sh->n_features < (int64_t)1 << 40;
+}
+
+template <typename Fn>
+int dispatch_f(int f, Fn&& fn) {
+    switch (f) {
+        case 1: fn(std::integral_constant<int, 1>{}); return 0;
+        case 2: fn(std::integral_constant<int, 2>{}); return 0;
+        case 4: fn(std::integral_constant<int, 4>{}); return 0;
+        case 8: fn(std::integral_constant<int, 8>{}); return 0;
+    }
+    return NVP_ERR_UNSUPPORTED;
+}
+
+int make_args(EncodeArgs& a, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+              const nvp_sparse_shape* sh) {
+    if (!levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !shape_ok(sh)) return NVP_ERR_BADARG;
+    if (lv_xy->n_features != lv_yt->n_features || lv_xy->n_features != lv_xt->n_features) return NVP_ERR_UNSUPPORTED;
+    a.lv[0] = *lv_xy; a.lv[1] = *lv_yt; a.lv[2] = *lv_xt; a.sh = *sh;
+    int col = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.col0[p] = col;
+        col += a.lv[p].n_levels * a.lv[p].n_features;
+        a.slots[p] = (a.lv[p].n_levels + kLevelsPerSlot - 1) / kLevelsPerSlot;
+    }
+    a.col0[3] = col;
+    a.d = col + 9 * sh->n_features;
+    a.rows = nvp_rows_even(a.d);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvp_dense2d_fwd(const float* params, const float* x, float* out, int64_t n, const nvp_levels* lv, void* stream) {
+    if (!levels_ok(lv) || n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads), (lv->n_levels + kLevelsPerSlot - 1) / kLevelsPerSlot);
+    int rc = dispatch_f(lv->n_features, [&](auto f) {
+        hipLaunchKernelGGL((dense2d_fwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream, params, x, out, n, *lv);
+    });
+    if (rc) return rc;
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_dense2d_bwd(const float* x, const float* dout, float* dparams, int64_t n, const nvp_levels* lv, void* stream) {
+    if (!levels_ok(lv) || n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads), (lv->n_levels + kLevelsPerSlot - 1) / kLevelsPerSlot);
+    int rc = dispatch_f(lv->n_features, [&](auto f) {
+        hipLaunchKernelGGL((dense2d_bwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, dout, dparams, n, *lv);
+    });
+    if (rc) return rc;
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_sparse3x3_fwd(const float* emb, const float* coords, float* out, int64_t n, const nvp_sparse_shape* sh, void* stream) {
+    if (!shape_ok(sh) || n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sparse_fwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       emb, coords, out, n, *sh, 0);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, int64_t n, const nvp_sparse_shape* sh, void* stream) {
+    if (!shape_ok(sh) || n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sparse_fwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       emb, coords, out, n, *sh, 1);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_sparse3x3_bwd(const float* coords, const float* dout, float* demb, int64_t n, const nvp_sparse_shape* sh, void* stream) {
+    if (!shape_ok(sh) || n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       coords, dout, demb, n, *sh);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, const float* kf_xt, const float* emb,
+                   float* zt, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                   const nvp_sparse_shape* sh, int temporal_interp, void* stream) {
+    EncodeArgs a;
+    int rc = make_args(a, lv_xy, lv_yt, lv_xt, sh);
+    if (rc) return rc;
+    if (n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    int64_t npad = nvp_ntiles(n) * NVP_T;
+    dim3 grid((unsigned)((npad + kThreads - 1) / kThreads), a.slots[0] + a.slots[1] + a.slots[2] + 1);
+    rc = dispatch_f(a.lv[0].n_features, [&](auto f) {
+        hipLaunchKernelGGL((encode_fwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream,
+                           coords, kf_xy, kf_yt, kf_xt, emb, zt, n, npad, a, temporal_interp);
+    });
+    if (rc) return rc;
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_encode_bwd(const float* coords, const float* dzt, float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb,
+                   int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                   const nvp_sparse_shape* sh, void* stream) {
+    EncodeArgs a;
+    int rc = make_args(a, lv_xy, lv_yt, lv_xt, sh);
+    if (rc) return rc;
+    if (n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    dim3 grid((unsigned)((n + kThreads - 1) / kThreads), a.slots[0] + a.slots[1] + a.slots[2] + 1);
+    rc = dispatch_f(a.lv[0].n_features, [&](auto f) {
+        hipLaunchKernelGGL((encode_bwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream,
+                           coords, dzt, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, a);
+    });
+    if (rc) return rc;
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream) {
+    if (n < 0 || d < 1 || rows < d) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    dim3 grid((unsigned)nvp_ntiles(n), (rows + 31) / 32);
+    hipLaunchKernelGGL(rows_to_ptm_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream) {
+    if (n < 0 || d < 1 || rows < d) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    dim3 grid((unsigned)nvp_ntiles(n), (rows + 31) / 32);
+    hipLaunchKernelGGL(ptm_to_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

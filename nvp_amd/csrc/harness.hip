@@ -1,0 +1,76 @@
+// Device-side counterparts of the reference's training-loop glue:
+// the batch gather of dataio.py:104-120 with the video resident in HBM, and image_mse
+// (loss_functions.py:1-3 after the (x-127.5)/127.5 normalisation of training.py:47-48)
+// fused with its own gradient.
+#include "nvp_common.h"
+
+namespace {
+
+// coords = (tcoord_tab[ti], row/(H-1), col/(W-1)) with pi = row*W + col   (dataio.py:11-20,106-118)
+__global__ __launch_bounds__(256) void sample_gather_kernel(const uint8_t* __restrict__ video, const int64_t* __restrict__ ti,
+                                                            const int64_t* __restrict__ pi, const float* __restrict__ tcoord_tab,
+                                                            const float* __restrict__ tstep_tab, float* __restrict__ coords,
+                                                            float* __restrict__ steps, uint8_t* __restrict__ gt,
+                                                            int64_t n, int height, int width) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t t = ti[k], p = pi[k];
+    const int row = (int)(p / width), col = (int)(p - (int64_t)row * width);
+    coords[k * 3 + 0] = tcoord_tab[t];
+    coords[k * 3 + 1] = __fdiv_rn((float)row, (float)(height - 1));
+    coords[k * 3 + 2] = __fdiv_rn((float)col, (float)(width - 1));
+    steps[k] = tstep_tab[t];
+    const uint8_t* src = video + (t * (int64_t)height * width + p) * 3;
+    gt[k * 3 + 0] = src[0];
+    gt[k * 3 + 1] = src[1];
+    gt[k * 3 + 2] = src[2];
+}
+
+__global__ __launch_bounds__(256) void mse_u8_kernel(const float* __restrict__ rgb, const uint8_t* __restrict__ gt,
+                                                     float* __restrict__ drgb, float* __restrict__ loss_sum,
+                                                     int64_t n3, float gscale) {
+    float local = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n3; k += (int64_t)gridDim.x * 256) {
+        const float g = __fdiv_rn(__fsub_rn((float)gt[k], 127.5f), 127.5f);
+        const float df = rgb[k] - g;
+        local = __fmaf_rn(df, df, local);
+        if (drgb) drgb[k] = df * gscale;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) nvp_atomic_add(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi,
+                      const float* tcoord_tab, const float* tstep_tab,
+                      float* coords, float* steps, uint8_t* gt_u8,
+                      int64_t n, int32_t t_frames, int32_t height, int32_t width, void* stream) {
+    if (!video || !ti || !pi || !tcoord_tab || !tstep_tab || !coords || !steps || !gt_u8 || n < 0 || t_frames < 1 || height < 2 || width < 2)
+        return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       video, ti, pi, tcoord_tab, tstep_tab, coords, steps, gt_u8, n, height, width);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_mse_u8(const float* rgb, const uint8_t* gt_u8, float* drgb, float* loss_sum, int64_t n, void* stream) {
+    if (!rgb || !gt_u8 || !loss_sum || n < 0) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    const int64_t n3 = n * 3;
+    int64_t blocks = (n3 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mse_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       rgb, gt_u8, drgb, loss_sum, n3, 2.0f / (float)n3);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

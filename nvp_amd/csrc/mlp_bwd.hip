@@ -1,0 +1,168 @@
+// Backward of the modulator MLP + modulated SIREN w.r.t. activations (the "dX chain" of
+// R12): from dL/drgb produce the latent gradient and the nine per-pixel streams the
+// weight-gradient GEMMs (mlp_dw.hip) contract over the pixel axis.
+//
+// Same structure as mlp_fwd.hip: one wavefront = one 32-pixel tile, every transposed GEMM
+//   dX[in][pixel] = sum_out W[out][in] * dY[out][pixel]
+// runs on v_mfma_f32_32x32x2_f32 with A = packed W^T stream and B = the dY registers that
+// the previous stage just produced.  The kernel runs one wave per SIMD (512 registers) so
+// dq/dp of a layer, two 64-register accumulators and the latent-gradient accumulator all
+// stay resident; nothing is staged through LDS.
+//
+// Chain (forward names: p_k modulator pre-activation, h_k = lrelu(p_k), q_k SIREN
+// pre-sine, x_k = sin(q_k) h_k, q_0 = 30 (w s + c)):
+//   dx2 = V3^T drgb
+//   dq_k = dx_k h_k cos(q_k);  dh_k (+)= dx_k sin(q_k);  dp_k = dh_k lrelu'(p_k)
+//   dx_{k-1} = V_k^T dq_k;     dh_{k-1} = W_k[:, :128]^T dp_k;   dz += W_k[:, 128:]^T dp_k
+// Bound: fp32 MFMA; 219 392 FLOP/px (nvp_s) + HBM streams 2.5 KB/px in, 5.1 KB/px out.
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int kWaves = 4;
+
+template <int ZT>
+__global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
+                                                                    const float* __restrict__ saved, nvp_mlp_params p,
+                                                                    const float* __restrict__ packed,
+                                                                    float* __restrict__ dy, float* __restrict__ xs,
+                                                                    float* __restrict__ dzt, int64_t n, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;                       // wave-uniform
+    const int j = lane & 31, h = lane >> 5;
+    const NvpBwdLayout L = nvp_bwd_layout(d);
+    const int rows = nvp_rows_even(d);
+    const int64_t px = tile * 32 + j;
+    const bool valid = px < n;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    const int64_t tb = tile * (int64_t)NVP_H * 32;
+    const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
+    float* dyt = dy + tb;                  // dp0,dp1,dp2,dq0s,dq1,dq2
+    float* xst = xs + tb;                  // x0,x1,x2
+    const float4* wp = reinterpret_cast<const float4*>(packed);
+
+    f32x16 dz[ZT];
+#pragma unroll
+    for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
+
+    f32x16 dx[4], dh[4], dq[4], dp[4];
+
+    // ---- last layer: dx2 = V3^T drgb (VALU, 3 terms)
+    {
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (valid) { g0 = drgb[px * 3 + 0]; g1 = drgb[px * 3 + 1]; g2 = drgb[px * 3 + 2]; }
+        const float* w3 = p.last_w;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                dx[T][r] = __fmaf_rn(w3[2 * NVP_H + row], g2, __fmaf_rn(w3[NVP_H + row], g1, w3[row] * g0));
+            }
+            nvp_pin(dx[T]);
+            NVP_LOAD_FENCE();
+        }
+#pragma unroll
+        for (int T = 0; T < 4; ++T) dh[T] = nvp_zero16();
+    }
+
+    // ---- layers 2, 1: element-wise stage then the three transposed GEMMs
+#pragma unroll
+    for (int k = 2; k >= 1; --k) {
+        const float* hk = sv + (int64_t)k * act;
+        const float* qk = sv + (int64_t)(2 + k) * act;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 hv, qv, xv;
+            load_ptm16(hv, hk, T, lane);
+            load_ptm16(qv, qk, T, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sn, cs;
+                nvp_sincos(qv[r], sn, cs);
+                const float dxv = dx[T][r];
+                xv[r] = sn * hv[r];
+                dq[T][r] = dxv * hv[r] * cs;
+                const float dhv = dh[T][r] + dxv * sn;
+                dp[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
+            }
+            nvp_pin(dq[T]);
+            nvp_pin(dp[T]);
+            store_ptm16(xst + (int64_t)k * act, xv, T, lane);
+            store_ptm16(dyt + (int64_t)(3 + k) * act, dq[T], T, lane);
+            store_ptm16(dyt + (int64_t)k * act, dp[T], T, lane);
+            NVP_LOAD_FENCE();
+        }
+        // dx_{k-1} = V_k^T dq_k ; dh_{k-1} = W_k[:, :128]^T dp_k ; dz += W_k[:, 128:]^T dp_k
+#pragma unroll
+        for (int T = 0; T < 4; ++T) { dx[T] = nvp_zero16(); dh[T] = nvp_zero16(); }
+        chain_h(dx, dq, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
+        chain_h(dh, dp, wp + L.off[4 - k] / 4, lane);          // streams 2 (mod2h^T), 3 (mod1h^T)
+        chain_hz<ZT>(dz, dp, packed + L.off[4 + k], lane);     // streams 6 (z2^T), 5 (z1^T)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) { nvp_pin(dx[T]); nvp_pin(dh[T]); }
+    }
+
+    // ---- layer 0: q0 = 30 (w s + c) is recomputed
+    {
+        const float s = valid ? steps[px] : 0.f;
+        const float* w0 = p.sir_w[0];
+        const float* c0 = p.sir_b[0];
+        const float* h0 = sv;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 hv, xv, dq0;
+            load_ptm16(hv, h0, T, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                const float q = 30.0f * __fmaf_rn(s, w0[row], c0[row]);
+                float sn, cs;
+                nvp_sincos(q, sn, cs);
+                const float dxv = dx[T][r];
+                xv[r] = sn * hv[r];
+                dq0[r] = 30.0f * (dxv * hv[r] * cs);          // gradient w.r.t. (w s + c)
+                const float dhv = dh[T][r] + dxv * sn;
+                dp[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
+            }
+            nvp_pin(dp[T]);
+            store_ptm16(xst, xv, T, lane);
+            store_ptm16(dyt + 3 * act, dq0, T, lane);
+            store_ptm16(dyt, dp[T], T, lane);
+            NVP_LOAD_FENCE();
+        }
+        chain_hz<ZT>(dz, dp, packed + L.off[4], lane);         // stream 4 (z0^T)
+    }
+
+    // ---- latent gradient out (PTM, rows = D rounded up to even)
+    {
+        float* o = dzt + tile * (int64_t)rows * 32;
+#pragma unroll
+        for (int T = 0; T < ZT; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                if (row < rows) o[row * 32 + j] = dz[T][r];
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
+                              const float* packed_bwd, float* dy, float* xs, float* dzt, int64_t n, int32_t d, void* stream) {
+    if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !xs || !dzt || n < 0 || d < 1) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    const int64_t ntiles = nvp_ntiles(n);
+    const int zt = nvp_bwd_layout(d).zt;
+    dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    if (zt == 4)
+        hipLaunchKernelGGL(mlp_bwd_dx_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dzt, n, ntiles, d);
+    else if (zt == 8)
+        hipLaunchKernelGGL(mlp_bwd_dx_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dzt, n, ntiles, d);
+    else
+        return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
+    NVP_LAUNCH_CHECK();
+    return 0;
+}

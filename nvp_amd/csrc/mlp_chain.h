@@ -1,0 +1,129 @@
+// MFMA chain helpers shared by the forward and backward MLP kernels (see mlp_fwd.hip for
+// the design: pixel on the MFMA column axis, D registers of one layer = B operands of the next).
+#pragma once
+#include "mlp_layout.h"
+
+__device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4 a, const float b) {
+    acc[0] = nvp_mfma(a.x, b, acc[0]);
+    acc[1] = nvp_mfma(a.y, b, acc[1]);
+    acc[2] = nvp_mfma(a.z, b, acc[2]);
+    acc[3] = nvp_mfma(a.w, b, acc[3]);
+}
+
+// Operand loads are software-pipelined by hand in groups of G k-steps (double-buffered in
+// registers); the empty asm with a memory clobber stops hipcc from hoisting every load of
+// the unrolled chain to the top (which costs >100 VGPRs and spills).
+constexpr int G = 4;
+#define NVP_LOAD_FENCE() asm volatile("" ::: "memory")
+
+// 64 chained steps: B operands are the previous layer's D registers.
+__device__ __forceinline__ void chain_h(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float4* __restrict__ wp, int lane) {
+    float4 a[2][G];
+    const float4* w = wp + lane;
+#pragma unroll
+    for (int i = 0; i < G; ++i) a[0][i] = w[i * 64];
+#pragma unroll
+    for (int g = 0; g < 64 / G; ++g) {
+        if (g + 1 < 64 / G) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = w[((g + 1) * G + i) * 64];
+        }
+        NVP_LOAD_FENCE();
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int step = g * G + i;
+            mfma4(acc, a[g & 1][i], hin[step >> 4][step & 15]);
+        }
+    }
+}
+
+// zs steps over the latent: step u consumes rows 2u (lane half 0) and 2u+1 (half 1).
+__device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float* __restrict__ z, int zs,
+                                        const float4* __restrict__ wp, int lane) {
+    const float* zl = z + (lane >> 5) * 32 + (lane & 31);
+    const float4* w = wp + lane;
+    const int ng = zs / G;
+    float4 a[G], an[G];
+    float b[G], bn[G];
+    if (ng > 0) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) { a[i] = w[i * 64]; b[i] = zl[i * 64]; }
+    }
+    for (int g = 0; g < ng; ++g) {
+        if (g + 1 < ng) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) { an[i] = w[((g + 1) * G + i) * 64]; bn[i] = zl[((g + 1) * G + i) * 64]; }
+        }
+        NVP_LOAD_FENCE();
+#pragma unroll
+        for (int i = 0; i < G; ++i) mfma4(acc, a[i], b[i]);
+#pragma unroll
+        for (int i = 0; i < G; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+    }
+    for (int u = ng * G; u < zs; ++u) mfma4(acc, w[u * 64], zl[u * 64]);
+}
+
+__device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[T][r] = v[T][r] > 0.f ? v[T][r] : v[T][r] * 0.01f;
+}
+
+__device__ __forceinline__ void store_ptm(float* __restrict__ tile_base, const f32x16 (&v)[4], int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile_base[(32 * T + nvp_frag_row(r, h)) * 32 + j] = v[T][r];
+}
+
+
+// One 64-step chain whose output has ZT 32-row tiles (latent gradient): the packed stream
+// holds ZT floats per lane and step.
+template <int ZT>
+__device__ __forceinline__ void chain_hz(f32x16 (&acc)[ZT], const f32x16 (&hin)[4], const float* __restrict__ wp, int lane) {
+    constexpr int Q = ZT / 4;                     // float4 per lane per step
+    const float4* w = reinterpret_cast<const float4*>(wp) + lane * Q;
+    constexpr int GZ = 2;
+    float4 a[2][GZ][Q];
+#pragma unroll
+    for (int i = 0; i < GZ; ++i)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) a[0][i][q] = w[i * 64 * Q + q];
+#pragma unroll
+    for (int g = 0; g < 64 / GZ; ++g) {
+        if (g + 1 < 64 / GZ) {
+#pragma unroll
+            for (int i = 0; i < GZ; ++i)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) a[(g + 1) & 1][i][q] = w[((g + 1) * GZ + i) * 64 * Q + q];
+        }
+        NVP_LOAD_FENCE();
+#pragma unroll
+        for (int i = 0; i < GZ; ++i) {
+            const int step = g * GZ + i;
+            const float b = hin[step >> 4][step & 15];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                acc[4 * q + 0] = nvp_mfma(a[g & 1][i][q].x, b, acc[4 * q + 0]);
+                acc[4 * q + 1] = nvp_mfma(a[g & 1][i][q].y, b, acc[4 * q + 1]);
+                acc[4 * q + 2] = nvp_mfma(a[g & 1][i][q].z, b, acc[4 * q + 2]);
+                acc[4 * q + 3] = nvp_mfma(a[g & 1][i][q].w, b, acc[4 * q + 3]);
+            }
+        }
+    }
+}
+
+// Load one 16-row block (tile T) of a PTM activation into fragment registers.
+__device__ __forceinline__ void load_ptm16(f32x16& v, const float* __restrict__ tile_base, int T, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = tile_base[(32 * T + nvp_frag_row(r, h)) * 32 + j];
+}
+
+__device__ __forceinline__ void store_ptm16(float* __restrict__ tile_base, const f32x16& v, int T, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile_base[(32 * T + nvp_frag_row(r, h)) * 32 + j] = v[r];
+}

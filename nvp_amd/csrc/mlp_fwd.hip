@@ -1,0 +1,146 @@
+// Fused forward of the modulator MLP + modulated SIREN (R8-R10) on fp32 MFMA.
+//
+// One wavefront owns one tile of 32 pixels for the whole 7-layer network.  Every GEMM is
+// computed as  D[out feature][pixel] = sum_k W[out][k] * act[k][pixel]  with
+// v_mfma_f32_32x32x2_f32: A = packed weight stream (global, L2-resident, one coalesced
+// 1-KiB dwordx4 load feeds four MFMAs), B = activations.  Because the pixel sits on the
+// MFMA column (lane) axis on both sides, the 64 D registers of a layer are consumed
+// as-is as the next layer's B operands: activations never leave the register file,
+// nothing goes through LDS, there is no barrier in the kernel.
+// The latent z (B operand of the three modulator layers) streams from the PTM tensor
+// written by the encoder: step u reads rows 2u and 2u+1 = one 256-B line pair per wave.
+//
+// fp32 MFMA is bit-equal to an ordered fmaf chain, so results differ from the CPU oracle
+// only by summation order (<= 1e-5 on RGB is asserted in tests/).
+//
+// Bound: fp32 MFMA (157.3 TFLOP/s).  Algorithmic work: 219 648 FLOP/px (nvp_s).
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int kWaves = 4;
+
+template <bool SAVE>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __restrict__ zt, const float* __restrict__ steps,
+                                                                 nvp_mlp_params p, const float* __restrict__ packed,
+                                                                 float* __restrict__ rgb, float* __restrict__ saved,
+                                                                 int64_t n, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;                       // wave-uniform
+    const int j = lane & 31, h = lane >> 5;
+    const NvpFwdLayout L = nvp_fwd_layout(d);
+    const float* z = zt + tile * (int64_t)(2 * L.zs) * 32;
+    const float4* wp = reinterpret_cast<const float4*>(packed);
+    const int64_t px = tile * 32 + j;
+    const float s = px < n ? steps[px] : 0.f;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;    // floats per saved activation
+    float* sv = SAVE ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
+
+    f32x16 hm[4];       // current modulator hidden h_k
+    f32x16 x[4];        // current SIREN activation x_k
+    f32x16 acc[4];
+
+    // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
+    {
+        const float4* w = wp + L.off[0] / 4;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
+        mfma4(hm, w[lane], 1.0f);
+        chain_z(hm, z, L.zs, w + 64, lane);
+        lrelu4(hm);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
+        if (SAVE) store_ptm(sv + 0 * act, hm, lane);
+    }
+    // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
+    {
+        const float* w0 = p.sir_w[0];
+        const float* c0 = p.sir_b[0];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                const float q = 30.0f * __fmaf_rn(s, w0[row], c0[row]);
+                x[T][r] = nvp_sin(q) * hm[T][r];
+            }
+            nvp_pin(x[T]);           // finish this 16-row block here: keeps the table loads of
+            NVP_LOAD_FENCE();        // later blocks from piling up in registers
+        }
+    }
+    // ---- layers 1 and 2
+#pragma unroll
+    for (int k = 1; k <= 2; ++k) {
+        // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
+        {
+            const float4* w = wp + L.off[k] / 4;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            mfma4(acc, w[lane], 1.0f);
+            chain_h(acc, hm, w + 64, lane);
+            chain_z(acc, z, L.zs, w + 65 * 64, lane);
+            lrelu4(acc);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
+            if (SAVE) store_ptm(sv + (int64_t)k * act, hm, lane);
+        }
+        // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
+        {
+            const float4* w = wp + L.off[2 + k] / 4;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            mfma4(acc, w[lane], 1.0f);
+            chain_h(acc, x, w + 64, lane);
+            if (SAVE) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[T][r] = nvp_sin(acc[T][r]) * hm[T][r];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) nvp_pin(x[T]);
+        }
+    }
+    // ---- last layer (3 x 128, Identity): VALU dot products + cross-half add
+    {
+        const float* w3 = p.last_w;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                const float v = x[T][r];
+                o0 = __fmaf_rn(w3[row], v, o0);
+                o1 = __fmaf_rn(w3[NVP_H + row], v, o1);
+                o2 = __fmaf_rn(w3[2 * NVP_H + row], v, o2);
+            }
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
+            NVP_LOAD_FENCE();
+        }
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        if (h == 0 && px < n) {
+            rgb[px * 3 + 0] = o0 + p.last_b[0];
+            rgb[px * 3 + 1] = o1 + p.last_b[1];
+            rgb[px * 3 + 2] = o2 + p.last_b[2];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
+                           float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
+    if (!zt || !steps || !p || !packed_fwd || !rgb || n < 0 || d < 1) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    const int64_t ntiles = nvp_ntiles(n);
+    dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    if (saved)
+        hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
+    else
+        hipLaunchKernelGGL(mlp_fwd_kernel<false>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}

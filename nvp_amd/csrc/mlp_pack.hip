@@ -1,0 +1,99 @@
+// Re-lay the 14 MLP tensors out as MFMA A-operand streams (see mlp_layout.h).
+// ~0.5 MB per call, one thread per packed float; runs once per optimizer step.
+#include "mlp_layout.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pack_fwd_kernel(nvp_mlp_params p, float* __restrict__ out, int d) {
+    const NvpFwdLayout L = nvp_fwd_layout(d);
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L.off[5]) return;
+    int seg = 0;
+    while (idx >= L.off[seg + 1]) ++seg;
+    int64_t loc = idx - L.off[seg];
+    int tp = (int)(loc & 3);
+    int lane = (int)((loc >> 2) & 63);
+    int step = (int)(loc >> 8);
+    int i = lane & 31, h = lane >> 5;
+    int out_row = 32 * tp + i;
+
+    const float* W; const float* b; int ld; bool has_h, has_z;
+    switch (seg) {
+        case 0: W = p.mod_w[0]; b = p.mod_b[0]; ld = d; has_h = false; has_z = true; break;
+        case 1: W = p.mod_w[1]; b = p.mod_b[1]; ld = NVP_H + d; has_h = true; has_z = true; break;
+        case 2: W = p.mod_w[2]; b = p.mod_b[2]; ld = NVP_H + d; has_h = true; has_z = true; break;
+        case 3: W = p.sir_w[1]; b = p.sir_b[1]; ld = NVP_H; has_h = true; has_z = false; break;
+        default: W = p.sir_w[2]; b = p.sir_b[2]; ld = NVP_H; has_h = true; has_z = false; break;
+    }
+    float v = 0.f;
+    if (step == 0) {
+        v = (h == 0) ? b[out_row] : 0.f;
+    } else {
+        int s = step - 1;
+        if (has_h && s < 64) {
+            v = W[(int64_t)out_row * ld + nvp_chain_k(s, h)];
+        } else {
+            int u = has_h ? s - 64 : s;
+            int in = 2 * u + h;
+            if (has_z && in < d) v = W[(int64_t)out_row * ld + (has_h ? NVP_H : 0) + in];
+        }
+    }
+    out[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* __restrict__ out, int d) {
+    const NvpBwdLayout L = nvp_bwd_layout(d);
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L.off[7]) return;
+    int seg = 0;
+    while (idx >= L.off[seg + 1]) ++seg;
+    int64_t loc = idx - L.off[seg];
+    int per = (seg < 4) ? 4 : L.zt;
+    int tp = (int)(loc % per);
+    int64_t rest = loc / per;
+    int lane = (int)(rest & 63);
+    int step = (int)(rest >> 6);
+    int i = lane & 31, h = lane >> 5;
+    int in = 32 * tp + i;                 // A row = input index
+    int o = nvp_chain_k(step, h);         // k = output index
+    float v = 0.f;
+    switch (seg) {
+        case 0: v = p.sir_w[2][(int64_t)o * NVP_H + in]; break;
+        case 1: v = p.sir_w[1][(int64_t)o * NVP_H + in]; break;
+        case 2: v = p.mod_w[2][(int64_t)o * (NVP_H + d) + in]; break;
+        case 3: v = p.mod_w[1][(int64_t)o * (NVP_H + d) + in]; break;
+        case 4: if (in < d) v = p.mod_w[0][(int64_t)o * d + in]; break;
+        case 5: if (in < d) v = p.mod_w[1][(int64_t)o * (NVP_H + d) + NVP_H + in]; break;
+        default: if (in < d) v = p.mod_w[2][(int64_t)o * (NVP_H + d) + NVP_H + in]; break;
+    }
+    out[idx] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t nvp_packed_fwd_floats(int32_t d) { return nvp_fwd_layout(d).off[5]; }
+int64_t nvp_packed_bwd_floats(int32_t d) { return nvp_bwd_layout(d).off[7]; }
+int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
+int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) { return nvp_param_layout(d).total * (int64_t)n_chunks; }
+int32_t nvp_latent_rows(int32_t d) { return nvp_rows_even(d); }
+const char* nvp_version(void) { return "nvp_hip 0.1 (gfx950)"; }
+
+int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
+    if (!p || !packed || d < 1) return NVP_ERR_BADARG;
+    int64_t n = nvp_fwd_layout(d).off[5];
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, packed, d);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
+    if (!p || !packed || d < 1) return NVP_ERR_BADARG;
+    int64_t n = nvp_bwd_layout(d).off[7];
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, packed, d);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

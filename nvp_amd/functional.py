@@ -1,0 +1,245 @@
+"""torch.autograd.Function wrappers around the HIP kernels (autograd contract).
+
+Every function enqueues hand-written gfx950 kernels from libnvp_hip.so on the current
+HIP stream; PyTorch only owns the memory and the autograd tape.  Backward returns dense
+fp32 gradients with the parameters' shapes (what torch.optim.AdamW consumes), and `None`
+for coordinates / temporal steps, exactly like the reference's autograd graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def dw_chunks(n: int) -> int:
+    """Number of pixel chunks of the split-K weight-gradient GEMMs."""
+    return max(1, min(128, L.ntiles(n) // 8))
+
+
+# --------------------------------------------------------------------------------------
+# tinycudann.Encoding  (R2 / R3)
+# --------------------------------------------------------------------------------------
+class DenseGrid2D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, params: torch.Tensor, levels: L.Levels) -> torch.Tensor:
+        lib = L.load()
+        x = _f32c(x)
+        params = _f32c(params)
+        if x.dim() != 2 or x.shape[1] != 2:
+            raise RuntimeError(f"Encoding expects [N,2] inputs, got {tuple(x.shape)}")
+        if params.numel() != L.levels_n_params(levels):
+            raise RuntimeError("params has the wrong length for this encoding_config")
+        n = x.shape[0]
+        out = torch.empty((n, levels.n_levels * levels.n_features), device=x.device, dtype=torch.float32)
+        L.check(lib.nvp_dense2d_fwd(L.ptr(params), L.ptr(x), L.ptr(out), n, C.byref(levels), L.stream_ptr()), "nvp_dense2d_fwd")
+        ctx.levels = levels
+        ctx.save_for_backward(x, params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        lib = L.load()
+        x, params = ctx.saved_tensors
+        dparams = torch.zeros_like(params)
+        dout = _f32c(dout)
+        L.check(lib.nvp_dense2d_bwd(L.ptr(x), L.ptr(dout), L.ptr(dparams), x.shape[0], C.byref(ctx.levels), L.stream_ptr()),
+                "nvp_dense2d_bwd")
+        return None, dparams, None
+
+
+# --------------------------------------------------------------------------------------
+# SparseGrid  (R5 / R6 / R7)
+# --------------------------------------------------------------------------------------
+def _sparse_shape(emb: torch.Tensor) -> L.SparseShape:
+    if emb.dim() != 4:
+        raise RuntimeError("embeddings must be [T, X, Y, F]")
+    T, X, Y, F = emb.shape
+    return L.SparseShape(T, X, Y, F)
+
+
+class SparseGrid3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs: torch.Tensor, emb: torch.Tensor, inter: bool) -> torch.Tensor:
+        lib = L.load()
+        inputs = _f32c(inputs)
+        emb = _f32c(emb)
+        if inputs.dim() != 2 or inputs.shape[1] != 3:
+            raise RuntimeError(f"SparseGrid expects [N,3] inputs (t,x,y), got {tuple(inputs.shape)}")
+        sh = _sparse_shape(emb)
+        n = inputs.shape[0]
+        out = torch.empty((n, 9 * sh.n_features), device=inputs.device, dtype=torch.float32)
+        fn = lib.nvp_sparse3x3_inter_fwd if inter else lib.nvp_sparse3x3_fwd
+        L.check(fn(L.ptr(emb), L.ptr(inputs), L.ptr(out), n, C.byref(sh), L.stream_ptr()), "nvp_sparse3x3_fwd")
+        ctx.inter = inter
+        ctx.sh = sh
+        ctx.save_for_backward(inputs, emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        if ctx.inter:
+            raise NotImplementedError("forward_inter is an inference-only path (reference eval.py --t_interp)")
+        lib = L.load()
+        inputs, emb = ctx.saved_tensors
+        demb = torch.zeros_like(emb)
+        dout = _f32c(dout)
+        L.check(lib.nvp_sparse3x3_bwd(L.ptr(inputs), L.ptr(dout), L.ptr(demb), inputs.shape[0], C.byref(ctx.sh), L.stream_ptr()),
+                "nvp_sparse3x3_bwd")
+        return None, demb, None
+
+
+# --------------------------------------------------------------------------------------
+# MLP core shared by SirenWrapper and the fused NVP function
+# --------------------------------------------------------------------------------------
+def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tensor], n: int, d: int, save: bool):
+    lib = L.load()
+    dev = zt.device
+    if n == 0:
+        return torch.empty((0, 3), device=dev, dtype=torch.float32), None
+    stream = L.stream_ptr()
+    pstruct = L.mlp_params_struct(mlp)
+    packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
+    L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_fwd")
+    rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+    saved = torch.empty((5, L.ntiles(n), L.HIDDEN, L.TILE), device=dev, dtype=torch.float32) if save else None
+    L.check(lib.nvp_mlp_fwd(L.ptr(zt), L.ptr(steps), C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), n, d, stream),
+            "nvp_mlp_fwd")
+    return rgb, saved
+
+
+def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, saved: torch.Tensor,
+                  mlp: Sequence[torch.Tensor], n: int, d: int) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    lib = L.load()
+    dev = zt.device
+    stream = L.stream_ptr()
+    nt = L.ntiles(n)
+    pstruct = L.mlp_params_struct(mlp)
+    packed = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32)
+    L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
+    dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
+    xs = torch.empty((3, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
+    dzt = torch.empty_like(zt)
+    drgb = _f32c(drgb)
+    L.check(lib.nvp_mlp_bwd_dx(L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
+                               L.ptr(dy), L.ptr(xs), L.ptr(dzt), n, d, stream), "nvp_mlp_bwd_dx")
+    grads = [torch.empty_like(t) for t in mlp]
+    gstruct = L.mlp_params_struct(grads)
+    nch = dw_chunks(n)
+    partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
+    L.check(lib.nvp_mlp_bwd_dw(L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), L.ptr(xs),
+                               L.ptr(partials), nch, C.byref(gstruct), n, d, stream), "nvp_mlp_bwd_dw")
+    return dzt, grads
+
+
+def _check_mlp(mlp: Sequence[torch.Tensor], d: int) -> None:
+    H = L.HIDDEN
+    want = [(H, d), (H,), (H, H + d), (H,), (H, H + d), (H,), (H, 1), (H,), (H, H), (H,), (H, H), (H,), (3, H), (3,)]
+    if len(mlp) != 14:
+        raise RuntimeError("expected 14 MLP tensors")
+    for t, w in zip(mlp, want):
+        if tuple(t.shape) != w:
+            raise RuntimeError(f"MLP tensor has shape {tuple(t.shape)}, kernels are specialised for {w} "
+                               "(n_neurons=128, n_hidden_layers=3, dim_out=3)")
+
+
+class ModulatedSiren(torch.autograd.Function):
+    """SirenWrapper.forward(coords=steps [N,1], latent [N,D]) -> [N,3]  (R8-R10, R12)."""
+
+    @staticmethod
+    def forward(ctx, latent: torch.Tensor, steps: torch.Tensor, *mlp: torch.Tensor) -> torch.Tensor:
+        lib = L.load()
+        latent = _f32c(latent)
+        n, d = latent.shape
+        steps = _f32c(steps).reshape(-1)
+        if steps.numel() != n:
+            raise RuntimeError("coords and latent disagree on the batch size")
+        mlp = [_f32c(t) for t in mlp]
+        _check_mlp(mlp, d)
+        rows = lib.nvp_latent_rows(d)
+        zt = torch.empty((L.ntiles(n), rows, L.TILE), device=latent.device, dtype=torch.float32)
+        if n:
+            L.check(lib.nvp_rows_to_ptm(L.ptr(latent), L.ptr(zt), n, d, rows, L.stream_ptr()), "nvp_rows_to_ptm")
+        need_grad = any(ctx.needs_input_grad)
+        rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
+        ctx.n, ctx.d, ctx.rows = n, d, rows
+        if need_grad:
+            if saved is None:
+                saved = torch.empty(0, device=latent.device)
+            ctx.save_for_backward(zt, steps, saved, *mlp)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb: torch.Tensor):
+        lib = L.load()
+        zt, steps, saved, *mlp = ctx.saved_tensors
+        n, d = ctx.n, ctx.d
+        if n == 0:
+            return (torch.zeros((0, d), device=zt.device), None, *[torch.zeros_like(t) for t in mlp])
+        dzt, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
+        dlat = torch.empty((n, d), device=zt.device, dtype=torch.float32)
+        L.check(lib.nvp_ptm_to_rows(L.ptr(dzt), L.ptr(dlat), n, d, ctx.rows, L.stream_ptr()), "nvp_ptm_to_rows")
+        return (dlat, None, *grads)
+
+
+class NVPFused(torch.autograd.Function):
+    """NVP.forward hot path (R11): coords [N,3], steps [N] -> rgb [N,3] in four kernels
+    (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""
+
+    @staticmethod
+    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, *mlp):
+        lib = L.load()
+        coords = _f32c(coords)
+        steps = _f32c(steps).reshape(-1)
+        kf_xy, kf_yt, kf_xt, emb = _f32c(kf_xy), _f32c(kf_yt), _f32c(kf_xt), _f32c(emb)
+        mlp = [_f32c(t) for t in mlp]
+        n = coords.shape[0]
+        sh = _sparse_shape(emb)
+        for kf, lv in ((kf_xy, lv_xy), (kf_yt, lv_yt), (kf_xt, lv_xt)):
+            if kf.numel() != L.levels_n_params(lv):
+                raise RuntimeError("keyframe params have the wrong length for their encoding_config")
+        d = sum(lv.n_levels * lv.n_features for lv in (lv_xy, lv_yt, lv_xt)) + 9 * sh.n_features
+        _check_mlp(mlp, d)
+        rows = lib.nvp_latent_rows(d)
+        dev = coords.device
+        zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32)
+        if n:
+            L.check(lib.nvp_encode_fwd(L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
+                                       C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
+                                       1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_fwd")
+        need_grad = any(ctx.needs_input_grad)
+        rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
+        if need_grad:
+            if temporal_interp:
+                raise NotImplementedError("temporal_interp=True is an inference-only path (reference eval.py --t_interp)")
+            ctx.n, ctx.d = n, d
+            ctx.lv = (lv_xy, lv_yt, lv_xt)
+            ctx.sh = sh
+            if saved is None:
+                saved = torch.empty(0, device=dev)
+            ctx.save_for_backward(coords, steps, zt, saved, kf_xy, kf_yt, kf_xt, emb, *mlp)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb):
+        lib = L.load()
+        coords, steps, zt, saved, kf_xy, kf_yt, kf_xt, emb, *mlp = ctx.saved_tensors
+        n, d = ctx.n, ctx.d
+        d_xy, d_yt, d_xt, d_emb = (torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb))
+        if n == 0:
+            return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
+        dzt, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
+        lv = ctx.lv
+        L.check(lib.nvp_encode_bwd(L.ptr(coords), L.ptr(dzt), L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
+                                   C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.stream_ptr()),
+                "nvp_encode_bwd")
+        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *grads)

@@ -1,0 +1,42 @@
+"""SparseGrid - the 3D sparse positional-feature grid (reference sparsegrid.py:4-156).
+
+Same constructor, parameter name (`embeddings` [T,X,Y,F]), init (U(-1e-4,1e-4),
+sparsegrid.py:19-21) and methods (`forward`, `forward_inter`) as the reference; the gather
+and its gradient scatter-add run in libnvp_hip.so (nvp_sparse3x3_*).  `embeddings` is read
+at call time (eval.py:179 rebinds it).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .functional import SparseGrid3x3
+
+
+class SparseGrid(nn.Module):
+    def __init__(self, level_dim=2, x_resolution=300, y_resolution=300, t_resolution=600, upsample=False):
+        super().__init__()
+        self.level_dim = level_dim
+        self.x_resolution = x_resolution
+        self.y_resolution = y_resolution
+        self.t_resolution = t_resolution
+        self.embeddings = nn.Parameter(torch.empty(t_resolution, x_resolution, y_resolution, level_dim))
+        self.upsample = upsample
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def _grid(self) -> torch.Tensor:
+        if self.upsample:
+            # reference sparsegrid.py:26-34 (x2 bilinear pre-upsample of the whole grid every
+            # call).  Both shipped configs set "upsample": false; SURVEY 8f-N4 ranks it last.
+            raise NotImplementedError("SparseGrid(upsample=True) is not implemented on the HIP path yet")
+        return self.embeddings
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        return SparseGrid3x3.apply(inputs, self._grid(), False)
+
+    def forward_inter(self, inputs: torch.Tensor) -> torch.Tensor:
+        return SparseGrid3x3.apply(inputs, self._grid(), True)
