@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py - Mpixels/s of NVP's per-coordinate encoding path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimisation iteration of the reference's loop (training.py:42-76) over
+one batch of N = 1 245 184 synthetic (t, x, y) samples of a 1920x1080x600 video
+(BASELINE.json configs[1], config_nvp_s): on-device sampler + gt gather, NVP forward
+(grid gathers -> MFMA MLP), fused MSE, backward (MFMA dX chain, split-K dW GEMMs, grid
+scatter-add), for N>1 ONE all-reduce of the flat 543 MB gradient over RCCL, AdamW + cosine.
+Nothing is skipped inside the timed region.  Each rank keeps the full per-GPU batch (weak
+scaling); value = world * N pixels / max-over-ranks step time.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  "roofline":     dominant kernel's algorithmic FLOP (or bytes) per launch / its HIP-event
+                  duration inside the timed region, vs the gfx950 peak;
+  "cpu_baseline": the oracle (pure-PyTorch CPU port of the reference path) timed on this
+                  host's cores on a bounded sample of the same workload (N=1 run only);
+  "kernels":      mean ms of every hot-path kernel stage, "fwd_bwd_mpx_s": hot path only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CONFIG_NVP_S = {  # values of the reference's config/config_nvp_s.json
+    "2d_encoding_xy": {"otype": "DenseGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 32,
+                       "base_resolution": 16, "per_level_scale": 1.35},
+    "2d_encoding_xt": {"otype": "DenseGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 32,
+                       "base_resolution": 16, "per_level_scale": 1.35},
+    "2d_encoding_yt": {"otype": "DenseGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 32,
+                       "base_resolution": 16, "per_level_scale": 1.35},
+    "3d_encoding": {"otype": "SparseGrid", "n_features_per_level": 2, "x_resolution": 300, "y_resolution": 300,
+                    "t_resolution": 600, "upsample": False},
+    "network": {"n_neurons": 128, "n_hidden_layers": 3},
+}
+VIDEO = (600, 1080, 1920)       # T, H, W  (UVG-HD Jockey geometry)
+N_PX = 1245184                  # reference dataio.py:91
+
+# Algorithmic work per pixel (SURVEY.md 8d / DESIGN.md): GEMM MACs x 2 only.
+F = 2
+D = 57 * F
+FLOP_PX = {
+    "nvp_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),          # 219 648
+    "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 2 * 128 * 128 + 2 * 128 * 128 + 3 * 128),              # dX of every layer but SIREN 0
+    "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),       # dW: same MACs as fwd
+}
+BYTES_PX = {
+    # gather: coords 12 + 192 corner F-vectors + 9 sparse F-vectors (4F bytes each) + latent write 4D
+    "nvp_encode_fwd": 12 + (192 + 9) * 4 * F + 4 * D,
+    # scatter: coords 12 + latent-grad read 4D + the same cells read-modify-written once
+    "nvp_encode_bwd": 12 + 4 * D + (192 + 9) * 4 * F,
+}
+PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM = 8.0e12
+
+
+def cpu_baseline(n_sample: int, reps: int = 2):
+    """Oracle fwd+bwd (incl. dense grid grads, as the reference's autograd does) on the host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nvp_oracle as O
+    cfg = CONFIG_NVP_S
+    sd = O.init_state(cfg, seed=0)
+    for v in sd.values():
+        v.requires_grad_(True)
+    gen = torch.Generator().manual_seed(0)
+    T, H, W = VIDEO
+    times = []
+    for it in range(reps + 1):
+        _, _, coords, steps = O.sample_batch(T, H, W, n_sample, gen)
+        gt = O.normalise_gt(torch.randint(0, 256, (1, n_sample, 3), generator=gen, dtype=torch.uint8))
+        t0 = time.perf_counter()
+        out = O.nvp_forward(coords.unsqueeze(0), steps.unsqueeze(0), sd, cfg)
+        loss = O.image_mse(out, gt)
+        for v in sd.values():
+            v.grad = None
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    best = min(times)
+    return {"value": n_sample / best / 1e6, "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_sample} px of the same batch distribution, full nvp_s parameters (135.8M fp32), "
+                      f"fwd+bwd incl. dense grid grads, best of {reps}, {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=262144)
+    args = ap.parse_args()
+
+    from nvp_amd import _lib, functional, harness, parallel
+    from nvp_amd.modules import NVP
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        if rank == 0 and args.gpus > 1:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+
+    torch.manual_seed(0)                       # identical parameters on every rank
+    model = NVP(out_features=3, encoding_config=CONFIG_NVP_S).to(dev)
+    parallel.broadcast_parameters(model)
+    T, H, W = VIDEO
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    video = torch.randint(0, 256, (T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)   # synthetic u8 RGB, 3.7 GB
+    data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank)   # rank-offset sampler seed
+    total = args.steps + args.warmup
+    opt, sched = harness.make_optimizer(model, total_steps=max(total, 1))
+    bucket = parallel.GradBucket(parallel.unique_parameters(model)) if world > 1 else None
+
+    def one_step():
+        mi, gt = data.sample()
+        return harness.train_step(model, opt, sched, mi, gt, bucket=bucket)
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    functional.TIMER = functional.KernelTimer()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernels = functional.TIMER.summary()
+    functional.TIMER = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+
+    ms_per_step = dt / max(args.steps, 1) * 1e3
+    value = world * N_PX / (ms_per_step * 1e-3) / 1e6
+    if rank == 0:
+        kms = {k: round(v[0], 4) for k, v in kernels.items()}
+        dom = max(kms, key=kms.get) if kms else None
+        roof = None
+        if dom in FLOP_PX:
+            ach = FLOP_PX[dom] * N_PX / (kms[dom] * 1e-3)
+            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_MFMA_F32 / 1e12,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": None,
+                    "ms_per_launch": kms[dom], "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
+        elif dom in BYTES_PX:
+            ach = BYTES_PX[dom] * N_PX / (kms[dom] * 1e-3)
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM, 4), "traffic": None,
+                    "ms_per_launch": kms[dom], "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
+        hot_ms = sum(kms.values())
+        line = {
+            "metric": "Mpixels/sec fwd+bwd (full optimisation step), UVG-HD 1080p geometry",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s, "
+                                   f"{N_PX} (t,x,y) samples per GPU per step, random-init parameters",
+                       "pixels_per_gpu_step": N_PX, "global_batch_pixels": world * N_PX,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "step_contents": "device sampler + fwd + mse + bwd + " + ("allreduce + " if world > 1 else "") + "AdamW + cosine"},
+            "roofline": roof,
+            "kernels_ms": kms,
+            "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
+            "final_loss": float(loss),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

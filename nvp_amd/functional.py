@@ -21,6 +21,39 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+class KernelTimer:
+    """Optional HIP-event timer around individual kernel launches (bench.py roofline leg).
+    Events are recorded on torch's current stream, which is the stream every launch uses."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def run(self, name, fn, *args):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        self.spans.setdefault(name, []).append((a, b))
+        return rc
+
+    def summary(self):
+        """name -> (mean ms, count); call after a device synchronize."""
+        return {k: (sum(a.elapsed_time(b) for a, b in v) / len(v), len(v)) for k, v in self.spans.items()}
+
+    def reset(self):
+        self.spans = {}
+
+
+TIMER = None      # set to a KernelTimer() to time launches
+
+
+def _call(name, fn, *args):
+    if TIMER is not None:
+        return TIMER.run(name, fn, *args)
+    return fn(*args)
+
+
 def dw_chunks(n: int) -> int:
     """Number of pixel chunks of the split-K weight-gradient GEMMs."""
     return max(1, min(128, L.ntiles(n) // 8))
@@ -112,7 +145,7 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
     L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_fwd")
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     saved = torch.empty((5, L.ntiles(n), L.HIDDEN, L.TILE), device=dev, dtype=torch.float32) if save else None
-    L.check(lib.nvp_mlp_fwd(L.ptr(zt), L.ptr(steps), C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), n, d, stream),
+    L.check(_call("nvp_mlp_fwd", lib.nvp_mlp_fwd, L.ptr(zt), L.ptr(steps), C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), n, d, stream),
             "nvp_mlp_fwd")
     return rgb, saved
 
@@ -130,13 +163,13 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     xs = torch.empty((3, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
     dzt = torch.empty_like(zt)
     drgb = _f32c(drgb)
-    L.check(lib.nvp_mlp_bwd_dx(L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
+    L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
                                L.ptr(dy), L.ptr(xs), L.ptr(dzt), n, d, stream), "nvp_mlp_bwd_dx")
     grads = [torch.empty_like(t) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
-    L.check(lib.nvp_mlp_bwd_dw(L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), L.ptr(xs),
+    L.check(_call("nvp_mlp_bwd_dw", lib.nvp_mlp_bwd_dw, L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), L.ptr(xs),
                                L.ptr(partials), nch, C.byref(gstruct), n, d, stream), "nvp_mlp_bwd_dw")
     return dzt, grads
 
@@ -213,7 +246,7 @@ class NVPFused(torch.autograd.Function):
         dev = coords.device
         zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32)
         if n:
-            L.check(lib.nvp_encode_fwd(L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
+            L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
                                        1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_fwd")
         need_grad = any(ctx.needs_input_grad)
@@ -239,7 +272,7 @@ class NVPFused(torch.autograd.Function):
             return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
         dzt, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
-        L.check(lib.nvp_encode_bwd(L.ptr(coords), L.ptr(dzt), L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
+        L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dzt), L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
                                    C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.stream_ptr()),
                 "nvp_encode_bwd")
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *grads)

@@ -1,0 +1,151 @@
+"""Own counterpart of the reference's training harness: the sampler of
+dataio.py:78-120 with the u8 video resident in HBM, image_mse (loss_functions.py:1-3 after
+training.py:47-48) fused with its gradient, and one optimisation step in the reference's
+order (training.py:13-14,50-76): forward, loss, zero_grad, backward, step, sched.step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+N_SAMPLES = 1245184          # reference dataio.py:91
+
+
+class ImageMSEU8(torch.autograd.Function):
+    """mean((out - (gt_u8-127.5)/127.5)^2) with d/dout produced in the same pass (R13)."""
+
+    @staticmethod
+    def forward(ctx, out: torch.Tensor, gt_u8: torch.Tensor) -> torch.Tensor:
+        lib = L.load()
+        o = out.contiguous()
+        n = o.numel() // 3
+        if gt_u8.dtype != torch.uint8 or gt_u8.numel() != o.numel():
+            raise RuntimeError("gt must be uint8 with the same number of elements as the model output")
+        gt_u8 = gt_u8.contiguous()
+        loss_sum = torch.zeros(1, device=o.device, dtype=torch.float32)
+        drgb = torch.empty_like(o) if ctx.needs_input_grad[0] else None
+        if n:
+            L.check(lib.nvp_mse_u8(L.ptr(o), L.ptr(gt_u8, torch.uint8), L.ptr(drgb), L.ptr(loss_sum), n, L.stream_ptr()), "nvp_mse_u8")
+        ctx.save_for_backward(drgb if drgb is not None else torch.empty(0, device=o.device))
+        return (loss_sum / max(o.numel(), 1)).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (drgb,) = ctx.saved_tensors
+        return drgb * g, None
+
+
+def image_mse_u8(model_out: torch.Tensor, gt_u8: torch.Tensor) -> torch.Tensor:
+    return ImageMSEU8.apply(model_out, gt_u8)
+
+
+class DeviceVideo:
+    """u8 video [T, H, W, 3] kept on the device + the reference's per-step random sampler."""
+
+    def __init__(self, video_u8: torch.Tensor, n_samples: int = N_SAMPLES, seed: int = 0):
+        if video_u8.dtype != torch.uint8 or video_u8.dim() != 4 or video_u8.shape[-1] != 3:
+            raise ValueError("video must be uint8 [T, H, W, 3]")
+        self.video = video_u8.contiguous()
+        self.T, self.H, self.W = (int(v) for v in video_u8.shape[:3])
+        self.n = int(n_samples)
+        dev = video_u8.device
+        half_dt = 0.5 / self.T
+        # dataio.py:93-99: modulation input and temporal coordinate tables
+        self.tstep_tab = torch.linspace(half_dt, 1 - half_dt, self.T).to(dev)
+        self.tcoord_tab = torch.linspace(0, 1, self.T).to(dev)
+        self.gen = torch.Generator(device=dev).manual_seed(seed)
+
+    def sample(self) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+        """-> ({'all_coords': [1,N,3], 'temporal_steps': [1,N]}, {'img': uint8 [1,N,3]})
+        randint order as dataio.py:106-107 (temporal indices first, then spatial)."""
+        lib = L.load()
+        dev = self.video.device
+        n = self.n
+        ti = torch.randint(0, self.T, (n,), device=dev, generator=self.gen)
+        pi = torch.randint(0, self.H * self.W, (n,), device=dev, generator=self.gen)
+        coords = torch.empty((n, 3), device=dev, dtype=torch.float32)
+        steps = torch.empty((n,), device=dev, dtype=torch.float32)
+        gt = torch.empty((n, 3), device=dev, dtype=torch.uint8)
+        L.check(lib.nvp_sample_gather(L.ptr(self.video, torch.uint8), L.ptr(ti, torch.int64), L.ptr(pi, torch.int64),
+                                      L.ptr(self.tcoord_tab), L.ptr(self.tstep_tab), L.ptr(coords), L.ptr(steps),
+                                      L.ptr(gt, torch.uint8), n, self.T, self.H, self.W, L.stream_ptr()), "nvp_sample_gather")
+        return ({"all_coords": coords.unsqueeze(0), "temporal_steps": steps.unsqueeze(0)}, {"img": gt.unsqueeze(0)})
+
+    def frame_batch(self, frame: int, lo: int, hi: int):
+        """Whole-frame evaluation slice (eval.py:219-239): pixels [lo, hi) of one frame."""
+        dev = self.video.device
+        p = torch.arange(lo, hi, device=dev)
+        row = torch.div(p, self.W, rounding_mode="floor").float() / (self.H - 1)
+        col = (p % self.W).float() / (self.W - 1)
+        t = self.tcoord_tab[frame].expand(hi - lo)
+        coords = torch.stack((t, row, col), dim=1).unsqueeze(0)
+        steps = self.tstep_tab[frame].expand(1, hi - lo)
+        return {"all_coords": coords, "temporal_steps": steps}, self.video[frame].reshape(-1, 3)[lo:hi]
+
+
+def make_optimizer(model: torch.nn.Module, total_steps: int, lr: float = 1e-2):
+    """AdamW(lr, weight_decay=1e-3) + CosineAnnealingLR(T_max=steps, eta_min=1e-5): training.py:13-14."""
+    opt = torch.optim.AdamW(lr=lr, params=model.parameters(), weight_decay=0.001)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=total_steps, eta_min=1e-5)
+    return opt, sched
+
+
+def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
+    """One iteration in the reference's order (training.py:50-76). Returns the (device) loss.
+    `bucket` (parallel.GradBucket) turns on data parallelism: gradients live in one flat
+    buffer that is zeroed here and all-reduced once between backward and the optimizer."""
+    out = model(model_input)["model_out"]
+    loss = image_mse_u8(out, gt["img"])
+    if bucket is not None:
+        bucket.zero_()
+    else:
+        opt.zero_grad()
+    loss.backward()
+    if bucket is not None:
+        bucket.all_reduce_mean()
+    opt.step()
+    sched.step()
+    return loss.detach()
+
+
+def train_psnr(loss: torch.Tensor) -> float:
+    """10*log10(4/mse): signal range 2 (training.py:58)."""
+    return 10.0 * math.log10(4.0 / float(loss))
+
+
+@torch.no_grad()
+def eval_psnr(model, video: DeviceVideo, frames, n_slice: int = 100) -> float:
+    """Per-frame PSNR on [0,1] as eval.py:243-256: (img+1)/2, clamp, vs u8/255, mean over frames."""
+    hw = video.H * video.W
+    step = (hw + n_slice - 1) // n_slice
+    psnrs = []
+    for f in frames:
+        se = 0.0
+        for lo in range(0, hw, step):
+            hi = min(hw, lo + step)
+            mi, gt = video.frame_batch(f, lo, hi)
+            out = model(mi)["model_out"].reshape(-1, 3)
+            img = torch.clamp((out + 1) / 2, 0, 1)
+            se += float(((img - gt.float() / 255.0) ** 2).sum())
+        psnrs.append(10.0 * math.log10(1.0 / (se / (hw * 3))))
+    return sum(psnrs) / len(psnrs)
+
+
+def procedural_video(T: int, H: int, W: int, device, seed: int = 0) -> torch.Tensor:
+    """Deterministic smooth moving pattern (stand-in for UVG frames, which are not shipped)."""
+    g = torch.Generator().manual_seed(seed)
+    ph = torch.rand(6, generator=g) * 6.28
+    t = torch.linspace(0, 1, T, device=device)[:, None, None]
+    y = torch.linspace(0, 1, H, device=device)[None, :, None]
+    x = torch.linspace(0, 1, W, device=device)[None, None, :]
+    chans = []
+    for c in range(3):
+        v = (torch.sin(6.28 * (3 + c) * x + 4 * t + ph[c]) * torch.cos(6.28 * (2 + c) * y - 3 * t + ph[3 + c])
+             + 0.5 * torch.sin(25 * (x - 0.3 * t) * (y + 0.2)))
+        chans.append(((v / 1.5 * 0.5 + 0.5).clamp(0, 1) * 255).to(torch.uint8))
+    return torch.stack(chans, dim=-1).contiguous()

@@ -1,0 +1,95 @@
+"""Pixel-batch data parallelism: one process per GPU, every rank draws its
+own i.i.d. pixel batch, parameters are replicated, and after backward ONE all-reduce
+(RCCL over xGMI; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests) sums a single
+flat fp32 gradient buffer, which is then scaled by 1/world.  Weak scaling: the per-GPU
+batch stays N = 1 245 184, the global batch is world * N.
+
+The flat buffer is persistent: `GradBucket` points every parameter's `.grad` at a view of
+one contiguous tensor, so the collective really is a single call on 543 MB (nvp_s) and no
+per-step flatten/unflatten copy exists.  autograd accumulates in place into those views
+(`zero_grad(set_to_none=False)` semantics are provided by `GradBucket.zero_()`).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None) -> tuple:
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def unique_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
+    """NVP registers its SirenNet twice (net and wrapper.net); parameters() already dedups."""
+    return [p for p in module.parameters() if p.requires_grad]
+
+
+class GradBucket:
+    """All gradients of a module as views into one flat fp32 buffer + the per-step all-reduce."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params = list(params)
+        if not self.params:
+            raise ValueError("no parameters")
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.views = []
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("GradBucket expects fp32 parameters on one device")
+            v = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(v)
+            off += p.numel()
+        self.attach()
+
+    def attach(self) -> None:
+        """(Re)bind .grad to the bucket views (after zero_grad(set_to_none=True) or a rebuild)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+        self.attach()
+
+    def consistent(self) -> bool:
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
+
+    def all_reduce_mean(self) -> None:
+        """One collective over the whole gradient; no-op for a single process."""
+        if not self.consistent():
+            # a grad tensor was replaced (e.g. zero_grad(set_to_none=True)): copy back into the bucket
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+            self.attach()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / dist.get_world_size())
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """Make every rank start from rank `src`'s parameters (replicated-parameter DP)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for p in unique_parameters(module):
+            dist.broadcast(p.data, src=src)

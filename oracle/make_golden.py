@@ -233,6 +233,25 @@ def gen_e2e(seed):
     np.savez_compressed(os.path.join(OUT, "traj3.npz"), losses=np.array(losses, dtype=np.float64))
 
 
+def gen_init(seed):
+    """Init-stream parity: the reference's constructors consume torch's global RNG in a fixed
+    order (SparseGrid, SirenNet layers weight->bias, last layer, Modulator Linear defaults,
+    then kaiming_normal_).  Store a fingerprint of every tensor for a given seed."""
+    torch.manual_seed(seed)
+    grid = ref_sparsegrid.SparseGrid(level_dim=2, x_resolution=9, y_resolution=7, t_resolution=8, upsample=False)
+    net = ref_modulation.SirenNet(dim_in=1, dim_hidden=128, dim_out=3, num_layers=3, w0_initial=30.)
+    wrapper = ref_modulation.SirenWrapper(net, latent_dim=114)
+    sd = mlp_state(net, wrapper)
+    sd["sparse_grid.embeddings"] = grid.embeddings
+    blob = {}
+    for k, v in sd.items():
+        f = v.detach().flatten()
+        blob["head:" + k] = f[:8].numpy().copy()
+        blob["sum:" + k] = np.array(f.double().sum().item())
+        blob["absmax:" + k] = np.array(f.abs().max().item())
+    np.savez_compressed(os.path.join(OUT, f"init_seed{seed}.npz"), **blob)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # deterministic reductions while generating
@@ -242,6 +261,7 @@ def main():
     gen_mlp(114, 256, seed=21)
     gen_mlp(228, 256, seed=22)
     gen_e2e(seed=31)
+    gen_init(seed=123)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"golden fixtures written to {OUT} ({tot / 1024:.0f} KiB); oracle == reference on all cases")
 

@@ -1,0 +1,137 @@
+"""CPU tests of the host side: the C-ABI library loads and exports what include/nvp_hip.h
+declares, the host geometry equals the oracle's, and the module surface mirrors the
+reference's (names, state_dict keys, init stream, loud failure without a HIP device)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import nvp_oracle as O
+from conftest import GOLDEN, ROOT, small_cfg
+from nvp_amd import _lib as L
+from nvp_amd import modulation, modules, sparsegrid
+from nvp_amd import tinycudann as tcnn
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nvp_hip.h")).read()
+    declared = set(re.findall(r"\b(nvp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"nvp_levels", "nvp_sparse_shape", "nvp_mlp_params", "nvp_mlp_grads"}
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libnvp_hip.so does not export {name}"
+    assert declared == set(L.SIGNATURES), "ctypes signature table out of sync with the header"
+
+
+def test_library_size_queries_match_layout_arithmetic():
+    lib = L.load()
+    assert lib.nvp_version().startswith(b"nvp_hip")
+    for d in (114, 228, 57):
+        zs = (d + 1) // 2
+        steps = (1 + zs) + 2 * (65 + zs) + 2 * 65
+        assert lib.nvp_packed_fwd_floats(d) == steps * 64 * 4
+        H = 128
+        total = H * d + H + 2 * (H * (H + d) + H) + (H + H) + 2 * (H * H + H) + 3 * H + 3
+        assert lib.nvp_mlp_param_floats(d) == total
+        assert lib.nvp_dw_partial_floats(d, 7) == 7 * total
+        assert lib.nvp_latent_rows(d) == d + (d & 1)
+    assert lib.nvp_mlp_param_floats(114) == 110595      # MLP params of nvp_s
+    assert lib.nvp_mlp_param_floats(228) == 154371      # nvp_l
+
+
+def test_levels_struct_equals_oracle_geometry():
+    cfg = small_cfg()["2d_encoding_xy"]
+    lv = L.make_levels(cfg)
+    scales, ress, offs = O.dense_grid_levels(cfg)
+    assert list(lv.res)[:16] == ress
+    assert list(lv.offset)[:17] == offs
+    assert [np.float32(s) for s in lv.scale][:16] == [np.float32(s) for s in scales]
+    assert L.levels_n_params(lv) == O.dense_grid_n_params(cfg) == 9232224
+
+
+def test_state_dict_keys_and_shapes_match_reference():
+    cfg = small_cfg(F=2)
+    m = modules.NVP(out_features=3, encoding_config=cfg, type="nvp")     # 'type' kwarg is swallowed (train_video.py:46)
+    keys = set(m.state_dict().keys())
+    want = {"keyframes_xy.params", "keyframes_yt.params", "keyframes_xt.params", "sparse_grid.embeddings"}
+    for pre in ("net.", "wrapper.net."):
+        for k in range(3):
+            want |= {f"{pre}layers.{k}.weight", f"{pre}layers.{k}.bias"}
+        want |= {f"{pre}last_layer.weight", f"{pre}last_layer.bias"}
+    for k in range(3):
+        want |= {f"wrapper.modulator.layers.{k}.0.weight", f"wrapper.modulator.layers.{k}.0.bias"}
+    assert keys == want                                                    # SURVEY section 5 [probe]
+    assert m.wrapper.net is m.net
+    assert m.keyframes_xy.params.shape == (9232224,) and m.keyframes_xy.dtype == torch.float32
+    assert m.keyframes_xy.n_output_dims == 32
+    assert m.sparse_grid.embeddings.shape == (8, 9, 7, 2)
+    assert m.wrapper.modulator.layers[1][0].weight.shape == (128, 128 + 114)
+    assert m.latent_dim == 114
+    # tcnn's default seed makes the three planes start identical; grids are U(-1e-4, 1e-4)
+    assert torch.equal(m.keyframes_xy.params, m.keyframes_xt.params)
+    assert float(m.keyframes_xy.params.abs().max()) <= 1e-4
+    assert float(m.sparse_grid.embeddings.abs().max()) <= 1e-4
+
+
+def test_init_stream_matches_reference_constructors():
+    g = np.load(os.path.join(GOLDEN, "init_seed123.npz"))
+    torch.manual_seed(123)
+    grid = sparsegrid.SparseGrid(level_dim=2, x_resolution=9, y_resolution=7, t_resolution=8, upsample=False)
+    net = modulation.SirenNet(dim_in=1, dim_hidden=128, dim_out=3, num_layers=3, w0_initial=30.)
+    wrapper = modulation.SirenWrapper(net, latent_dim=114)
+    sd = {"sparse_grid.embeddings": grid.embeddings}
+    for k in range(3):
+        sd[f"wrapper.modulator.layers.{k}.0.weight"] = wrapper.modulator.layers[k][0].weight
+        sd[f"wrapper.modulator.layers.{k}.0.bias"] = wrapper.modulator.layers[k][0].bias
+        sd[f"net.layers.{k}.weight"] = net.layers[k].weight
+        sd[f"net.layers.{k}.bias"] = net.layers[k].bias
+    sd["net.last_layer.weight"] = net.last_layer.weight
+    sd["net.last_layer.bias"] = net.last_layer.bias
+    for k, v in sd.items():
+        f = v.detach().flatten()
+        assert np.array_equal(f[:8].numpy(), g["head:" + k]), k
+        assert f.double().sum().item() == float(g["sum:" + k]), k
+
+
+def test_rebinding_params_is_picked_up():
+    """eval.py:170-179 assigns fresh nn.Parameters; the modules must read them at call time."""
+    enc = tcnn.Encoding(n_input_dims=2, encoding_config=small_cfg()["2d_encoding_xy"])
+    new = torch.nn.Parameter(torch.zeros_like(enc.params))
+    enc.params = new
+    assert enc.params is new and dict(enc.named_parameters())["params"] is new
+
+
+def test_product_fails_loudly_without_a_hip_device():
+    cfg = small_cfg()
+    m = modules.NVP(out_features=3, encoding_config=cfg)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m({"all_coords": torch.rand(1, 64, 3), "temporal_steps": torch.rand(1, 64)})
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.sparse_grid(torch.rand(5, 3))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.keyframes_xy(torch.rand(5, 2))
+
+
+def test_unsupported_configs_raise():
+    with pytest.raises(NotImplementedError):
+        tcnn.Encoding(n_input_dims=3, encoding_config=small_cfg()["2d_encoding_xy"])
+    with pytest.raises(NotImplementedError):
+        tcnn.Encoding(n_input_dims=2, encoding_config={"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2,
+                                                       "per_level_scale": 1.35})
+    net = modulation.SirenNet(dim_in=1, dim_hidden=64, dim_out=3, num_layers=3)
+    w = modulation.SirenWrapper(net, latent_dim=114)
+    with pytest.raises(NotImplementedError):
+        w.mlp_tensors()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "nvp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "nvp_oracle" not in src and "oracle" not in re.findall(r"^\s*(?:from|import)\s+(\S+)", src, re.M), f
