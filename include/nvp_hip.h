@@ -86,6 +86,7 @@ int64_t nvp_packed_bwd_floats(int32_t latent_dim);
 int64_t nvp_dw_partial_floats(int32_t latent_dim, int32_t n_chunks);
 int64_t nvp_mlp_param_floats(int32_t latent_dim);
 int32_t nvp_latent_rows(int32_t latent_dim);   /* rows of a PTM latent tensor (D rounded up to even) */
+int32_t nvp_dz_stride(int32_t latent_dim);     /* row stride of the row-major latent gradient (D rounded up to 4) */
 
 /* ---- R2/R3: tinycudann.Encoding forward / backward (reference modules.py:65-67) ---
  * x [N,2] row-major, out/dout [N, n_levels*F] row-major, dparams accumulate. */
@@ -112,11 +113,17 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
                    const float* emb, float* zt, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                    const nvp_sparse_shape* sh, int temporal_interp, void* stream);
-/* dzt PTM -> scatter-add into the four grids' gradients (accumulate). */
-int nvp_encode_bwd(const float* coords, const float* dzt,
+/* R3 + R6 fused: latent gradient -> gradients of the four grids (nvp_amd/csrc/encode_bwd.hip).
+ * dz: ROW-MAJOR [>= N][dz_stride] latent gradient as written by nvp_mlp_bwd_dx (columns
+ * xy | yt | xt | sparse).  d_kf_*: every element is OVERWRITTEN (deterministic sorted-band
+ * fixed-point accumulation, no atomics, no zero-fill needed); d_emb: accumulate (caller zeroes).
+ * workspace: device scratch of nvp_encode_bwd_workspace_bytes() bytes. */
+int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
+                                       const nvp_levels* lv_xt);
+int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, void* stream);
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Row-major [N,D] <-> PTM [ntiles][rows][32] (used by the stand-alone SirenWrapper). */
 int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream);
@@ -135,8 +142,8 @@ int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, co
                 float* rgb, float* saved, int64_t n, int32_t latent_dim, void* stream);
 
 /* ---- R12: autograd of R8-R10 (reference training.py:74).
- * bwd_dx: drgb [N,3] -> dzt (PTM latent gradient) + the nine PTM [ntiles][128][32]
- *         streams the weight-gradient GEMMs consume:
+ * bwd_dx: drgb [N,3] -> dz_rows (latent gradient, ROW-MAJOR [ntiles*32][nvp_dz_stride(D)])
+ *         + the nine PTM [ntiles][128][32] streams the weight-gradient GEMMs consume:
  *         dy = {dp0,dp1,dp2 (modulator pre-activation grads), dq0s (= 30*dq0), dq1, dq2},
  *         xs = {x0,x1,x2 (modulated sine outputs)}.
  * bwd_dw: all 14 parameter gradients = split-K GEMMs over the pixel axis into
@@ -144,7 +151,7 @@ int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, co
  *         into `g` (overwritten). */
 int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved,
                    const nvp_mlp_params* p, const float* packed_bwd,
-                   float* dy, float* xs, float* dzt, int64_t n, int32_t latent_dim, void* stream);
+                   float* dy, float* xs, float* dz_rows, int64_t n, int32_t latent_dim, void* stream);
 int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
                    const float* dy, const float* xs, float* partials, int32_t n_chunks,
                    const nvp_mlp_grads* g, int64_t n, int32_t latent_dim, void* stream);

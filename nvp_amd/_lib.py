@@ -57,8 +57,10 @@ SIGNATURES = {
     "nvp_sparse3x3_inter_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
     "nvp_encode_fwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), C.c_int, _vp],
-    "nvp_encode_bwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
-                       C.POINTER(SparseShape), _vp],
+    "nvp_encode_bwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
+                       C.POINTER(SparseShape), _vp, _i64, _vp],
+    "nvp_encode_bwd_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels)],
+    "nvp_dz_stride": [_i32],
     "nvp_rows_to_ptm": [_p, _p, _i64, _i32, _i32, _vp],
     "nvp_ptm_to_rows": [_p, _p, _i64, _i32, _i32, _vp],
     "nvp_mlp_pack_fwd": [C.POINTER(MlpParams), _p, _i32, _vp],
@@ -78,6 +80,7 @@ SIGNATURES = {
 _RESTYPES = {
     "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64,
     "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
+    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32,
 }
 
 _lib: Optional[C.CDLL] = None

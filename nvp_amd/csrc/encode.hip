@@ -15,6 +15,10 @@
 // contract them into an FMA and flip a cell at a .5 boundary.
 #include "nvp_common.h"
 
+// __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
+// index and interpolation arithmetic keeps the reference's separately rounded multiply and add.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -288,26 +292,6 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_kernel(const float* __res
     }
 }
 
-template <int F>
-__global__ __launch_bounds__(kThreads) void encode_bwd_kernel(const float* __restrict__ coords, const float* __restrict__ dzt,
-                                                              float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2,
-                                                              float* __restrict__ demb, int64_t n, EncodeArgs a) {
-    int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (px >= n) return;
-    const float* c = coords + px * 3;
-    float t = c[0], x = c[1], y = c[2];
-    int s = blockIdx.y;
-    if (s < a.slots[0]) {
-        dense_slot_bwd<F, true>(d0, a.lv[0], s * kLevelsPerSlot, x, y, dzt, px, a.col0[0], a.rows);
-    } else if ((s -= a.slots[0]) < a.slots[1]) {
-        dense_slot_bwd<F, true>(d1, a.lv[1], s * kLevelsPerSlot, t, y, dzt, px, a.col0[1], a.rows);
-    } else if ((s -= a.slots[1]) < a.slots[2]) {
-        dense_slot_bwd<F, true>(d2, a.lv[2], s * kLevelsPerSlot, t, x, dzt, px, a.col0[2], a.rows);
-    } else {
-        sparse_bwd<true>(demb, a.sh, t, x, y, dzt, px, a.col0[3], a.rows);
-    }
-}
-
 // row-major [N,D] <-> PTM [ntiles][rows][32]; a block transposes a 32-pixel x 32-column
 // patch through LDS so both sides move full lines.
 __global__ __launch_bounds__(256) void rows_to_ptm_kernel(const float* __restrict__ src, float* __restrict__ dst,
@@ -454,24 +438,6 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
     rc = dispatch_f(a.lv[0].n_features, [&](auto f) {
         hipLaunchKernelGGL((encode_fwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream,
                            coords, kf_xy, kf_yt, kf_xt, emb, zt, n, npad, a, temporal_interp);
-    });
-    if (rc) return rc;
-    NVP_LAUNCH_CHECK();
-    return 0;
-}
-
-int nvp_encode_bwd(const float* coords, const float* dzt, float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb,
-                   int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, void* stream) {
-    EncodeArgs a;
-    int rc = make_args(a, lv_xy, lv_yt, lv_xt, sh);
-    if (rc) return rc;
-    if (n < 0) return NVP_ERR_BADARG;
-    if (n == 0) return 0;
-    dim3 grid((unsigned)((n + kThreads - 1) / kThreads), a.slots[0] + a.slots[1] + a.slots[2] + 1);
-    rc = dispatch_f(a.lv[0].n_features, [&](auto f) {
-        hipLaunchKernelGGL((encode_bwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream,
-                           coords, dzt, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, a);
     });
     if (rc) return rc;
     NVP_LAUNCH_CHECK();

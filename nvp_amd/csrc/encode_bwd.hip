@@ -1,0 +1,511 @@
+// Gradient scatter-add of the NVP encoders (R3 + R6) for gfx950, atomic-free on the dense
+// planes.
+//
+// Measured on MI355X (tools/probes): global fp32 atomics sustain only ~21 Gop/s whatever the
+// footprint or scope, LDS ds_add_f32 ~0.2 Top/s, but LDS *integer* atomics 3-8 Top/s.  The
+// reference-shaped scatter (one fp32 atomic per corner x feature = 478 M atomics per step for
+// nvp_s) therefore costs ~25 ms.  This file replaces it by a deterministic scheme:
+//
+//  1. sort the batch's pixels by the row coordinate of each plane (y for the xy and yt planes,
+//     x for the xt plane) - two 1.2 M-key radix sorts (rocPRIM);
+//  2. permute: coordinates and the per-level latent gradients are rewritten in sorted order,
+//     level-major, so every later access is a coalesced stream; the same pass finds
+//     max|dz|, which fixes the fixed-point scale;
+//  3. row tables: for every level, the first sorted pixel of each grid row (binary searches);
+//  4. band kernel: a workgroup owns rows [r0, r1) of one level of one plane, keeps them as an
+//     int64 fixed-point table in LDS (<= 144 KB) and visits exactly the sorted pixel range that
+//     can touch those rows.  Bilinear corner weights x gradient are added with ds_add_u64:
+//     integer addition is exact and order-independent, so the result is bit-reproducible.
+//     Bands with few rows-per-pixel are additionally split over several workgroups
+//     ("splits"); split tables go to slabs that step 5 sums.  Fine levels are exclusive and
+//     are stored straight into the gradient.  Every gradient element is written exactly once
+//     with plain coalesced stores - no atomics, no zero-fill pass needed.
+//  5. slab reduction for the split levels.
+//
+// The sparse 3x3 grid still uses fp32 atomics (22 M per step, ~1 ms); it is the next
+// candidate for the same treatment.
+//
+// Quantisation: contributions are scaled by 2^k with k chosen from max|dz| so that the sum of
+// N contributions cannot overflow 2^62; each contribution keeps >= 40 significant bits below
+// max|dz| (fp32 carries 24), so the scatter is more accurate than an fp32 atomic chain.
+#include <cstring>
+#include "nvp_common.h"
+#include <rocprim/rocprim.hpp>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kBandThreads = 1024;
+constexpr int kLdsEntries = 18000;            // int64 entries -> 144 000 B of the 160 KB LDS
+constexpr int kTargetVisits = 16384;          // pixel visits per band workgroup
+constexpr int kMaxSlots = 256;                // dzmax slots
+
+struct LevelPlan {
+    int first_block;     // first blockIdx of this (plane, level)
+    int bands, splits;
+    int rows;            // rows per band
+    int rs_off;          // offset of this level's row-start table
+    int pad;
+    long long slab_off;  // float offset of the split slabs, -1 when exclusive (splits == 1)
+};
+
+struct Plan {
+    LevelPlan lp[3][NVP_MAX_LEVELS];
+    int total_blocks;
+    int rs_total[3];         // row-start entries per plane
+    long long slab_floats;   // total slab floats
+    int reduce_items;        // number of (plane, level) pairs with splits > 1
+};
+
+void make_plan(Plan& P, const nvp_levels* lv[3], int64_t n) {
+    int blocks = 0;
+    long long slab = 0;
+    P.reduce_items = 0;
+    for (int p = 0; p < 3; ++p) {
+        int rs = 0;
+        const int F = lv[p]->n_features;
+        for (int l = 0; l < lv[p]->n_levels; ++l) {
+            LevelPlan& L = P.lp[p][l];
+            const int res = lv[p]->res[l];
+            int rows = kLdsEntries / (res * F);
+            if (rows < 1) rows = 1;               // (res*F <= 18000 for every supported config)
+            if (rows > res) rows = res;
+            L.rows = rows;
+            L.bands = (res + rows - 1) / rows;
+            // pixels visited by one band ~ n * (rows + 2) / res  (whole level: n)
+            double visits = (L.bands == 1) ? (double)n : (double)n * (rows + 2) / res;
+            int splits = (int)((visits + kTargetVisits - 1) / kTargetVisits);
+            if (splits < 1) splits = 1;
+            if (splits > 256) splits = 256;
+            L.splits = splits;
+            L.first_block = blocks;
+            blocks += L.bands * splits;
+            L.rs_off = rs;
+            rs += res + 1;
+            L.pad = 0;
+            if (splits > 1) {
+                L.slab_off = slab;
+                slab += (long long)splits * res * res * F;
+                ++P.reduce_items;
+            } else {
+                L.slab_off = -1;
+            }
+        }
+        P.rs_total[p] = rs;
+    }
+    P.total_blocks = blocks;
+    P.slab_floats = slab;
+}
+
+// ------------------------------------------------------------------------------------------
+struct Ws {                      // workspace carve (byte offsets)
+    size_t keys_in[2], keys_out[2], iota, order[2], cs[3], dzs[3], rowstart[3], dzmax, slabs, sort_tmp, total;
+    size_t sort_tmp_bytes;
+};
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], int64_t n) {
+    size_t o = 0;
+    for (int k = 0; k < 2; ++k) { W.keys_in[k] = o; o = align_up(o + n * 4); }
+    for (int k = 0; k < 2; ++k) { W.keys_out[k] = o; o = align_up(o + n * 4); }
+    W.iota = o; o = align_up(o + n * 4);
+    for (int k = 0; k < 2; ++k) { W.order[k] = o; o = align_up(o + n * 4); }
+    for (int p = 0; p < 3; ++p) { W.cs[p] = o; o = align_up(o + n * 8); }
+    for (int p = 0; p < 3; ++p) { W.dzs[p] = o; o = align_up(o + (size_t)n * lv[p]->n_levels * lv[p]->n_features * 4); }
+    for (int p = 0; p < 3; ++p) { W.rowstart[p] = o; o = align_up(o + (size_t)P.rs_total[p] * 4); }
+    W.dzmax = o; o = align_up(o + kMaxSlots * 4);
+    W.slabs = o; o = align_up(o + (size_t)P.slab_floats * 4);
+    size_t tmp = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
+                                             (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
+    if (e != hipSuccess) return (int)e;
+    W.sort_tmp_bytes = tmp;
+    W.sort_tmp = o; o = align_up(o + tmp);
+    W.total = o;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ coords, float* __restrict__ ky, float* __restrict__ kx,
+                                                   int* __restrict__ iota, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    kx[i] = coords[i * 3 + 1];
+    ky[i] = coords[i * 3 + 2];
+    iota[i] = (int)i;
+}
+
+struct PermArgs {
+    const int* order[3];      // sorted->pixel id, per plane
+    float2* cs[3];
+    float* dzs[3];
+    int col0[3], nlev[3];
+    int c0[3], c1[3];         // coordinate columns feeding (dim0, dim1) of each plane
+};
+
+// one thread = one (sorted position, plane); F floats per level, 128-B contiguous read per plane
+template <int F>
+__global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride,
+                                                      PermArgs A, unsigned* __restrict__ dzmax, int64_t n) {
+    const int plane = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (p < n) {
+        const int id = A.order[plane][p];
+        const float* c = coords + (int64_t)id * 3;
+        A.cs[plane][p] = make_float2(c[A.c0[plane]], c[A.c1[plane]]);
+        const float* src = dz + (int64_t)id * dz_stride + A.col0[plane];
+        float* dst = A.dzs[plane];
+        const int nl = A.nlev[plane];
+        for (int l = 0; l < nl; ++l) {
+            float v[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) { v[f] = src[l * F + f]; m = fmaxf(m, fabsf(v[f])); }
+#pragma unroll
+            for (int f = 0; f < F; ++f) dst[((int64_t)l * n + p) * F + f] = v[f];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(m));
+}
+
+__device__ __forceinline__ int row_of(float c1, float scale) { return (int)floorf(c1 * scale + 0.5f); }
+
+struct RowArgs {
+    const float2* cs[3];
+    int* rowstart[3];
+    nvp_levels lv[3];
+    int rs_off[3][NVP_MAX_LEVELS];
+    int rs_total[3];
+};
+
+// rowstart[level][r] = first sorted position whose row index at that level is >= r  (r in [0, res])
+__global__ __launch_bounds__(256) void rowstart_kernel(RowArgs A, int64_t n) {
+    const int plane = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= A.rs_total[plane]) return;
+    int l = 0;
+    while (l + 1 < A.lv[plane].n_levels && idx >= A.rs_off[plane][l + 1]) ++l;
+    const int r = idx - A.rs_off[plane][l];
+    const float scale = A.lv[plane].scale[l];
+    const float2* cs = A.cs[plane];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (row_of(cs[mid].y, scale) >= r) hi = mid; else lo = mid + 1;
+    }
+    A.rowstart[plane][idx] = (int)lo;
+}
+
+// value * 2^k as a signed 64-bit integer, round-half-up in magnitude
+__device__ __forceinline__ long long to_fixed(float v, int k) {
+    const unsigned b = __float_as_uint(v);
+    const int e = (b >> 23) & 0xff;
+    const unsigned m = (b & 0x7fffffu) | (e ? 0x800000u : 0u);
+    const int sh = (e ? e : 1) - 150 + k;
+    long long q;
+    if (sh >= 0) q = (long long)m << (sh > 38 ? 38 : sh);
+    else {
+        const int rs = -sh;
+        q = rs > 24 ? 0 : (long long)((m + (1u << (rs - 1))) >> rs);
+    }
+    return (b >> 31) ? -q : q;
+}
+
+struct BandArgs {
+    Plan plan;
+    nvp_levels lv[3];
+    const float2* cs[3];
+    const float* dzs[3];
+    const int* rowstart[3];
+    float* grad[3];
+    float* slabs;
+    const unsigned* dzmax;
+    int headroom_bits;
+};
+
+template <int F>
+__global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ int s_k;
+    // ---- decode the work item
+    int plane = 0, level = 0;
+    {
+        const int b = blockIdx.x;
+        // (plane, level) pairs are laid out in increasing first_block order
+        for (int p = 0; p < 3; ++p)
+            for (int l = 0; l < A.lv[p].n_levels; ++l)
+                if (b >= A.plan.lp[p][l].first_block) { plane = p; level = l; }
+    }
+    const LevelPlan L = A.plan.lp[plane][level];
+    const int local = blockIdx.x - L.first_block;
+    const int band = local / L.splits, split = local - band * L.splits;
+    const int res = A.lv[plane].res[level];
+    const float scale = A.lv[plane].scale[level];
+    const int r0 = band * L.rows;
+    const int r1 = min(res, r0 + L.rows);
+    const int entries = (r1 - r0) * res * F;
+
+    for (int i = threadIdx.x; i < entries; i += kBandThreads) tab[i] = 0ull;
+    if (threadIdx.x < 64) {
+        // fixed-point scale from max|dz| (kMaxSlots candidates, 4 per lane)
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64) m = max(m, A.dzmax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) {
+            const int e = (int)((m >> 23) & 0xff) - 127;            // floor(log2 max|dz|); m == 0 -> -127
+            s_k = 62 - A.headroom_bits - (e + 1);
+        }
+    }
+    __syncthreads();
+    const int k = s_k;
+
+    // ---- sorted pixel ranges that can touch rows [r0, r1): rows iy in [r0-2, r1-1], plus the
+    //      wrap-around of the last two rows into rows 0/1 (cell index is taken mod res^2)
+    const int* rs = A.rowstart[plane] + L.rs_off;
+    const int loA = rs[max(r0 - 2, 0)], hiA = rs[r1];
+    int loW = 0, hiW = 0;
+    if (r0 == 0) { loW = max(rs[max(res - 2, 0)], hiA); hiW = (int)n; if (loW > hiW) loW = hiW; }
+    const int lenA = hiA - loA, lenT = lenA + (hiW - loW);
+    const int kb = (int)(((long long)lenT * split) / L.splits);
+    const int ke = (int)(((long long)lenT * (split + 1)) / L.splits);
+
+    const float2* cs = A.cs[plane];
+    const float* dz = A.dzs[plane] + (int64_t)level * n * F;
+    for (int kk = kb + threadIdx.x; kk < ke; kk += kBandThreads) {
+        const int p = kk < lenA ? loA + kk : loW + (kk - lenA);
+        const float2 c = cs[p];
+        float g[F];
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) { g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
+        if (!any) continue;
+        const float p0 = c.x * scale + 0.5f, p1 = c.y * scale + 0.5f;
+        const float f0 = floorf(p0), f1 = floorf(p1);
+        const float w0 = p0 - f0, w1 = p1 - f1;
+        const int i0 = (int)f0, i1 = (int)f1;
+        const float u0 = 1.0f - w0, u1 = 1.0f - w1;
+#pragma unroll
+        for (int cnr = 0; cnr < 4; ++cnr) {
+            const int a = cnr & 1, b = cnr >> 1;
+            int cell = (i0 + a) + (i1 + b) * res;
+            const int size = res * res;
+            if ((unsigned)cell >= (unsigned)size) { cell %= size; if (cell < 0) cell += size; }
+            const int off = cell - r0 * res;              // row test: cell in [r0*res, r1*res)
+            if (off < 0 || off >= (r1 - r0) * res) continue;
+            const float w = (a ? w0 : u0) * (b ? w1 : u1);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const long long q = to_fixed(w * g[f], k);
+                atomicAdd(&tab[off * F + f], (unsigned long long)q);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- flush: exclusive bands go straight to the gradient, split bands to their slab
+    const double inv = ldexp(1.0, -k);
+    const int64_t lvl_off = (int64_t)A.lv[plane].offset[level] * F;
+    float* dst = (L.slab_off < 0) ? A.grad[plane] + lvl_off + (int64_t)r0 * res * F
+                                  : A.slabs + L.slab_off + (int64_t)split * res * res * F + (int64_t)r0 * res * F;
+    for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = (float)((double)(long long)tab[i] * inv);
+}
+
+struct ReduceArgs {
+    Plan plan;
+    nvp_levels lv[3];
+    float* grad[3];
+    const float* slabs;
+};
+
+// grid.y enumerates the (plane, level) pairs that were split
+__global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceArgs A) {
+    int want = blockIdx.y, plane = -1, level = -1;
+    for (int p = 0; p < 3 && plane < 0; ++p)
+        for (int l = 0; l < A.lv[p].n_levels; ++l)
+            if (A.plan.lp[p][l].splits > 1 && want-- == 0) { plane = p; level = l; break; }
+    if (plane < 0) return;
+    const LevelPlan L = A.plan.lp[plane][level];
+    const int F = A.lv[plane].n_features;
+    const int64_t cells = (int64_t)A.lv[plane].res[level] * A.lv[plane].res[level] * F;
+    float* dst = A.grad[plane] + (int64_t)A.lv[plane].offset[level] * F;
+    const float* src = A.slabs + L.slab_off;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < L.splits; ++sp) s += src[(int64_t)sp * cells + i];
+        dst[i] = s;
+    }
+}
+
+// sparse 3x3 grid: fp32 atomics from the row-major latent gradient (reference autograd of
+// sparsegrid.py:61-69: clamped border duplicates accumulate)
+__device__ __forceinline__ int nearest_idx(float c, int res) {
+    float f = (float)(res - 1) * c;
+    int i = (int)(f + 0.5f);
+    return min(max(i, 0), res - 1);
+}
+
+__global__ __launch_bounds__(256) void sparse_bwd_rows_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride,
+                                                              int col0, float* __restrict__ demb, int64_t n, nvp_sparse_shape sh) {
+    const int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (px >= n) return;
+    const float* c = coords + px * 3;
+    const int F = sh.n_features;
+    const int ti = nearest_idx(c[0], sh.t_res), xi = nearest_idx(c[1], sh.x_res), yi = nearest_idx(c[2], sh.y_res);
+    const float* g = dz + px * dz_stride + col0;
+    const int64_t plane = (int64_t)sh.x_res * sh.y_res;
+    for (int i = 0; i < 3; ++i) {
+        const int vx = min(max(xi + i - 1, 0), sh.x_res - 1);
+        for (int j = 0; j < 3; ++j) {
+            const int vy = min(max(yi + j - 1, 0), sh.y_res - 1);
+            float* dst = demb + ((int64_t)ti * plane + (int64_t)vx * sh.y_res + vy) * F;
+            for (int f = 0; f < F; ++f) {
+                const float v = g[(i * 3 + j) * F + f];
+                if (v != 0.f) nvp_atomic_add(dst + f, v);
+            }
+        }
+    }
+}
+
+bool levels_ok(const nvp_levels* lv) {
+    if (!lv || lv->n_levels < 1 || lv->n_levels > NVP_MAX_LEVELS) return false;
+    const int f = lv->n_features;
+    if (!(f == 1 || f == 2 || f == 4 || f == 8)) return false;
+    for (int l = 0; l < lv->n_levels; ++l)
+        if (lv->res[l] < 2 || lv->res[l] * f > kLdsEntries) return false;
+    return true;
+}
+
+template <int F>
+int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
+               const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, hipStream_t s) {
+    float* ky = (float*)(ws + W.keys_in[0]);
+    float* kx = (float*)(ws + W.keys_in[1]);
+    int* iota = (int*)(ws + W.iota);
+    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota, n);
+    size_t tmp = W.sort_tmp_bytes;
+    for (int k = 0; k < 2; ++k) {
+        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[k]), (float*)(ws + W.keys_out[k]),
+                                                 (const int*)iota, (int*)(ws + W.order[k]), (size_t)n, 0, 32, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipError_t me = hipMemsetAsync(ws + W.dzmax, 0, kMaxSlots * 4, s);
+    if (me != hipSuccess) return (int)me;
+
+    // planes in latent order: xy <- (x, y) sorted by y ; yt <- (t, y) sorted by y ; xt <- (t, x) sorted by x
+    PermArgs PA;
+    int col = 0;
+    const int c0[3] = {1, 0, 0}, c1[3] = {2, 2, 1}, ord[3] = {0, 0, 1};
+    for (int p = 0; p < 3; ++p) {
+        PA.order[p] = (const int*)(ws + W.order[ord[p]]);
+        PA.cs[p] = (float2*)(ws + W.cs[p]);
+        PA.dzs[p] = (float*)(ws + W.dzs[p]);
+        PA.col0[p] = col; PA.nlev[p] = lv[p]->n_levels; PA.c0[p] = c0[p]; PA.c1[p] = c1[p];
+        col += lv[p]->n_levels * lv[p]->n_features;
+    }
+    hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, coords, dz, dz_stride, PA,
+                       (unsigned*)(ws + W.dzmax), n);
+
+    RowArgs RA;
+    int rs_max = 0;
+    for (int p = 0; p < 3; ++p) {
+        RA.cs[p] = (const float2*)(ws + W.cs[p]);
+        RA.rowstart[p] = (int*)(ws + W.rowstart[p]);
+        RA.lv[p] = *lv[p];
+        for (int l = 0; l < lv[p]->n_levels; ++l) RA.rs_off[p][l] = P.lp[p][l].rs_off;
+        RA.rs_total[p] = P.rs_total[p];
+        if (P.rs_total[p] > rs_max) rs_max = P.rs_total[p];
+    }
+    hipLaunchKernelGGL(rowstart_kernel, dim3((rs_max + 255) / 256, 3), dim3(256), 0, s, RA, n);
+
+    BandArgs BA;
+    BA.plan = P;
+    float* grads[3] = {g0, g1, g2};
+    for (int p = 0; p < 3; ++p) {
+        BA.lv[p] = *lv[p];
+        BA.cs[p] = (const float2*)(ws + W.cs[p]);
+        BA.dzs[p] = (const float*)(ws + W.dzs[p]);
+        BA.rowstart[p] = (const int*)(ws + W.rowstart[p]);
+        BA.grad[p] = grads[p];
+    }
+    BA.slabs = (float*)(ws + W.slabs);
+    BA.dzmax = (const unsigned*)(ws + W.dzmax);
+    int hb = 1;
+    while (((int64_t)1 << hb) < n) ++hb;
+    BA.headroom_bits = hb + 1;
+    hipLaunchKernelGGL((band_kernel<F>), dim3(P.total_blocks), dim3(kBandThreads), kLdsEntries * 8, s, BA, n);
+
+    if (P.reduce_items > 0) {
+        ReduceArgs R;
+        R.plan = P;
+        for (int p = 0; p < 3; ++p) { R.lv[p] = *lv[p]; R.grad[p] = grads[p]; }
+        R.slabs = (const float*)(ws + W.slabs);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(64, P.reduce_items), dim3(256), 0, s, R);
+    }
+
+    hipLaunchKernelGGL(sparse_bwd_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, dz, dz_stride, col, demb, n, *sh);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt) {
+    if (n < 0 || !levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt)) return NVP_ERR_BADARG;
+    if (n == 0) return 256;
+    const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
+    Plan P;
+    make_plan(P, lv, n);
+    Ws W;
+    if (carve(W, P, lv, n)) return NVP_ERR_BADARG;
+    return (int64_t)W.total;
+}
+
+// dz: row-major latent gradient [>= n][dz_stride] (columns xy | yt | xt | sparse).
+// d_kf_*: every element is OVERWRITTEN (no zero-fill needed); d_emb: accumulate (caller zeroes).
+int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
+                   float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
+                   const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh || n < 0) return NVP_ERR_BADARG;
+    if (lv_xy->n_features != lv_yt->n_features || lv_xy->n_features != lv_xt->n_features) return NVP_ERR_UNSUPPORTED;
+    if (n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;
+    const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        // an empty batch still owes zero gradients for the planes it "overwrites"
+        for (int p = 0; p < 3; ++p) {
+            float* g = p == 0 ? d_kf_xy : (p == 1 ? d_kf_yt : d_kf_xt);
+            hipError_t e = hipMemsetAsync(g, 0, (size_t)lv[p]->offset[lv[p]->n_levels] * lv[p]->n_features * 4, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
+    }
+    if (!coords || !dz || !d_kf_xy || !d_kf_yt || !d_kf_xt || !d_emb || !workspace) return NVP_ERR_BADARG;
+    Plan P;
+    make_plan(P, lv, n);
+    Ws W;
+    int rc = carve(W, P, lv, n);
+    if (rc) return rc;
+    if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
+    const int need = lv_xy->n_levels * lv_xy->n_features + lv_yt->n_levels * lv_yt->n_features + lv_xt->n_levels * lv_xt->n_features +
+                     9 * sh->n_features;
+    if (dz_stride < need) return NVP_ERR_BADARG;
+    switch (lv_xy->n_features) {
+        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
+        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
+        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
+        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
+        default: return NVP_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

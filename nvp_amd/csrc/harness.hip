@@ -4,6 +4,10 @@
 // fused with its own gradient.
 #include "nvp_common.h"
 
+// __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
+// index and interpolation arithmetic keeps the reference's separately rounded multiply and add.
+#pragma clang fp contract(off)
+
 namespace {
 
 // coords = (tcoord_tab[ti], row/(H-1), col/(W-1)) with pi = row*W + col   (dataio.py:11-20,106-118)

@@ -26,13 +26,12 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const float* __restrict__ packed,
                                                                     float* __restrict__ dy, float* __restrict__ xs,
-                                                                    float* __restrict__ dzt, int64_t n, int64_t ntiles, int d) {
+                                                                    float* __restrict__ dzr, int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     if (tile >= ntiles) return;                       // wave-uniform
     const int j = lane & 31, h = lane >> 5;
     const NvpBwdLayout L = nvp_bwd_layout(d);
-    const int rows = nvp_rows_even(d);
     const int64_t px = tile * 32 + j;
     const bool valid = px < n;
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
@@ -135,15 +134,19 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
         chain_hz<ZT>(dz, dp, packed + L.off[4], lane);         // stream 4 (z0^T)
     }
 
-    // ---- latent gradient out (PTM, rows = D rounded up to even)
+    // ---- latent gradient out, ROW-MAJOR [pixel][stride] (stride = D rounded up to 4): a lane
+    //      owns 4 consecutive features per register group -> one 16-B store; the scatter stage
+    //      then gathers a pixel's features as contiguous 128-B runs.
     {
-        float* o = dzt + tile * (int64_t)rows * 32;
+        const int stride = nvp_dz_stride_dev(d);
+        float* o = dzr + px * stride;
 #pragma unroll
         for (int T = 0; T < ZT; ++T)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * T + nvp_frag_row(r, h);
-                if (row < rows) o[row * 32 + j] = dz[T][r];
+            for (int g = 0; g < 4; ++g) {
+                const int base = 32 * T + 8 * g + 4 * h;
+                if (base < stride)
+                    *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
             }
     }
 }
@@ -151,16 +154,16 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
 }  // namespace
 
 extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                              const float* packed_bwd, float* dy, float* xs, float* dzt, int64_t n, int32_t d, void* stream) {
-    if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !xs || !dzt || n < 0 || d < 1) return NVP_ERR_BADARG;
+                              const float* packed_bwd, float* dy, float* xs, float* dz_rows, int64_t n, int32_t d, void* stream) {
+    if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !xs || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     if (zt == 4)
-        hipLaunchKernelGGL(mlp_bwd_dx_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dzt, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_dx_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dz_rows, n, ntiles, d);
     else if (zt == 8)
-        hipLaunchKernelGGL(mlp_bwd_dx_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dzt, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_dx_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dz_rows, n, ntiles, d);
     else
         return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
     NVP_LAUNCH_CHECK();

@@ -161,17 +161,17 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
     dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
     xs = torch.empty((3, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
-    dzt = torch.empty_like(zt)
+    dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
     drgb = _f32c(drgb)
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
-                               L.ptr(dy), L.ptr(xs), L.ptr(dzt), n, d, stream), "nvp_mlp_bwd_dx")
+                               L.ptr(dy), L.ptr(xs), L.ptr(dz_rows), n, d, stream), "nvp_mlp_bwd_dx")
     grads = [torch.empty_like(t) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
     L.check(_call("nvp_mlp_bwd_dw", lib.nvp_mlp_bwd_dw, L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), L.ptr(xs),
                                L.ptr(partials), nch, C.byref(gstruct), n, d, stream), "nvp_mlp_bwd_dw")
-    return dzt, grads
+    return dz_rows, grads
 
 
 def _check_mlp(mlp: Sequence[torch.Tensor], d: int) -> None:
@@ -202,7 +202,7 @@ class ModulatedSiren(torch.autograd.Function):
         zt = torch.empty((L.ntiles(n), rows, L.TILE), device=latent.device, dtype=torch.float32)
         if n:
             L.check(lib.nvp_rows_to_ptm(L.ptr(latent), L.ptr(zt), n, d, rows, L.stream_ptr()), "nvp_rows_to_ptm")
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
         ctx.n, ctx.d, ctx.rows = n, d, rows
         if need_grad:
@@ -218,10 +218,8 @@ class ModulatedSiren(torch.autograd.Function):
         n, d = ctx.n, ctx.d
         if n == 0:
             return (torch.zeros((0, d), device=zt.device), None, *[torch.zeros_like(t) for t in mlp])
-        dzt, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
-        dlat = torch.empty((n, d), device=zt.device, dtype=torch.float32)
-        L.check(lib.nvp_ptm_to_rows(L.ptr(dzt), L.ptr(dlat), n, d, ctx.rows, L.stream_ptr()), "nvp_ptm_to_rows")
-        return (dlat, None, *grads)
+        dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
+        return (dz_rows[:n, :d].contiguous(), None, *grads)
 
 
 class NVPFused(torch.autograd.Function):
@@ -249,7 +247,7 @@ class NVPFused(torch.autograd.Function):
             L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
                                        1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_fwd")
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
         rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
         if need_grad:
             if temporal_interp:
@@ -267,12 +265,22 @@ class NVPFused(torch.autograd.Function):
         lib = L.load()
         coords, steps, zt, saved, kf_xy, kf_yt, kf_xt, emb, *mlp = ctx.saved_tensors
         n, d = ctx.n, ctx.d
-        d_xy, d_yt, d_xt, d_emb = (torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb))
         if n == 0:
-            return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
-        dzt, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
+            z = [torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb)]
+            return (None, None, *z, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
+        dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
-        L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dzt), L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
-                                   C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.stream_ptr()),
+        # keyframe gradients are written exactly once per element by the sorted-band scatter
+        # (no zero-fill); the sparse grid still accumulates with atomics into zeros.
+        d_xy, d_yt, d_xt = (torch.empty_like(t) for t in (kf_xy, kf_yt, kf_xt))
+        d_emb = torch.zeros_like(emb)
+        ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]))
+        if ws_bytes < 0:
+            raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
+        ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
+        L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1],
+                      L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
+                      C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
+                      L.ptr(ws, torch.uint8), ws_bytes, L.stream_ptr()),
                 "nvp_encode_bwd")
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *grads)
