@@ -189,7 +189,7 @@ class ModulatedSiren(torch.autograd.Function):
     """SirenWrapper.forward(coords=steps [N,1], latent [N,D]) -> [N,3]  (R8-R10, R12)."""
 
     @staticmethod
-    def forward(ctx, latent: torch.Tensor, steps: torch.Tensor, *mlp: torch.Tensor) -> torch.Tensor:
+    def forward(ctx, latent: torch.Tensor, steps: torch.Tensor, grad_mode: bool, *mlp: torch.Tensor) -> torch.Tensor:
         lib = L.load()
         latent = _f32c(latent)
         n, d = latent.shape
@@ -202,7 +202,7 @@ class ModulatedSiren(torch.autograd.Function):
         zt = torch.empty((L.ntiles(n), rows, L.TILE), device=latent.device, dtype=torch.float32)
         if n:
             L.check(lib.nvp_rows_to_ptm(L.ptr(latent), L.ptr(zt), n, d, rows, L.stream_ptr()), "nvp_rows_to_ptm")
-        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
         ctx.n, ctx.d, ctx.rows = n, d, rows
         if need_grad:
@@ -217,9 +217,9 @@ class ModulatedSiren(torch.autograd.Function):
         zt, steps, saved, *mlp = ctx.saved_tensors
         n, d = ctx.n, ctx.d
         if n == 0:
-            return (torch.zeros((0, d), device=zt.device), None, *[torch.zeros_like(t) for t in mlp])
+            return (torch.zeros((0, d), device=zt.device), None, None, *[torch.zeros_like(t) for t in mlp])
         dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
-        return (dz_rows[:n, :d].contiguous(), None, *grads)
+        return (dz_rows[:n, :d].contiguous(), None, None, *grads)
 
 
 class NVPFused(torch.autograd.Function):
@@ -227,7 +227,7 @@ class NVPFused(torch.autograd.Function):
     (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""
 
     @staticmethod
-    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, *mlp):
+    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, grad_mode, *mlp):
         lib = L.load()
         coords = _f32c(coords)
         steps = _f32c(steps).reshape(-1)
@@ -247,7 +247,7 @@ class NVPFused(torch.autograd.Function):
             L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
                                        1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_fwd")
-        need_grad = torch.is_grad_enabled() and any(ctx.needs_input_grad)
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
         if need_grad:
             if temporal_interp:
@@ -267,7 +267,7 @@ class NVPFused(torch.autograd.Function):
         n, d = ctx.n, ctx.d
         if n == 0:
             z = [torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb)]
-            return (None, None, *z, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
+            return (None, None, *z, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
         dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
         # keyframe gradients are written exactly once per element by the sorted-band scatter
@@ -283,4 +283,4 @@ class NVPFused(torch.autograd.Function):
                       C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
                       L.ptr(ws, torch.uint8), ws_bytes, L.stream_ptr()),
                 "nvp_encode_bwd")
-        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, *grads)
+        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, *grads)

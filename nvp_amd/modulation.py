@@ -138,4 +138,4 @@ class SirenWrapper(nn.Module):
     def forward(self, coords, latent=None):
         modulate = exists(self.modulator)
         assert not (modulate ^ exists(latent)), 'latent vector must be only supplied if `latent_dim` was passed in on instantiation'
-        return ModulatedSiren.apply(latent, coords, *self.mlp_tensors())
+        return ModulatedSiren.apply(latent, coords, torch.is_grad_enabled(), *self.mlp_tensors())

@@ -53,5 +53,5 @@ class NVP(nn.Module):
                              self.keyframes_xy.params, self.keyframes_yt.params, self.keyframes_xt.params,
                              self.sparse_grid.embeddings,
                              self.keyframes_xy.levels, self.keyframes_yt.levels, self.keyframes_xt.levels,
-                             bool(temporal_interp), *self.wrapper.mlp_tensors())
+                             bool(temporal_interp), torch.is_grad_enabled(), *self.wrapper.mlp_tensors())
         return {'model_out': out.reshape((b, t, 3))}

@@ -194,6 +194,19 @@ def modulator_forward(z: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[
     return tuple(hs)
 
 
+def modulator_preacts(z: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]):
+    """The three LeakyReLU inputs (same arithmetic as modulator_forward).  Tests use them to
+    keep gradient comparisons away from the kink at 0, where d/dp jumps from 0.01 to 1 and a
+    1-ulp difference in p (summation order) legitimately changes the gradient."""
+    pre = []
+    x = z
+    for W, b in zip(Ws, bs):
+        p = F.linear(x, W, b)
+        pre.append(p)
+        x = torch.cat((F.leaky_relu(p, LRELU_SLOPE), z), dim=1)
+    return tuple(pre)
+
+
 def siren_forward(s: torch.Tensor, mods, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
                   W_last: torch.Tensor, b_last: torch.Tensor, w0_first: float = W0_FIRST) -> torch.Tensor:
     """x_k = sin(w0_k * (x_{k-1} W_k^T + b_k)) * mod_k, w0 = (30, 1, 1); rgb = x W_last^T + b_last
