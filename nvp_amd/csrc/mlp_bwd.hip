@@ -5,9 +5,10 @@
 // Same structure as mlp_fwd.hip: one wavefront = one 32-pixel tile, every transposed GEMM
 //   dX[in][pixel] = sum_out W[out][in] * dY[out][pixel]
 // runs on v_mfma_f32_32x32x2_f32 with A = packed W^T stream and B = the dY registers that
-// the previous stage just produced.  The kernel runs one wave per SIMD (512 registers) so
-// dq/dp of a layer, two 64-register accumulators and the latent-gradient accumulator all
-// stay resident; nothing is staged through LDS.
+// the previous stage just produced; nothing is staged through LDS.  Two kernels, both at two
+// waves per SIMD so one wave's element-wise / memory phases hide behind the other's MFMAs:
+// the chain kernel (dq, dp, one accumulator: <= 256 registers) and the latent-gradient
+// kernel, which re-reads the three dp streams it needs (an extra 1.5 KB/px of warm reads).
 //
 // Chain (forward names: p_k modulator pre-activation, h_k = lrelu(p_k), q_k SIREN
 // pre-sine, x_k = sin(q_k) h_k, q_0 = 30 (w s + c)):
@@ -21,14 +22,19 @@ namespace {
 
 constexpr int kWaves = 4;
 
-template <int ZT>
-__global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
+// ------------------------------------------------------------------------------------------
+// Kernel A: the dX chain without the latent gradient.  Register plan (2 waves/SIMD, <= 256):
+//   dx[4], dh[4] (128) are rewritten in place into dq, dp by the element-wise stage, then
+//   dx' = chain(dq) needs one 64-register accumulator (192 live), after which dq is dead and
+//   dh' = chain(dp) reuses the space.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const float* __restrict__ packed,
                                                                     float* __restrict__ dy, float* __restrict__ xs,
-                                                                    float* __restrict__ dzr, int64_t n, int64_t ntiles, int d) {
+                                                                    int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
     if (tile >= ntiles) return;                       // wave-uniform
     const int j = lane & 31, h = lane >> 5;
     const NvpBwdLayout L = nvp_bwd_layout(d);
@@ -41,11 +47,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
     float* xst = xs + tb;                  // x0,x1,x2
     const float4* wp = reinterpret_cast<const float4*>(packed);
 
-    f32x16 dz[ZT];
-#pragma unroll
-    for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
-
-    f32x16 dx[4], dh[4], dq[4], dp[4];
+    f32x16 dx[4], dh[4];
 
     // ---- last layer: dx2 = V3^T drgb (VALU, 3 terms)
     {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
         for (int T = 0; T < 4; ++T) dh[T] = nvp_zero16();
     }
 
-    // ---- layers 2, 1: element-wise stage then the three transposed GEMMs
+    // ---- layers 2, 1: element-wise stage (dx,dh -> dq,dp in place) then the two transposed GEMMs
 #pragma unroll
     for (int k = 2; k >= 1; --k) {
         const float* hk = sv + (int64_t)k * act;
@@ -82,25 +84,30 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
                 nvp_sincos(qv[r], sn, cs);
                 const float dxv = dx[T][r];
                 xv[r] = sn * hv[r];
-                dq[T][r] = dxv * hv[r] * cs;
+                dx[T][r] = dxv * hv[r] * cs;                      // dq
                 const float dhv = dh[T][r] + dxv * sn;
-                dp[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
+                dh[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;       // dp
             }
-            nvp_pin(dq[T]);
-            nvp_pin(dp[T]);
+            nvp_pin(dx[T]);
+            nvp_pin(dh[T]);
             store_ptm16(xst + (int64_t)k * act, xv, T, lane);
-            store_ptm16(dyt + (int64_t)(3 + k) * act, dq[T], T, lane);
-            store_ptm16(dyt + (int64_t)k * act, dp[T], T, lane);
+            store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
+            store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
             NVP_LOAD_FENCE();
         }
-        // dx_{k-1} = V_k^T dq_k ; dh_{k-1} = W_k[:, :128]^T dp_k ; dz += W_k[:, 128:]^T dp_k
+        // dx_{k-1} = V_k^T dq_k
+        f32x16 acc[4];
 #pragma unroll
-        for (int T = 0; T < 4; ++T) { dx[T] = nvp_zero16(); dh[T] = nvp_zero16(); }
-        chain_h(dx, dq, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
-        chain_h(dh, dp, wp + L.off[4 - k] / 4, lane);          // streams 2 (mod2h^T), 3 (mod1h^T)
-        chain_hz<ZT>(dz, dp, packed + L.off[4 + k], lane);     // streams 6 (z2^T), 5 (z1^T)
+        for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+        chain_h<2>(acc, dx, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
 #pragma unroll
-        for (int T = 0; T < 4; ++T) { nvp_pin(dx[T]); nvp_pin(dh[T]); }
+        for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+        // dh_{k-1} = W_k[:, :128]^T dp_k
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+        chain_h<2>(acc, dh, wp + L.off[4 - k] / 4, lane);          // streams 2 (mod2h^T), 3 (mod1h^T)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
     }
 
     // ---- layer 0: q0 = 30 (w s + c) is recomputed
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
         const float* h0 = sv;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            f32x16 hv, xv, dq0;
+            f32x16 hv, xv, dq0, dp0;
             load_ptm16(hv, h0, T, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -123,32 +130,70 @@ __global__ __launch_bounds__(kWaves * 64, 1) void mlp_bwd_dx_kernel(const float*
                 xv[r] = sn * hv[r];
                 dq0[r] = 30.0f * (dxv * hv[r] * cs);          // gradient w.r.t. (w s + c)
                 const float dhv = dh[T][r] + dxv * sn;
-                dp[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
+                dp0[r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
             }
-            nvp_pin(dp[T]);
             store_ptm16(xst, xv, T, lane);
             store_ptm16(dyt + 3 * act, dq0, T, lane);
-            store_ptm16(dyt, dp[T], T, lane);
+            store_ptm16(dyt, dp0, T, lane);
             NVP_LOAD_FENCE();
         }
-        chain_hz<ZT>(dz, dp, packed + L.off[4], lane);         // stream 4 (z0^T)
     }
+}
 
-    // ---- latent gradient out, ROW-MAJOR [pixel][stride] (stride = D rounded up to 4): a lane
-    //      owns 4 consecutive features per register group -> one 16-B store; the scatter stage
-    //      then gathers a pixel's features as contiguous 128-B runs.
-    {
-        const int stride = nvp_dz_stride_dev(d);
-        float* o = dzr + px * stride;
+// ------------------------------------------------------------------------------------------
+// Kernel Z: latent gradient  dz = W0^T dp0 + W1[:,128:]^T dp1 + W2[:,128:]^T dp2, reading the
+// three dp streams the chain kernel just wrote (L2/MALL-warm).  Output ROW-MAJOR
+// [pixel][stride] (stride = D rounded up to 4): a lane owns 4 consecutive features per
+// register group -> one 16-B store; the scatter stage gathers a pixel's features as
+// contiguous 128-B runs.
+// ------------------------------------------------------------------------------------------
+template <int ZT>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_kernel(const float* __restrict__ dy, const float* __restrict__ packed,
+                                                                    float* __restrict__ dzr, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
+    if (tile >= ntiles) return;
+    const int j = lane & 31, h = lane >> 5;
+    const NvpBwdLayout L = nvp_bwd_layout(d);
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    const float* dyt = dy + tile * (int64_t)NVP_H * 32;
+
+    f32x16 dz[ZT];
 #pragma unroll
-        for (int T = 0; T < ZT; ++T)
+    for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
+
+    f32x16 b[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int base = 32 * T + 8 * g + 4 * h;
-                if (base < stride)
-                    *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
+    for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + 2 * act, T, lane);
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+        f32x16 nb[4];
+        if (ZT == 4 && k > 0) {             // prefetch the next dp stream while this one is consumed
+#pragma unroll
+            for (int T = 0; T < 4; ++T) load_ptm16(nb[T], dyt + (int64_t)(k - 1) * act, T, lane);
+        }
+        NVP_LOAD_FENCE();
+        chain_hz<ZT>(dz, b, packed + L.off[4 + k], lane);       // streams 6 (z2^T), 5 (z1^T), 4 (z0^T)
+        if (k > 0) {
+            if (ZT == 4) {
+#pragma unroll
+                for (int T = 0; T < 4; ++T) b[T] = nb[T];
+            } else {
+#pragma unroll
+                for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + (int64_t)(k - 1) * act, T, lane);
             }
+        }
     }
+    const int stride = nvp_dz_stride_dev(d);
+    float* o = dzr + (tile * 32 + j) * stride;
+#pragma unroll
+    for (int T = 0; T < ZT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int base = 32 * T + 8 * g + 4 * h;
+            if (base < stride)
+                *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
+        }
 }
 
 }  // namespace
@@ -160,12 +205,12 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    if (zt != 4 && zt != 8) return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, n, ntiles, d);
     if (zt == 4)
-        hipLaunchKernelGGL(mlp_bwd_dx_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dz_rows, n, ntiles, d);
-    else if (zt == 8)
-        hipLaunchKernelGGL(mlp_bwd_dx_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, dz_rows, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_dz_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
     else
-        return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
+        hipLaunchKernelGGL(mlp_bwd_dz_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -16,17 +16,21 @@ __device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4 a, const fl
 constexpr int G = 4;
 #define NVP_LOAD_FENCE() asm volatile("" ::: "memory")
 
-// 64 chained steps: B operands are the previous layer's D registers.
+// 64 chained steps: B operands are the previous layer's D registers.  GG = k-steps per
+// prefetch group (register cost 8*GG for the double buffer).
+template <int GG = G>
 __device__ __forceinline__ void chain_h(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float4* __restrict__ wp, int lane) {
+    constexpr int G = GG;
     float4 a[2][G];
-    const float4* w = wp + lane;
+    // wp is wave-uniform (SGPR base); lane is the only per-lane part -> saddr + voffset + imm loads
+    const unsigned ul = (unsigned)lane;
 #pragma unroll
-    for (int i = 0; i < G; ++i) a[0][i] = w[i * 64];
+    for (int i = 0; i < G; ++i) a[0][i] = (wp + i * 64)[ul];
 #pragma unroll
     for (int g = 0; g < 64 / G; ++g) {
         if (g + 1 < 64 / G) {
 #pragma unroll
-            for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = w[((g + 1) * G + i) * 64];
+            for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = (wp + ((g + 1) * G + i) * 64)[ul];
         }
         NVP_LOAD_FENCE();
 #pragma unroll
@@ -40,19 +44,23 @@ __device__ __forceinline__ void chain_h(f32x16 (&acc)[4], const f32x16 (&hin)[4]
 // zs steps over the latent: step u consumes rows 2u (lane half 0) and 2u+1 (half 1).
 __device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float* __restrict__ z, int zs,
                                         const float4* __restrict__ wp, int lane) {
-    const float* zl = z + (lane >> 5) * 32 + (lane & 31);
-    const float4* w = wp + lane;
+    // z and wp are wave-uniform; row 2u+h of the PTM latent sits at (2u+h)*32 + j = u*64 + lane
+    const unsigned ul = (unsigned)lane;
+    const float* zl = z;
+    const float4* w = wp;
     const int ng = zs / G;
     float4 a[G], an[G];
     float b[G], bn[G];
     if (ng > 0) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) { a[i] = w[i * 64]; b[i] = zl[i * 64]; }
+        for (int i = 0; i < G; ++i) { a[i] = (w + i * 64)[ul]; b[i] = (zl + i * 64)[ul]; }
     }
     for (int g = 0; g < ng; ++g) {
         if (g + 1 < ng) {
+            const float4* wn = w + (g + 1) * G * 64;      // scalar pointer bumps
+            const float* zn = zl + (g + 1) * G * 64;
 #pragma unroll
-            for (int i = 0; i < G; ++i) { an[i] = w[((g + 1) * G + i) * 64]; bn[i] = zl[((g + 1) * G + i) * 64]; }
+            for (int i = 0; i < G; ++i) { an[i] = (wn + i * 64)[ul]; bn[i] = (zn + i * 64)[ul]; }
         }
         NVP_LOAD_FENCE();
 #pragma unroll
@@ -60,7 +68,7 @@ __device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float* __restric
 #pragma unroll
         for (int i = 0; i < G; ++i) { a[i] = an[i]; b[i] = bn[i]; }
     }
-    for (int u = ng * G; u < zs; ++u) mfma4(acc, w[u * 64], zl[u * 64]);
+    for (int u = ng * G; u < zs; ++u) mfma4(acc, (w + u * 64)[ul], (zl + u * 64)[ul]);
 }
 
 __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
@@ -70,12 +78,16 @@ __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
         for (int r = 0; r < 16; ++r) v[T][r] = v[T][r] > 0.f ? v[T][r] : v[T][r] * 0.01f;
 }
 
+// PTM addressing with a wave-uniform tile base: row 32T + 8g + 4h + e, pixel j sits at
+// tile_base[(32T + 8g + e)*32 + (128h + j)] - a compile-time constant plus one 32-bit lane offset.
+__device__ __forceinline__ unsigned nvp_lane_off(int lane) { return (unsigned)(((lane >> 5) << 7) + (lane & 31)); }
+
 __device__ __forceinline__ void store_ptm(float* __restrict__ tile_base, const f32x16 (&v)[4], int lane) {
-    const int j = lane & 31, h = lane >> 5;
+    const unsigned lo = nvp_lane_off(lane);
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tile_base[(32 * T + nvp_frag_row(r, h)) * 32 + j] = v[T][r];
+        for (int r = 0; r < 16; ++r) (tile_base + (32 * T + 8 * (r >> 2) + (r & 3)) * 32)[lo] = v[T][r];
 }
 
 
@@ -84,20 +96,21 @@ __device__ __forceinline__ void store_ptm(float* __restrict__ tile_base, const f
 template <int ZT>
 __device__ __forceinline__ void chain_hz(f32x16 (&acc)[ZT], const f32x16 (&hin)[4], const float* __restrict__ wp, int lane) {
     constexpr int Q = ZT / 4;                     // float4 per lane per step
-    const float4* w = reinterpret_cast<const float4*>(wp) + lane * Q;
+    const float4* w = reinterpret_cast<const float4*>(wp);      // wave-uniform
+    const unsigned ul = (unsigned)(lane * Q);
     constexpr int GZ = 2;
     float4 a[2][GZ][Q];
 #pragma unroll
     for (int i = 0; i < GZ; ++i)
 #pragma unroll
-        for (int q = 0; q < Q; ++q) a[0][i][q] = w[i * 64 * Q + q];
+        for (int q = 0; q < Q; ++q) a[0][i][q] = (w + (i * 64 * Q + q))[ul];
 #pragma unroll
     for (int g = 0; g < 64 / GZ; ++g) {
         if (g + 1 < 64 / GZ) {
 #pragma unroll
             for (int i = 0; i < GZ; ++i)
 #pragma unroll
-                for (int q = 0; q < Q; ++q) a[(g + 1) & 1][i][q] = w[((g + 1) * GZ + i) * 64 * Q + q];
+                for (int q = 0; q < Q; ++q) a[(g + 1) & 1][i][q] = (w + (((g + 1) * GZ + i) * 64 * Q + q))[ul];
         }
         NVP_LOAD_FENCE();
 #pragma unroll
@@ -117,13 +130,13 @@ __device__ __forceinline__ void chain_hz(f32x16 (&acc)[ZT], const f32x16 (&hin)[
 
 // Load one 16-row block (tile T) of a PTM activation into fragment registers.
 __device__ __forceinline__ void load_ptm16(f32x16& v, const float* __restrict__ tile_base, int T, int lane) {
-    const int j = lane & 31, h = lane >> 5;
+    const unsigned lo = nvp_lane_off(lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = tile_base[(32 * T + nvp_frag_row(r, h)) * 32 + j];
+    for (int r = 0; r < 16; ++r) v[r] = (tile_base + (32 * T + 8 * (r >> 2) + (r & 3)) * 32)[lo];
 }
 
 __device__ __forceinline__ void store_ptm16(float* __restrict__ tile_base, const f32x16& v, int T, int lane) {
-    const int j = lane & 31, h = lane >> 5;
+    const unsigned lo = nvp_lane_off(lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile_base[(32 * T + nvp_frag_row(r, h)) * 32 + j] = v[r];
+    for (int r = 0; r < 16; ++r) (tile_base + (32 * T + 8 * (r >> 2) + (r & 3)) * 32)[lo] = v[r];
 }

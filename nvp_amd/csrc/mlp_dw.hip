@@ -7,9 +7,11 @@
 //    by mlp_fwd/mlp_bwd, so an MFMA fragment for feature row i is "16 consecutive pixels of
 //    row i" = one 64-B run per lane, a fully coalesced 4-KiB read per wave - no transposes;
 //    lane (i, h) feeds pixel 16h + k at k-step k on BOTH operands, so the pairing is exact.
-//  * a job = one (layer, group of 4 column tiles); grid = (pixel chunk, job).  Wave w of the
-//    block owns output rows 32w..32w+31 and four 32x32 accumulators (64 registers) that
-//    stay resident across its whole pixel chunk.
+//  * a job = one (layer, group of 4 column tiles) = a 128 x 128 block of one dW; grid = (pixel
+//    chunk, job).  Each of the 4 waves owns a 64 x 64 sub-block = 2 x 2 MFMA tiles (64
+//    accumulator registers resident across the whole pixel chunk; 2 A + 2 B fragments feed
+//    64 MFMAs per 32-pixel tile); the next tile's fragments are prefetched into a second
+//    register set while the current tile's MFMAs run.
 //  * per-chunk partial results are written in the parameters' natural [out][in] layout
 //    (a D fragment row is 32 consecutive `in` columns = one 128-B line), then summed over
 //    chunks by a second kernel in a fixed order -> deterministic gradients.
@@ -50,9 +52,42 @@ __device__ __forceinline__ void load_frag(float (&f)[16], const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk) {
+// fragment set of one 32-pixel tile for a wave that owns a 64-row x 64-column block (2 x 2 MFMA tiles)
+struct Frags {
+    float a[2][16];
+    float b[2][16];
+};
+
+__device__ __forceinline__ void load_frags(Frags& f, const DwJob& J, int64_t t, int wr, int wc, int i, int h, const bool (&bval)[2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) load_frag(f.a[r], J.a + ((t * NVP_H + 64 * wr + 32 * r + i) * 32 + 16 * h));
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (bval[c]) load_frag(f.b[c], J.b + ((t * J.b_rows + J.b_row0 + 64 * wc + 32 * c + i) * 32 + 16 * h));
+        else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) f.b[c][k] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void mma_frags(f32x16 (&acc)[2][2], const Frags& f, float& bsum, bool want_bias) {
+    if (want_bias) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bsum += f.a[0][k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        acc[0][0] = nvp_mfma(f.a[0][k], f.b[0][k], acc[0][0]);
+        acc[0][1] = nvp_mfma(f.a[0][k], f.b[1][k], acc[0][1]);
+        acc[1][0] = nvp_mfma(f.a[1][k], f.b[0][k], acc[1][0]);
+        acc[1][1] = nvp_mfma(f.a[1][k], f.b[1][k], acc[1][1]);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk) {
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // provably wave-uniform
     const int i = lane & 31, h = lane >> 5;
     const int chunk = blockIdx.x;
     const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
@@ -61,48 +96,62 @@ __global__ __launch_bounds__(256) void mlp_dw_kernel(DwArgs A, float* __restrict
 
     if ((int)blockIdx.y < A.n_jobs - 1) {
         const DwJob J = A.job[blockIdx.y];
-        f32x16 acc[4];
+        const int wr = w >> 1, wc = w & 1;            // wave owns rows 64wr.., columns 64wc..
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = nvp_zero16();
-        float bsum = 0.f;
-        bool bval[4];
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bval[c] = (32 * c + i) < J.n_cols;
+            for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
+        float bsum = 0.f, bsum1 = 0.f;
+        bool bval[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bval[c] = (64 * wc + 32 * c + i) < J.n_cols;
+        const bool want_bias = (J.bias_off >= 0) && (wc == 0);
 
-        for (int64_t t = t0; t < t1; ++t) {
-            float a[16];
-            load_frag(a, J.a + ((t * NVP_H + 32 * w + i) * 32 + 16 * h));
-            if (J.bias_off >= 0) {
+        // software pipeline over pixel tiles: the next tile's 16 x 16-B loads are in flight while
+        // the 64 MFMAs of the current tile run (two statically named fragment sets)
+        Frags f0, f1;
+        int64_t t = t0;
+        if (t < t1) load_frags(f0, J, t, wr, wc, i, h, bval);
+        while (t < t1) {
+            if (t + 1 < t1) load_frags(f1, J, t + 1, wr, wc, i, h, bval);
+            asm volatile("" ::: "memory");
+            mma_frags(acc, f0, bsum, want_bias);
+            if (want_bias) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) bsum += a[k];
+                for (int k = 0; k < 16; ++k) bsum1 += f0.a[1][k];
             }
+            if (++t >= t1) break;
+            if (t + 1 < t1) load_frags(f0, J, t + 1, wr, wc, i, h, bval);
+            asm volatile("" ::: "memory");
+            mma_frags(acc, f1, bsum, want_bias);
+            if (want_bias) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float b[16];
-                if (bval[c]) load_frag(b, J.b + ((t * J.b_rows + J.b_row0 + 32 * c + i) * 32 + 16 * h));
-                else {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) b[k] = 0.f;
-                }
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[c] = nvp_mfma(a[k], b[k], acc[c]);
+                for (int k = 0; k < 16; ++k) bsum1 += f1.a[1][k];
             }
+            ++t;
         }
         // D[row = out][col = in]: lane holds column i of each tile, rows 8g+4h+e
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = 32 * c + i;
+        for (int c = 0; c < 2; ++c) {
+            const int col = 64 * wc + 32 * c + i;
             if (col < J.n_cols) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * w + nvp_frag_row(r, h);
-                    part[J.w_off + (int64_t)row * J.ld + col] = acc[c][r];
-                }
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 64 * wr + 32 * r2 + nvp_frag_row(r, h);
+                        part[J.w_off + (int64_t)row * J.ld + col] = acc[r2][c][r];
+                    }
             }
         }
-        if (J.bias_off >= 0) {
+        if (want_bias) {
             bsum += __shfl_xor(bsum, 32);
-            if (h == 0) part[J.bias_off + 32 * w + i] = bsum;
+            bsum1 += __shfl_xor(bsum1, 32);
+            if (h == 0) {
+                part[J.bias_off + 64 * wr + i] = bsum;
+                part[J.bias_off + 64 * wr + 32 + i] = bsum1;
+            }
         }
         return;
     }

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
                                                                  float* __restrict__ rgb, float* __restrict__ saved,
                                                                  int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
     if (tile >= ntiles) return;                       // wave-uniform
     const int j = lane & 31, h = lane >> 5;
     const NvpFwdLayout L = nvp_fwd_layout(d);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
         const float4* w = wp + L.off[0] / 4;
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
-        mfma4(hm, w[lane], 1.0f);
+        mfma4(hm, w[(unsigned)lane], 1.0f);
         chain_z(hm, z, L.zs, w + 64, lane);
         lrelu4(hm);
 #pragma unroll
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
             const float4* w = wp + L.off[k] / 4;
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            mfma4(acc, w[lane], 1.0f);
+            mfma4(acc, w[(unsigned)lane], 1.0f);
             chain_h(acc, hm, w + 64, lane);
             chain_z(acc, z, L.zs, w + 65 * 64, lane);
             lrelu4(acc);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
             const float4* w = wp + L.off[2 + k] / 4;
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            mfma4(acc, w[lane], 1.0f);
+            mfma4(acc, w[(unsigned)lane], 1.0f);
             chain_h(acc, x, w + 64, lane);
             if (SAVE) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll

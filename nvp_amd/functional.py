@@ -56,7 +56,7 @@ def _call(name, fn, *args):
 
 def dw_chunks(n: int) -> int:
     """Number of pixel chunks of the split-K weight-gradient GEMMs."""
-    return max(1, min(128, L.ntiles(n) // 8))
+    return max(1, min(256, L.ntiles(n) // 8))
 
 
 # --------------------------------------------------------------------------------------

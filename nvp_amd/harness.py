@@ -90,7 +90,11 @@ class DeviceVideo:
 
 def make_optimizer(model: torch.nn.Module, total_steps: int, lr: float = 1e-2):
     """AdamW(lr, weight_decay=1e-3) + CosineAnnealingLR(T_max=steps, eta_min=1e-5): training.py:13-14."""
-    opt = torch.optim.AdamW(lr=lr, params=model.parameters(), weight_decay=0.001)
+    # same update rule as the reference's torch.optim.AdamW; on a HIP device the single-pass
+    # "fused" implementation is used instead of the multi-pass foreach one (K13: 3.8 GB/step)
+    params = list(model.parameters())
+    fused = bool(params) and all(p.is_cuda for p in params)
+    opt = torch.optim.AdamW(lr=lr, params=params, weight_decay=0.001, fused=fused)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=total_steps, eta_min=1e-5)
     return opt, sched
 
