@@ -3,6 +3,17 @@
 #pragma once
 #include "mlp_layout.h"
 
+#ifdef NVP_ABL_NOLOAD      // ablation: weight operand from a register instead of memory
+#define NVP_WLOAD(ptr_expr) make_float4(1e-3f, 2e-3f, 3e-3f, 4e-3f)
+#else
+#define NVP_WLOAD(ptr_expr) (ptr_expr)
+#endif
+#if defined(NVP_ABL_NOLOAD) || defined(NVP_ABL_NOZ)   // ablation: latent operand from a register
+#define NVP_ZLOAD(ptr_expr) 0.25f
+#else
+#define NVP_ZLOAD(ptr_expr) (ptr_expr)
+#endif
+
 __device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4 a, const float b) {
     acc[0] = nvp_mfma(a.x, b, acc[0]);
     acc[1] = nvp_mfma(a.y, b, acc[1]);
@@ -13,8 +24,20 @@ __device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4 a, const fl
 // Operand loads are software-pipelined by hand in groups of G k-steps (double-buffered in
 // registers); the empty asm with a memory clobber stops hipcc from hoisting every load of
 // the unrolled chain to the top (which costs >100 VGPRs and spills).
-constexpr int G = 4;
+#ifndef NVP_G
+#define NVP_G 4
+#endif
+constexpr int G = NVP_G;
 #define NVP_LOAD_FENCE() asm volatile("" ::: "memory")
+// Inside the MFMA chains the fence must also pin the MFMAs: hipcc otherwise hoists the (register-only)
+// MFMAs of group g above it and sinks the loads of group g+1 next to their consumers, which shrinks the
+// prefetch distance to ONE k-step (256 cycles < L2 latency; seen as `s_waitcnt vmcnt(1)` before every
+// MFMA quad, MFMA pipe 62 % busy).  sched_barrier(0) lets nothing cross.
+#ifdef NVP_ABL_NOSB
+#define NVP_CHAIN_FENCE() NVP_LOAD_FENCE()
+#else
+#define NVP_CHAIN_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 // 64 chained steps: B operands are the previous layer's D registers.  GG = k-steps per
 // prefetch group (register cost 8*GG for the double buffer).
@@ -25,14 +48,14 @@ __device__ __forceinline__ void chain_h(f32x16 (&acc)[4], const f32x16 (&hin)[4]
     // wp is wave-uniform (SGPR base); lane is the only per-lane part -> saddr + voffset + imm loads
     const unsigned ul = (unsigned)lane;
 #pragma unroll
-    for (int i = 0; i < G; ++i) a[0][i] = (wp + i * 64)[ul];
+    for (int i = 0; i < G; ++i) a[0][i] = NVP_WLOAD((wp + i * 64)[ul]);
 #pragma unroll
     for (int g = 0; g < 64 / G; ++g) {
         if (g + 1 < 64 / G) {
 #pragma unroll
-            for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = (wp + ((g + 1) * G + i) * 64)[ul];
+            for (int i = 0; i < G; ++i) a[(g + 1) & 1][i] = NVP_WLOAD((wp + ((g + 1) * G + i) * 64)[ul]);
         }
-        NVP_LOAD_FENCE();
+        NVP_CHAIN_FENCE();
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int step = g * G + i;
@@ -53,22 +76,22 @@ __device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float* __restric
     float b[G], bn[G];
     if (ng > 0) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) { a[i] = (w + i * 64)[ul]; b[i] = (zl + i * 64)[ul]; }
+        for (int i = 0; i < G; ++i) { a[i] = NVP_WLOAD((w + i * 64)[ul]); b[i] = NVP_ZLOAD((zl + i * 64)[ul]); }
     }
     for (int g = 0; g < ng; ++g) {
         if (g + 1 < ng) {
             const float4* wn = w + (g + 1) * G * 64;      // scalar pointer bumps
             const float* zn = zl + (g + 1) * G * 64;
 #pragma unroll
-            for (int i = 0; i < G; ++i) { an[i] = (wn + i * 64)[ul]; bn[i] = (zn + i * 64)[ul]; }
+            for (int i = 0; i < G; ++i) { an[i] = NVP_WLOAD((wn + i * 64)[ul]); bn[i] = NVP_ZLOAD((zn + i * 64)[ul]); }
         }
-        NVP_LOAD_FENCE();
+        NVP_CHAIN_FENCE();
 #pragma unroll
         for (int i = 0; i < G; ++i) mfma4(acc, a[i], b[i]);
 #pragma unroll
         for (int i = 0; i < G; ++i) { a[i] = an[i]; b[i] = bn[i]; }
     }
-    for (int u = ng * G; u < zs; ++u) mfma4(acc, (w + u * 64)[ul], (zl + u * 64)[ul]);
+    for (int u = ng * G; u < zs; ++u) mfma4(acc, NVP_WLOAD((w + u * 64)[ul]), NVP_ZLOAD((zl + u * 64)[ul]));
 }
 
 __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
@@ -112,7 +135,7 @@ __device__ __forceinline__ void chain_hz(f32x16 (&acc)[ZT], const f32x16 (&hin)[
 #pragma unroll
                 for (int q = 0; q < Q; ++q) a[(g + 1) & 1][i][q] = (w + (((g + 1) * GZ + i) * 64 * Q + q))[ul];
         }
-        NVP_LOAD_FENCE();
+        NVP_CHAIN_FENCE();
 #pragma unroll
         for (int i = 0; i < GZ; ++i) {
             const int step = g * GZ + i;

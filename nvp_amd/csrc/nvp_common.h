@@ -80,7 +80,11 @@ __device__ __forceinline__ void nvp_sincos(float x, float& sn, float& cs) {
 }
 
 __device__ __forceinline__ float nvp_sin(float x) {
+#ifdef NVP_ABL_NOSIN            // ablation builds only (tools/ablate.sh): cheap stand-in activation
+    return x * 0.5f;
+#else
     float s, c;
     nvp_sincos(x, s, c);
     return s;
+#endif
 }
