@@ -81,11 +81,25 @@ __device__ __forceinline__ Vec<F> load_vec(const float* p) {
     return r;
 }
 
-// Output addressing: row-major [N, C] or PTM [ntiles][rows][32].
+// Output addressing: row-major [N, C] or PTM4 [ntiles][rows/4][32][4] (rows a multiple of 4;
+// the 4 rows of a row-group are contiguous per pixel, so a lane's natural access is 16 B).
 template <bool PTM>
 __device__ __forceinline__ int64_t out_addr(int64_t px, int col, int ncols_or_rows) {
-    if constexpr (PTM) return ((px >> 5) * ncols_or_rows + col) * 32 + (px & 31);
+    if constexpr (PTM) return (((px >> 5) * (ncols_or_rows >> 2) + (col >> 2)) * 32 + (px & 31)) * 4 + (col & 3);
     else return px * ncols_or_rows + col;
+}
+
+// store `count` consecutive columns starting at col0 for one pixel; 16-B stores when aligned
+template <bool PTM>
+__device__ __forceinline__ void store_cols(float* __restrict__ out, int64_t px, int col0, int ncols, const float* v, int count) {
+    if constexpr (PTM) {
+        if ((col0 & 3) == 0 && (count & 3) == 0) {
+            for (int c = 0; c < count; c += 4)
+                *reinterpret_cast<float4*>(out + out_addr<true>(px, col0 + c, ncols)) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+            return;
+        }
+    }
+    for (int c = 0; c < count; ++c) out[out_addr<PTM>(px, col0 + c, ncols)] = v[c];
 }
 
 // ---- dense 2D grid: one slot (<= 4 levels) of one plane for one pixel -------------
@@ -93,10 +107,13 @@ template <int F, bool PTM>
 __device__ __forceinline__ void dense_slot_fwd(const float* __restrict__ params, const nvp_levels& lv,
                                                int lvl0, float x0, float x1, bool valid,
                                                float* __restrict__ out, int64_t px, int col0, int ncols) {
+    float res[kLevelsPerSlot * F];
+    int nl = 0;
 #pragma unroll
     for (int dl = 0; dl < kLevelsPerSlot; ++dl) {
         int l = lvl0 + dl;
         if (l >= lv.n_levels) break;
+        nl = dl + 1;
         float acc[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) acc[f] = 0.f;
@@ -117,8 +134,9 @@ __device__ __forceinline__ void dense_slot_fwd(const float* __restrict__ params,
             }
         }
 #pragma unroll
-        for (int f = 0; f < F; ++f) out[out_addr<PTM>(px, col0 + l * F + f, ncols)] = acc[f];
+        for (int f = 0; f < F; ++f) res[dl * F + f] = acc[f];
     }
+    store_cols<PTM>(out, px, col0 + lvl0 * F, ncols, res, nl * F);
 }
 
 template <int F, bool PTM>
@@ -191,17 +209,19 @@ __device__ __forceinline__ void sparse_fwd(const float* __restrict__ emb, const 
     Patch p = patch_setup(t, x, y, sh, inter);
     const int64_t plane = (int64_t)sh.x_res * sh.y_res;
     for (int i = 0; i < 3; ++i) {
+        float row[3 * 8];                                    // one x-row of the patch: 3 cells x F <= 8
         for (int j = 0; j < 3; ++j) {
             int64_t cell = (int64_t)p.vx[i] * sh.y_res + p.vy[j];
             const float* lo = emb + ((int64_t)p.t_lo * plane + cell) * F;
             const float* hi = emb + ((int64_t)p.t_hi * plane + cell) * F;
-            for (int f = 0; f < F; ++f) {
+            for (int f = 0; f < F && f < 8; ++f) {
                 float v;
                 if (!inter) v = lo[f];
                 else v = __fadd_rn(__fmul_rn(lo[f], p.w_lo), __fmul_rn(hi[f], p.w_hi));
-                out[out_addr<PTM>(px, col0 + (i * 3 + j) * F + f, ncols)] = v;
+                row[j * F + f] = v;
             }
         }
+        for (int c = 0; c < 3 * F; ++c) out[out_addr<PTM>(px, col0 + i * 3 * F + c, ncols)] = row[c];
     }
 }
 
@@ -264,7 +284,7 @@ struct EncodeArgs {
     nvp_sparse_shape sh;
     int col0[4];               // first latent row of xy, yt, xt, sparse
     int slots[3];              // slots per plane
-    int rows;                  // PTM rows (D rounded up to even)
+    int rows;                  // PTM4 rows (D rounded up to a multiple of 4)
     int d;                     // latent dim
 };
 
@@ -288,45 +308,48 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_kernel(const float* __res
         dense_slot_fwd<F, true>(kf2, a.lv[2], s * kLevelsPerSlot, t, x, valid, zt, px, a.col0[2], a.rows);
     } else {
         sparse_fwd<true>(emb, a.sh, inter != 0, t, x, y, valid, zt, px, a.col0[3], a.rows);
-        for (int r = a.d; r < a.rows; ++r) zt[out_addr<true>(px, r, a.rows)] = 0.f;   // even-row padding
+        for (int r = a.d; r < a.rows; ++r) zt[out_addr<true>(px, r, a.rows)] = 0.f;   // pad rows (rows = D rounded up to 4)
     }
 }
 
-// row-major [N,D] <-> PTM [ntiles][rows][32]; a block transposes a 32-pixel x 32-column
-// patch through LDS so both sides move full lines.
+// row-major [N,D] <-> PTM4 [ntiles][rows/4][32][4]: one thread per (tile, row-group, pixel) moves
+// 4 consecutive features of one pixel (a 16-B piece on both sides).
 __global__ __launch_bounds__(256) void rows_to_ptm_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                           int64_t n, int d, int rows) {
-    __shared__ float tile[32][33];
-    int64_t t = blockIdx.x;
-    int c0 = blockIdx.y * 32;
-    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows of 32
-    for (int p = ty; p < 32; p += 8) {
-        int64_t px = t * 32 + p;
-        int c = c0 + tx;
-        tile[p][tx] = (px < n && c < d) ? src[px * d + c] : 0.f;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index in dst
+    const int r4 = rows >> 2;
+    const int64_t total = nvp_ntiles(n) * (int64_t)r4 * 32;
+    if (idx >= total) return;
+    const int j = (int)(idx & 31);
+    const int rg = (int)((idx >> 5) % r4);
+    const int64_t t = (idx >> 5) / r4;
+    const int64_t px = t * 32 + j;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * rg + e;
+        v[e] = (px < n && c < d) ? src[px * d + c] : 0.f;
     }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        int c = c0 + r;
-        if (c < rows) dst[(t * rows + c) * 32 + tx] = tile[tx][r];
-    }
+    reinterpret_cast<float4*>(dst)[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 __global__ __launch_bounds__(256) void ptm_to_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                           int64_t n, int d, int rows) {
-    __shared__ float tile[32][33];
-    int64_t t = blockIdx.x;
-    int c0 = blockIdx.y * 32;
-    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        int c = c0 + r;
-        tile[r][tx] = (c < rows) ? src[(t * rows + c) * 32 + tx] : 0.f;
-    }
-    __syncthreads();
-    for (int p = ty; p < 32; p += 8) {
-        int64_t px = t * 32 + p;
-        int c = c0 + tx;
-        if (px < n && c < d) dst[px * d + c] = tile[tx][p];
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int r4 = rows >> 2;
+    const int64_t total = nvp_ntiles(n) * (int64_t)r4 * 32;
+    if (idx >= total) return;
+    const int j = (int)(idx & 31);
+    const int rg = (int)((idx >> 5) % r4);
+    const int64_t t = (idx >> 5) / r4;
+    const int64_t px = t * 32 + j;
+    if (px >= n) return;
+    const float4 v = reinterpret_cast<const float4*>(src)[idx];
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * rg + e;
+        if (c < d) dst[px * d + c] = vv[e];
     }
 }
 
@@ -338,7 +361,7 @@ bool levels_ok(const nvp_levels* lv) {
 }
 
 bool shape_ok(const nvp_sparse_shape* sh) {
-    return sh && sh->t_res >= 1 && sh->x_res >= 1 && sh->y_res >= 1 && sh->n_features >= 1 &&
+    return sh && sh->t_res >= 1 && sh->x_res >= 1 && sh->y_res >= 1 && sh->n_features >= 1 && sh->n_features <= 8 &&
            (int64_t)sh->t_res * sh->x_res * sh->y_res * sh->n_features < (int64_t)1 << 40;
 }
 
@@ -366,7 +389,7 @@ int make_args(EncodeArgs& a, const nvp_levels* lv_xy, const nvp_levels* lv_yt, c
     }
     a.col0[3] = col;
     a.d = col + 9 * sh->n_features;
-    a.rows = nvp_rows_even(a.d);
+    a.rows = nvp_rows4(a.d);
     return 0;
 }
 
@@ -445,19 +468,19 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
 }
 
 int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream) {
-    if (n < 0 || d < 1 || rows < d) return NVP_ERR_BADARG;
+    if (n < 0 || d < 1 || rows < d || (rows & 3)) return NVP_ERR_BADARG;
     if (n == 0) return 0;
-    dim3 grid((unsigned)nvp_ntiles(n), (rows + 31) / 32);
-    hipLaunchKernelGGL(rows_to_ptm_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
+    const int64_t total = nvp_ntiles(n) * (int64_t)(rows >> 2) * 32;
+    hipLaunchKernelGGL(rows_to_ptm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
     NVP_LAUNCH_CHECK();
     return 0;
 }
 
 int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream) {
-    if (n < 0 || d < 1 || rows < d) return NVP_ERR_BADARG;
+    if (n < 0 || d < 1 || rows < d || (rows & 3)) return NVP_ERR_BADARG;
     if (n == 0) return 0;
-    dim3 grid((unsigned)nvp_ntiles(n), (rows + 31) / 32);
-    hipLaunchKernelGGL(ptm_to_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
+    const int64_t total = nvp_ntiles(n) * (int64_t)(rows >> 2) * 32;
+    hipLaunchKernelGGL(ptm_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
     NVP_LAUNCH_CHECK();
     return 0;
 }

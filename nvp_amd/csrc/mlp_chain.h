@@ -64,34 +64,62 @@ __device__ __forceinline__ void chain_h(f32x16 (&acc)[4], const f32x16 (&hin)[4]
     }
 }
 
-// zs steps over the latent: step u consumes rows 2u (lane half 0) and 2u+1 (half 1).
-__device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float* __restrict__ z, int zs,
+// Stage this wave's latent tile (PTM4, contiguous n4 float4) into its private LDS region with
+// coalesced 16-B loads.  Only the owning wave reads it back, so a wave barrier suffices.
+__device__ __forceinline__ void stage_z(float4* __restrict__ zl, const float4* __restrict__ z4, int n4, int lane) {
+    for (int base = 0; base < n4; base += 16 * 64) {          // <= 2 passes (rows <= 256)
+        float4 tmp[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                        // 16 independent 1-KiB wave loads in flight
+            const int idx = base + k * 64 + lane;
+            tmp[k] = idx < n4 ? z4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = base + k * 64 + lane;
+            if (idx < n4) zl[idx] = tmp[k];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// zs k-steps over the latent: step u consumes rows 2u (lane half 0) and 2u+1 (half 1).  In
+// PTM4 the float4 of row-group rg = u>>1 holds rows 4rg..4rg+3 of pixel j, i.e. the B operands
+// of steps 2rg and 2rg+1 for both lane halves: one ds_read_b128 per two steps, no HBM traffic
+// (the forward ablation showed re-streaming z per layer cost 17 % of the kernel).
+__device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float4* __restrict__ zl, int zs,
                                         const float4* __restrict__ wp, int lane) {
-    // z and wp are wave-uniform; row 2u+h of the PTM latent sits at (2u+h)*32 + j = u*64 + lane
     const unsigned ul = (unsigned)lane;
-    const float* zl = z;
-    const float4* w = wp;
-    const int ng = zs / G;
-    float4 a[G], an[G];
-    float b[G], bn[G];
+    const int j = lane & 31;
+    const bool hi = lane >= 32;
+    const int ng = zs / 4;
+    float4 a[4], an[4];
     if (ng > 0) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) { a[i] = NVP_WLOAD((w + i * 64)[ul]); b[i] = NVP_ZLOAD((zl + i * 64)[ul]); }
+        for (int i = 0; i < 4; ++i) a[i] = NVP_WLOAD((wp + i * 64)[ul]);
     }
     for (int g = 0; g < ng; ++g) {
         if (g + 1 < ng) {
-            const float4* wn = w + (g + 1) * G * 64;      // scalar pointer bumps
-            const float* zn = zl + (g + 1) * G * 64;
+            const float4* wn = wp + (g + 1) * 4 * 64;      // scalar pointer bump
 #pragma unroll
-            for (int i = 0; i < G; ++i) { an[i] = NVP_WLOAD((wn + i * 64)[ul]); bn[i] = NVP_ZLOAD((zn + i * 64)[ul]); }
+            for (int i = 0; i < 4; ++i) an[i] = NVP_WLOAD((wn + i * 64)[ul]);
         }
+        const float4 t0 = zl[(2 * g) * 32 + j];
+        const float4 t1 = zl[(2 * g + 1) * 32 + j];
         NVP_CHAIN_FENCE();
+        mfma4(acc, a[0], hi ? t0.y : t0.x);
+        mfma4(acc, a[1], hi ? t0.w : t0.z);
+        mfma4(acc, a[2], hi ? t1.y : t1.x);
+        mfma4(acc, a[3], hi ? t1.w : t1.z);
 #pragma unroll
-        for (int i = 0; i < G; ++i) mfma4(acc, a[i], b[i]);
-#pragma unroll
-        for (int i = 0; i < G; ++i) { a[i] = an[i]; b[i] = bn[i]; }
+        for (int i = 0; i < 4; ++i) a[i] = an[i];
     }
-    for (int u = ng * G; u < zs; ++u) mfma4(acc, NVP_WLOAD((w + u * 64)[ul]), NVP_ZLOAD((zl + u * 64)[ul]));
+    for (int u = ng * 4; u < zs; ++u) {
+        const float4 t = zl[(u >> 1) * 32 + j];
+        const float b = (u & 1) ? (hi ? t.w : t.z) : (hi ? t.y : t.x);
+        mfma4(acc, NVP_WLOAD((wp + u * 64)[ul]), b);
+    }
 }
 
 __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
@@ -101,18 +129,18 @@ __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
         for (int r = 0; r < 16; ++r) v[T][r] = v[T][r] > 0.f ? v[T][r] : v[T][r] * 0.01f;
 }
 
-// PTM addressing with a wave-uniform tile base: row 32T + 8g + 4h + e, pixel j sits at
-// tile_base[(32T + 8g + e)*32 + (128h + j)] - a compile-time constant plus one 32-bit lane offset.
-__device__ __forceinline__ unsigned nvp_lane_off(int lane) { return (unsigned)(((lane >> 5) << 7) + (lane & 31)); }
-
+// PTM4 addressing: a 128-row stream tile is 32 row-groups x 32 pixels x float4 (rows 4rg..4rg+3
+// of one pixel are contiguous).  Lane (j, h) owns rows 8g+4h+{0..3} of each 32-row tile T, i.e.
+// row-group 8T+2g+h, so its float4 sits at index (8T+2g)*32 + lane: every fragment load/store is
+// one 16-B access per lane and one contiguous 1-KiB line set per wave instruction.
 __device__ __forceinline__ void store_ptm(float* __restrict__ tile_base, const f32x16 (&v)[4], int lane) {
-    const unsigned lo = nvp_lane_off(lane);
+    float4* b4 = reinterpret_cast<float4*>(tile_base);
 #pragma unroll
     for (int T = 0; T < 4; ++T)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) (tile_base + (32 * T + 8 * (r >> 2) + (r & 3)) * 32)[lo] = v[T][r];
+        for (int g = 0; g < 4; ++g)
+            (b4 + (8 * T + 2 * g) * 32)[(unsigned)lane] = make_float4(v[T][4 * g], v[T][4 * g + 1], v[T][4 * g + 2], v[T][4 * g + 3]);
 }
-
 
 // One 64-step chain whose output has ZT 32-row tiles (latent gradient): the packed stream
 // holds ZT floats per lane and step.
@@ -151,15 +179,19 @@ __device__ __forceinline__ void chain_hz(f32x16 (&acc)[ZT], const f32x16 (&hin)[
     }
 }
 
-// Load one 16-row block (tile T) of a PTM activation into fragment registers.
+// Load / store one 32-row tile T of a PTM4 stream into fragment registers.
 __device__ __forceinline__ void load_ptm16(f32x16& v, const float* __restrict__ tile_base, int T, int lane) {
-    const unsigned lo = nvp_lane_off(lane);
+    const float4* b4 = reinterpret_cast<const float4*>(tile_base);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = (tile_base + (32 * T + 8 * (r >> 2) + (r & 3)) * 32)[lo];
+    for (int g = 0; g < 4; ++g) {
+        const float4 t = (b4 + (8 * T + 2 * g) * 32)[(unsigned)lane];
+        v[4 * g] = t.x; v[4 * g + 1] = t.y; v[4 * g + 2] = t.z; v[4 * g + 3] = t.w;
+    }
 }
 
 __device__ __forceinline__ void store_ptm16(float* __restrict__ tile_base, const f32x16& v, int T, int lane) {
-    const unsigned lo = nvp_lane_off(lane);
+    float4* b4 = reinterpret_cast<float4*>(tile_base);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) (tile_base + (32 * T + 8 * (r >> 2) + (r & 3)) * 32)[lo] = v[r];
+    for (int g = 0; g < 4; ++g)
+        (b4 + (8 * T + 2 * g) * 32)[(unsigned)lane] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }

@@ -3,9 +3,10 @@
 // i.e. GEMMs whose CONTRACTION axis is the pixel axis (1.2 M long) and whose output is tiny
 // (128 x {114,242,128}).  They are run split-K over pixel chunks on fp32 MFMA:
 //
-//  * both operands come from pixel-tile-major (PTM) streams [tile][feature][32 px] written
-//    by mlp_fwd/mlp_bwd, so an MFMA fragment for feature row i is "16 consecutive pixels of
-//    row i" = one 64-B run per lane, a fully coalesced 4-KiB read per wave - no transposes;
+//  * both operands come from the PTM4 streams written by mlp_fwd/mlp_bwd.  A 128-row x 32-px
+//    tile is 16 KiB contiguous: the block stages it through LDS with full-line 16-B loads
+//    (the ablation/PMC runs showed fragment-shaped global loads - 32 lines touched per wave
+//    instruction - starve the MFMA pipe), double-buffered, one barrier per pixel tile;
 //    lane (i, h) feeds pixel 16h + k at k-step k on BOTH operands, so the pairing is exact.
 //  * a job = one (layer, group of 4 column tiles) = a 128 x 128 block of one dW; grid = (pixel
 //    chunk, job).  Each of the 4 waves owns a 64 x 64 sub-block = 2 x 2 MFMA tiles (64
@@ -43,94 +44,128 @@ struct DwArgs {
     int64_t total;        // floats per partial
 };
 
-__device__ __forceinline__ void load_frag(float (&f)[16], const float* __restrict__ row_ptr) {
-    const float4* p = reinterpret_cast<const float4*>(row_ptr);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = p[q];
-        f[4 * q + 0] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
-    }
-}
+// ---- LDS staging ------------------------------------------------------------------------
+// A 128-row x 32-pixel tile of a PTM4 stream is 1024 contiguous float4 (16 KiB): the 256 threads
+// fetch it with four fully coalesced 16-B loads each.  It is written to LDS row-major with a
+// 33-float row stride: both the 4-B scatter writes (bank = row + px) and the fragment reads
+// (lane i reads row i, 16 consecutive pixels; bank = row + px) are conflict-free.  The MFMA
+// fragment for feature row i at k-step k is pixel 16h + k on BOTH operands.
+constexpr int kRowStride = 33;
+constexpr int kTileFloats = 128 * kRowStride;          // 4224 floats = 16.5 KiB
 
-// fragment set of one 32-pixel tile for a wave that owns a 64-row x 64-column block (2 x 2 MFMA tiles)
-struct Frags {
-    float a[2][16];
-    float b[2][16];
+struct Stage {
+    float4 a[4];
+    float4 b[4];
 };
 
-__device__ __forceinline__ void load_frags(Frags& f, const DwJob& J, int64_t t, int wr, int wc, int i, int h, const bool (&bval)[2]) {
+__device__ __forceinline__ void load_stage(Stage& s, const DwJob& J, int64_t t, int tid) {
+    const float4* A4 = reinterpret_cast<const float4*>(J.a) + t * 1024;
+    const float4* B4 = reinterpret_cast<const float4*>(J.b) + (t * (J.b_rows >> 2) + (J.b_row0 >> 2)) * 32;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) load_frag(f.a[r], J.a + ((t * NVP_H + 64 * wr + 32 * r + i) * 32 + 16 * h));
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        if (bval[c]) load_frag(f.b[c], J.b + ((t * J.b_rows + J.b_row0 + 64 * wc + 32 * c + i) * 32 + 16 * h));
-        else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) f.b[c][k] = 0.f;
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int f = k * 256 + tid;
+        s.a[k] = A4[f];
+        const int row = J.b_row0 + 4 * (f >> 5);
+        s.b[k] = row < J.b_rows ? B4[f] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
-__device__ __forceinline__ void mma_frags(f32x16 (&acc)[2][2], const Frags& f, float& bsum, bool want_bias) {
-    if (want_bias) {
+__device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb, const Stage& s, int tid) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) bsum += f.a[0][k];
+    for (int k = 0; k < 4; ++k) {
+        const int f = k * 256 + tid;
+        const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
+        la[o] = s.a[k].x; la[o + kRowStride] = s.a[k].y; la[o + 2 * kRowStride] = s.a[k].z; la[o + 3 * kRowStride] = s.a[k].w;
+        lb[o] = s.b[k].x; lb[o + kRowStride] = s.b[k].y; lb[o + 2 * kRowStride] = s.b[k].z; lb[o + 3 * kRowStride] = s.b[k].w;
     }
+}
+
+__device__ __forceinline__ void read_frag(float (&f)[16], const float* __restrict__ tile, int row, int h) {
+    const float* p = tile + row * kRowStride + 16 * h;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        acc[0][0] = nvp_mfma(f.a[0][k], f.b[0][k], acc[0][0]);
-        acc[0][1] = nvp_mfma(f.a[0][k], f.b[1][k], acc[0][1]);
-        acc[1][0] = nvp_mfma(f.a[1][k], f.b[0][k], acc[1][0]);
-        acc[1][1] = nvp_mfma(f.a[1][k], f.b[1][k], acc[1][1]);
-    }
+    for (int k = 0; k < 16; ++k) f[k] = p[k];
 }
 
 __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk) {
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));    // provably wave-uniform
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [2 buffers][A tile | B tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // provably wave-uniform
     const int i = lane & 31, h = lane >> 5;
     const int chunk = blockIdx.x;
     const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
     const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
     float* part = partials + (int64_t)chunk * A.total;
+    const bool small = (int)blockIdx.y == A.n_jobs - 1;
+    const DwJob J = A.job[blockIdx.y];
+    const int wr = w >> 1, wc = w & 1;                // regular jobs: wave owns rows 64wr.., columns 64wc..
 
-    if ((int)blockIdx.y < A.n_jobs - 1) {
-        const DwJob J = A.job[blockIdx.y];
-        const int wr = w >> 1, wc = w & 1;            // wave owns rows 64wr.., columns 64wc..
-        f32x16 acc[2][2];
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
-        float bsum = 0.f, bsum1 = 0.f;
-        bool bval[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) bval[c] = (64 * wc + 32 * c + i) < J.n_cols;
-        const bool want_bias = (J.bias_off >= 0) && (wc == 0);
+        for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
+    float bsum0 = 0.f, bsum1 = 0.f;                   // bias sums (regular) / last_b, sir0 sums (small)
+    float w0sum = 0.f;
+    const bool want_bias = !small && (J.bias_off >= 0) && (wc == 0);
 
-        // software pipeline over pixel tiles: the next tile's 16 x 16-B loads are in flight while
-        // the 64 MFMAs of the current tile run (two statically named fragment sets)
-        Frags f0, f1;
-        int64_t t = t0;
-        if (t < t1) load_frags(f0, J, t, wr, wc, i, h, bval);
-        while (t < t1) {
-            if (t + 1 < t1) load_frags(f1, J, t + 1, wr, wc, i, h, bval);
-            asm volatile("" ::: "memory");
-            mma_frags(acc, f0, bsum, want_bias);
+    Stage st;
+    if (t0 < t1) {
+        load_stage(st, J, t0, tid);
+        write_stage(lds, lds + kTileFloats, st, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        if (more) load_stage(st, J, t + 1, tid);       // global loads fly during this tile's MFMAs
+        const float* la = lds + cur * 2 * kTileFloats;
+        const float* lb = la + kTileFloats;
+        if (!small) {
+            float fa[2][16], fb[2][16];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) read_frag(fa[r], la, 64 * wr + 32 * r + i, h);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) read_frag(fb[c], lb, 64 * wc + 32 * c + i, h);
             if (want_bias) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) bsum1 += f0.a[1][k];
+                for (int k = 0; k < 16; ++k) { bsum0 += fa[0][k]; bsum1 += fa[1][k]; }
             }
-            if (++t >= t1) break;
-            if (t + 1 < t1) load_frags(f0, J, t + 1, wr, wc, i, h, bval);
-            asm volatile("" ::: "memory");
-            mma_frags(acc, f1, bsum, want_bias);
-            if (want_bias) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) bsum1 += f1.a[1][k];
+            for (int k = 0; k < 16; ++k) {
+                acc[0][0] = nvp_mfma(fa[0][k], fb[0][k], acc[0][0]);
+                acc[0][1] = nvp_mfma(fa[0][k], fb[1][k], acc[0][1]);
+                acc[1][0] = nvp_mfma(fa[1][k], fb[0][k], acc[1][0]);
+                acc[1][1] = nvp_mfma(fa[1][k], fb[1][k], acc[1][1]);
             }
-            ++t;
+        } else {
+            // small job: staged A = dq0s (for SIREN layer 0: dw0 = sum dq0s*s, dc0 = sum dq0s),
+            // staged B = x2 (for the last layer: dV3[c][col] = sum drgb[c] * x2[col]); wave w owns
+            // rows / columns 32w..32w+31
+            float q[16], xb[16], a3[16], sv[16];
+            read_frag(q, la, 32 * w + i, h);
+            read_frag(xb, lb, 32 * w + i, h);
+            const int64_t px0 = t * 32 + 16 * h;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t px = px0 + k;
+                a3[k] = (i < 3 && px < n) ? A.drgb[px * 3 + i] : 0.f;
+                sv[k] = px < n ? A.steps[px] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[0][0] = nvp_mfma(a3[k], xb[k], acc[0][0]);
+                bsum0 += a3[k];
+                w0sum = __fmaf_rn(q[k], sv[k], w0sum);
+                bsum1 += q[k];
+            }
         }
+        if (more) write_stage(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, tid);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (!small) {
         // D[row = out][col = in]: lane holds column i of each tile, rows 8g+4h+e
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -146,52 +181,26 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
             }
         }
         if (want_bias) {
-            bsum += __shfl_xor(bsum, 32);
+            bsum0 += __shfl_xor(bsum0, 32);
             bsum1 += __shfl_xor(bsum1, 32);
             if (h == 0) {
-                part[J.bias_off + 64 * wr + i] = bsum;
+                part[J.bias_off + 64 * wr + i] = bsum0;
                 part[J.bias_off + 64 * wr + 32 + i] = bsum1;
             }
         }
-        return;
-    }
-
-    // ---- small job: last layer (3 x 128, A = drgb^T) and SIREN layer 0 (128 x 1) ----------
-    {
-        f32x16 acc = nvp_zero16();
-        float bsum = 0.f;          // d last_b (rows 0..2, wave 0)
-        float w0sum = 0.f, c0sum = 0.f;
-        for (int64_t t = t0; t < t1; ++t) {
-            const int64_t px0 = t * 32 + 16 * h;
-            float a[16], b[16], q[16], s[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int64_t px = px0 + k;
-                a[k] = (i < 3 && px < n) ? A.drgb[px * 3 + i] : 0.f;
-                s[k] = px < n ? A.steps[px] : 0.f;
-            }
-            load_frag(b, A.x2 + ((t * NVP_H + 32 * w + i) * 32 + 16 * h));
-            load_frag(q, A.dq0s + ((t * NVP_H + 32 * w + i) * 32 + 16 * h));
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                acc = nvp_mfma(a[k], b[k], acc);
-                bsum += a[k];
-                w0sum = __fmaf_rn(q[k], s[k], w0sum);
-                c0sum += q[k];
-            }
-        }
+    } else {
         // d last_w[c][32w + i]: D rows 0..2 live in lane half 0, registers 0..2
         if (h == 0) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) part[A.last_w + (int64_t)r * NVP_H + 32 * w + i] = acc[r];
+            for (int r = 0; r < 3; ++r) part[A.last_w + (int64_t)r * NVP_H + 32 * w + i] = acc[0][0][r];
         }
-        bsum += __shfl_xor(bsum, 32);
+        bsum0 += __shfl_xor(bsum0, 32);
+        bsum1 += __shfl_xor(bsum1, 32);
         w0sum += __shfl_xor(w0sum, 32);
-        c0sum += __shfl_xor(c0sum, 32);
         if (h == 0) {
-            if (w == 0 && i < 3) part[A.last_b + i] = bsum;
+            if (w == 0 && i < 3) part[A.last_b + i] = bsum0;
             part[A.sir0_w + 32 * w + i] = w0sum;
-            part[A.sir0_b + 32 * w + i] = c0sum;
+            part[A.sir0_b + 32 * w + i] = bsum1;
         }
     }
 }
@@ -219,7 +228,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     if (!drgb || !steps || !zt || !saved || !dy || !xs || !partials || !g || n < 0 || d < 1 || n_chunks < 1) return NVP_ERR_BADARG;
     const NvpParamLayout P = nvp_param_layout(d);
     const int64_t ntiles = nvp_ntiles(n);
-    const int rows = nvp_rows_even(d);
+    const int rows = nvp_rows4(d);
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
     if (rows > 256) return NVP_ERR_UNSUPPORTED;
 
@@ -250,13 +259,18 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
         J.a = dy + (int64_t)(3 + k) * act; J.b = xs + (int64_t)(k - 1) * act; J.b_rows = NVP_H; J.b_row0 = 0;
         J.n_cols = NVP_H; J.w_off = P.sir_w[k]; J.ld = NVP_H; J.bias_off = P.sir_b[k];
     }
+    {   // the small job stages dq0s as its A tile and x2 as its B tile
+        DwJob& J = A.job[nj];
+        J.a = dy + 3 * act; J.b = xs + 2 * act; J.b_rows = NVP_H; J.b_row0 = 0; J.n_cols = NVP_H;
+        J.w_off = 0; J.ld = NVP_H; J.bias_off = -1;
+    }
     A.n_jobs = nj + 1;
     A.drgb = drgb; A.steps = steps; A.x2 = xs + 2 * act; A.dq0s = dy + 3 * act;
     A.last_w = P.last_w; A.last_b = P.last_b; A.sir0_w = P.sir_w[0]; A.sir0_b = P.sir_b[0];
     A.total = P.total;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(n_chunks, A.n_jobs), dim3(256), 0, (hipStream_t)stream, A, partials, n, ntiles, tiles_per_chunk);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(n_chunks, A.n_jobs), dim3(256), 2 * 2 * kTileFloats * sizeof(float), (hipStream_t)stream, A, partials, n, ntiles, tiles_per_chunk);
     NVP_LAUNCH_CHECK();
 
     ReduceArgs R;

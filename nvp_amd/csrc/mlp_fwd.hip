@@ -7,8 +7,8 @@
 // MFMA column (lane) axis on both sides, the 64 D registers of a layer are consumed
 // as-is as the next layer's B operands: activations never leave the register file,
 // nothing goes through LDS, there is no barrier in the kernel.
-// The latent z (B operand of the three modulator layers) streams from the PTM tensor
-// written by the encoder: step u reads rows 2u and 2u+1 = one 256-B line pair per wave.
+// The latent z (B operand of the three modulator layers) is copied once per tile from the
+// PTM4 tensor written by the encoder into the wave's private LDS region and read from there.
 //
 // fp32 MFMA is bit-equal to an ordered fmaf chain, so results differ from the CPU oracle
 // only by summation order (<= 1e-5 on RGB is asserted in tests/).
@@ -30,7 +30,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
     if (tile >= ntiles) return;                       // wave-uniform
     const int j = lane & 31, h = lane >> 5;
     const NvpFwdLayout L = nvp_fwd_layout(d);
-    const float* z = zt + tile * (int64_t)(2 * L.zs) * 32;
+    // this wave's latent tile -> its private LDS region (read by all three modulator layers)
+    extern __shared__ __attribute__((aligned(16))) float4 zlds[];
+    const int z4 = (nvp_rows4(d) / 4) * 32;                 // float4 per latent tile
+    float4* z = zlds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * z4;
+    stage_z(z, reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4, z4, lane);
     const float4* wp = reinterpret_cast<const float4*>(packed);
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
@@ -137,10 +141,12 @@ extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_pa
     if (n == 0) return 0;
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    const size_t lds = (size_t)kWaves * (nvp_rows4(d) / 4) * 32 * sizeof(float4);      // 59 KB (nvp_s), 117 KB (nvp_l)
+    if (lds > 160 * 1024) return NVP_ERR_UNSUPPORTED;
     if (saved)
-        hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
     else
-        hipLaunchKernelGGL(mlp_fwd_kernel<false>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_fwd_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
     NVP_LAUNCH_CHECK();
     return 0;
 }

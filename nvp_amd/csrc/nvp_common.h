@@ -18,6 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ inline int64_t nvp_ntiles(int64_t n) { return (n + NVP_T - 1) / NVP_T; }
 __host__ __device__ inline int nvp_rows_even(int d) { return (d + 1) & ~1; }
+__host__ __device__ inline int nvp_rows4(int d) { return (d + 3) & ~3; }      // PTM4 rows of the latent
 __host__ __device__ inline int nvp_dz_stride_dev(int d) { return (d + 3) & ~3; }
 __host__ __device__ inline int nvp_ztiles(int d) { return (nvp_rows_even(d) + 31) / 32; }
 
