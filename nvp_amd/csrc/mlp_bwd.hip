@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
     if (tile >= ntiles) return;                       // wave-uniform
+    nvp_stagger_start();
     const int j = lane & 31, h = lane >> 5;
     const NvpBwdLayout L = nvp_bwd_layout(d);
     const int64_t px = tile * 32 + j;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_kernel(const float*
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
     if (tile >= ntiles) return;
+    nvp_stagger_start();
     const int j = lane & 31, h = lane >> 5;
     const NvpBwdLayout L = nvp_bwd_layout(d);
     const int64_t act = ntiles * (int64_t)NVP_H * 32;

@@ -14,6 +14,21 @@
 #define NVP_ZLOAD(ptr_expr) (ptr_expr)
 #endif
 
+// The two waves that share a SIMD run the same phase sequence (MFMA chain, element-wise stage, ...).
+// If they start together they stay phase-aligned: both sit in VALU/memory phases at once (MFMA pipe
+// idle) and then contend for it.  Delaying the workgroups that land in the second residency slot of a
+// CU (observed dispatch: the first 256 blocks take one CU each) by a fraction of a phase, once, breaks
+// the alignment for the rest of the launch.  Placement is only a speed heuristic, never correctness.
+#ifndef NVP_STAGGER_SLEEPS
+#define NVP_STAGGER_SLEEPS 2
+#endif
+__device__ __forceinline__ void nvp_stagger_start() {
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll 1
+        for (int i = 0; i < NVP_STAGGER_SLEEPS; ++i) __builtin_amdgcn_s_sleep(127);      // ~8k cycles each
+    }
+}
+
 __device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4 a, const float b) {
     acc[0] = nvp_mfma(a.x, b, acc[0]);
     acc[1] = nvp_mfma(a.y, b, acc[1]);
@@ -129,6 +144,21 @@ __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
         for (int r = 0; r < 16; ++r) v[T][r] = v[T][r] > 0.f ? v[T][r] : v[T][r] * 0.01f;
 }
 
+// Stream stores: the activations / gradient streams are written once and consumed by a LATER kernel,
+// so they are stored non-temporally (no L2 allocation) unless NVP_NT_STORES=0.
+#ifndef NVP_NT_STORES
+#define NVP_NT_STORES 1
+#endif
+typedef float nvp_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nvp_stream_store(float4* p, float a, float b, float c, float d) {
+#if NVP_NT_STORES
+    nvp_f4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<nvp_f4*>(p));
+#else
+    *p = make_float4(a, b, c, d);
+#endif
+}
+
 // PTM4 addressing: a 128-row stream tile is 32 row-groups x 32 pixels x float4 (rows 4rg..4rg+3
 // of one pixel are contiguous).  Lane (j, h) owns rows 8g+4h+{0..3} of each 32-row tile T, i.e.
 // row-group 8T+2g+h, so its float4 sits at index (8T+2g)*32 + lane: every fragment load/store is
@@ -139,7 +169,7 @@ __device__ __forceinline__ void store_ptm(float* __restrict__ tile_base, const f
     for (int T = 0; T < 4; ++T)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            (b4 + (8 * T + 2 * g) * 32)[(unsigned)lane] = make_float4(v[T][4 * g], v[T][4 * g + 1], v[T][4 * g + 2], v[T][4 * g + 3]);
+            nvp_stream_store(&(b4 + (8 * T + 2 * g) * 32)[(unsigned)lane], v[T][4 * g], v[T][4 * g + 1], v[T][4 * g + 2], v[T][4 * g + 3]);
 }
 
 // One 64-step chain whose output has ZT 32-row tiles (latent gradient): the packed stream
@@ -190,8 +220,11 @@ __device__ __forceinline__ void load_ptm16(f32x16& v, const float* __restrict__ 
 }
 
 __device__ __forceinline__ void store_ptm16(float* __restrict__ tile_base, const f32x16& v, int T, int lane) {
+#ifdef NVP_ABL_NOSTORE          // ablation builds only
+    if (v[0] != 123.456f) return;
+#endif
     float4* b4 = reinterpret_cast<float4*>(tile_base);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        (b4 + (8 * T + 2 * g) * 32)[(unsigned)lane] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        nvp_stream_store(&(b4 + (8 * T + 2 * g) * 32)[(unsigned)lane], v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
     if (tile >= ntiles) return;                       // wave-uniform
+    nvp_stagger_start();
     const int j = lane & 31, h = lane >> 5;
     const NvpFwdLayout L = nvp_fwd_layout(d);
     // this wave's latent tile -> its private LDS region (read by all three modulator layers)

@@ -61,6 +61,9 @@ __device__ __forceinline__ void nvp_atomic_add(float* p, float v) { unsafeAtomic
 // re-derives this on the host from the same constants).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void nvp_sincos(float x, float& sn, float& cs) {
+#ifdef NVP_ABL_NOSIN            // ablation builds only
+    sn = x * 0.5f; cs = x * 0.25f; return;
+#endif
     const float n = __builtin_rintf(x * 0.636619747f);               // 2/pi
     float r = __fmaf_rn(n, -1.57079637e+00f, x);                       // 0x3fc90fdb
     r = __fmaf_rn(n, 4.37113883e-08f, r);                              // -(0xb33bbd2e)
