@@ -115,11 +115,11 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
                    const nvp_sparse_shape* sh, int temporal_interp, void* stream);
 /* R3 + R6 fused: latent gradient -> gradients of the four grids (nvp_amd/csrc/encode_bwd.hip).
  * dz: ROW-MAJOR [>= N][dz_stride] latent gradient as written by nvp_mlp_bwd_dx (columns
- * xy | yt | xt | sparse).  d_kf_*: every element is OVERWRITTEN (deterministic sorted-band
- * fixed-point accumulation, no atomics, no zero-fill needed); d_emb: accumulate (caller zeroes).
+ * xy | yt | xt | sparse).  d_kf_* and d_emb: every element is OVERWRITTEN (deterministic
+ * sorted-band fixed-point accumulation: no atomics, no zero-fill needed, bit-reproducible).
  * workspace: device scratch of nvp_encode_bwd_workspace_bytes() bytes. */
 int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
-                                       const nvp_levels* lv_xt);
+                                       const nvp_levels* lv_xt, const nvp_sparse_shape* sh);
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,

@@ -59,7 +59,7 @@ SIGNATURES = {
                        C.POINTER(SparseShape), C.c_int, _vp],
     "nvp_encode_bwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), _vp, _i64, _vp],
-    "nvp_encode_bwd_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels)],
+    "nvp_encode_bwd_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],
     "nvp_dz_stride": [_i32],
     "nvp_rows_to_ptm": [_p, _p, _i64, _i32, _i32, _vp],
     "nvp_ptm_to_rows": [_p, _p, _i64, _i32, _i32, _vp],

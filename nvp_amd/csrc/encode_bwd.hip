@@ -22,8 +22,7 @@
 //     with plain coalesced stores - no atomics, no zero-fill pass needed.
 //  5. slab reduction for the split levels.
 //
-// The sparse 3x3 grid still uses fp32 atomics (22 M per step, ~1 ms); it is the next
-// candidate for the same treatment.
+// The sparse 3x3 grid uses the same scheme with key = t_idx * X + x_idx (see below).
 //
 // Quantisation: contributions are scaled by 2^k with k chosen from max|dz| so that the sum of
 // N contributions cannot overflow 2^62; each contribution keeps >= 40 significant bits below
@@ -101,12 +100,13 @@ void make_plan(Plan& P, const nvp_levels* lv[3], int64_t n) {
 // ------------------------------------------------------------------------------------------
 struct Ws {                      // workspace carve (byte offsets)
     size_t keys_in[2], keys_out[2], iota, order[2], cs[3], dzs[3], rowstart[3], dzmax, slabs, sort_tmp, total;
+    size_t skey_in, skey_out, sorder, srowstart, sdzmax;      // sparse grid
     size_t sort_tmp_bytes;
 };
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], int64_t n) {
+int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape* sh, int64_t n) {
     size_t o = 0;
     for (int k = 0; k < 2; ++k) { W.keys_in[k] = o; o = align_up(o + n * 4); }
     for (int k = 0; k < 2; ++k) { W.keys_out[k] = o; o = align_up(o + n * 4); }
@@ -117,10 +117,20 @@ int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], int64_t n) {
     for (int p = 0; p < 3; ++p) { W.rowstart[p] = o; o = align_up(o + (size_t)P.rs_total[p] * 4); }
     W.dzmax = o; o = align_up(o + kMaxSlots * 4);
     W.slabs = o; o = align_up(o + (size_t)P.slab_floats * 4);
+    W.skey_in = o; o = align_up(o + n * 4);
+    W.skey_out = o; o = align_up(o + n * 4);
+    W.sorder = o; o = align_up(o + n * 4);
+    W.srowstart = o; o = align_up(o + ((size_t)sh->t_res * sh->x_res + 1) * 4);
+    W.sdzmax = o; o = align_up(o + kMaxSlots * 4);
     size_t tmp = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
                                              (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
     if (e != hipSuccess) return (int)e;
+    size_t tmp2 = 0;
+    e = rocprim::radix_sort_pairs(nullptr, tmp2, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
+                                  (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
+    if (e != hipSuccess) return (int)e;
+    if (tmp2 > tmp) tmp = tmp2;
     W.sort_tmp_bytes = tmp;
     W.sort_tmp = o; o = align_up(o + tmp);
     W.total = o;
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     const int* rs = A.rowstart[plane] + L.rs_off;
     const int loA = rs[max(r0 - 2, 0)], hiA = rs[r1];
     int loW = 0, hiW = 0;
-    if (r0 == 0) { loW = max(rs[max(res - 2, 0)], hiA); hiW = (int)n; if (loW > hiW) loW = hiW; }
+    if (r0 < 2) { loW = max(rs[max(res - 2, 0)], hiA); hiW = (int)n; if (loW > hiW) loW = hiW; }   // rows 0 and 1 receive the wrap
     const int lenA = hiA - loA, lenT = lenA + (hiW - loW);
     const int kb = (int)(((long long)lenT * split) / L.splits);
     const int ke = (int)(((long long)lenT * (split + 1)) / L.splits);
@@ -341,34 +351,92 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceArgs A) {
     }
 }
 
-// sparse 3x3 grid: fp32 atomics from the row-major latent gradient (reference autograd of
-// sparsegrid.py:61-69: clamped border duplicates accumulate)
+// ---- sparse 3x3 grid (R6), same scheme --------------------------------------------------
+// Key = t_idx * X + x_idx (nearest indices, reference sparsegrid.py:43-51).  A workgroup owns the
+// cells (t, x in [r0, r1), all y) as an int64 fixed-point LDS table and visits the sorted pixels
+// with x_idx in [r0-1, r1]: a pixel's clamped 3x3 patch only touches x rows x_idx-1..x_idx+1.
+// Clamped border duplicates accumulate exactly like the reference's index_put_(accumulate=True).
+// Every cell of the gradient is written exactly once (zeros included): no memset, no atomics.
 __device__ __forceinline__ int nearest_idx(float c, int res) {
     float f = (float)(res - 1) * c;
     int i = (int)(f + 0.5f);
     return min(max(i, 0), res - 1);
 }
 
-__global__ __launch_bounds__(256) void sparse_bwd_rows_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride,
-                                                              int col0, float* __restrict__ demb, int64_t n, nvp_sparse_shape sh) {
-    const int64_t px = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (px >= n) return;
-    const float* c = coords + px * 3;
+constexpr int kSparseThreads = 256;
+constexpr int kSparseEntries = 9000;            // int64 entries -> 72 KB: two workgroups per CU
+
+__global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
+                                                          unsigned* __restrict__ keys, unsigned* __restrict__ dzmax, int64_t n, nvp_sparse_shape sh) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (i < n) {
+        const float* c = coords + i * 3;
+        keys[i] = (unsigned)(nearest_idx(c[0], sh.t_res) * sh.x_res + nearest_idx(c[1], sh.x_res));
+        const float* g = dz + i * dz_stride + col0;
+        for (int k = 0; k < 9 * sh.n_features; ++k) m = fmaxf(m, fabsf(g[k]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(m));
+}
+
+// srowstart[k] = first sorted position whose key is >= k, k in [0, T*X]
+__global__ __launch_bounds__(256) void sparse_rowstart_kernel(const unsigned* __restrict__ keys_sorted, int* __restrict__ rowstart, int nkeys, int64_t n) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k > nkeys) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys_sorted[mid] >= (unsigned)k) hi = mid; else lo = mid + 1;
+    }
+    rowstart[k] = (int)lo;
+}
+
+__global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
+                                                                     const int* __restrict__ order, const int* __restrict__ rowstart,
+                                                                     const unsigned* __restrict__ dzmax, float* __restrict__ demb,
+                                                                     nvp_sparse_shape sh, int rows_per_band, int bands, int headroom_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
+    __shared__ int s_k;
     const int F = sh.n_features;
-    const int ti = nearest_idx(c[0], sh.t_res), xi = nearest_idx(c[1], sh.x_res), yi = nearest_idx(c[2], sh.y_res);
-    const float* g = dz + px * dz_stride + col0;
-    const int64_t plane = (int64_t)sh.x_res * sh.y_res;
-    for (int i = 0; i < 3; ++i) {
+    const int t = blockIdx.x / bands, band = blockIdx.x - t * bands;
+    const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
+    const int entries = (r1 - r0) * sh.y_res * F;
+    for (int i = threadIdx.x; i < entries; i += kSparseThreads) tab[i] = 0ull;
+    if (threadIdx.x < 64) {
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64) m = max(m, dzmax[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) s_k = 62 - headroom_bits - ((int)((m >> 23) & 0xff) - 127 + 1);
+    }
+    __syncthreads();
+    const int k = s_k;
+    const int lo = rowstart[t * sh.x_res + max(r0 - 1, 0)];
+    const int hi = rowstart[t * sh.x_res + min(r1, sh.x_res - 1) + 1];
+    // one work unit = (pixel, patch cell): 9 units per pixel
+    const int units = (hi - lo) * 9;
+    for (int u = threadIdx.x; u < units; u += kSparseThreads) {
+        const int p = lo + u / 9, cell9 = u - (u / 9) * 9;
+        const int id = order[p];
+        const float* c = coords + (int64_t)id * 3;
+        const int xi = nearest_idx(c[1], sh.x_res), yi = nearest_idx(c[2], sh.y_res);
+        const int i = cell9 / 3, j = cell9 - i * 3;
         const int vx = min(max(xi + i - 1, 0), sh.x_res - 1);
-        for (int j = 0; j < 3; ++j) {
-            const int vy = min(max(yi + j - 1, 0), sh.y_res - 1);
-            float* dst = demb + ((int64_t)ti * plane + (int64_t)vx * sh.y_res + vy) * F;
-            for (int f = 0; f < F; ++f) {
-                const float v = g[(i * 3 + j) * F + f];
-                if (v != 0.f) nvp_atomic_add(dst + f, v);
-            }
+        if (vx < r0 || vx >= r1) continue;
+        const int vy = min(max(yi + j - 1, 0), sh.y_res - 1);
+        const float* g = dz + (int64_t)id * dz_stride + col0 + cell9 * F;
+        unsigned long long* dst = tab + ((vx - r0) * sh.y_res + vy) * F;
+        for (int f = 0; f < F; ++f) {
+            const float v = g[f];
+            if (v != 0.f) atomicAdd(dst + f, (unsigned long long)to_fixed(v, k));
         }
     }
+    __syncthreads();
+    const double inv = ldexp(1.0, -k);
+    float* out = demb + (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
+    for (int i = threadIdx.x; i < entries; i += kSparseThreads) out[i] = (float)((double)(long long)tab[i] * inv);
 }
 
 bool levels_ok(const nvp_levels* lv) {
@@ -447,7 +515,30 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(64, P.reduce_items), dim3(256), 0, s, R);
     }
 
-    hipLaunchKernelGGL(sparse_bwd_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, dz, dz_stride, col, demb, n, *sh);
+    // ---- sparse grid
+    {
+        unsigned* sk_in = (unsigned*)(ws + W.skey_in);
+        unsigned* sk_out = (unsigned*)(ws + W.skey_out);
+        int* sorder = (int*)(ws + W.sorder);
+        int* srs = (int*)(ws + W.srowstart);
+        unsigned* sdzmax = (unsigned*)(ws + W.sdzmax);
+        me = hipMemsetAsync(sdzmax, 0, kMaxSlots * 4, s);
+        if (me != hipSuccess) return (int)me;
+        hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, dz, dz_stride, col, sk_in, sdzmax, n, *sh);
+        const int nkeys = sh->t_res * sh->x_res;
+        int end_bit = 1;
+        while (((int64_t)1 << end_bit) < nkeys && end_bit < 32) ++end_bit;
+        size_t tmp2 = W.sort_tmp_bytes;
+        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp2, (const unsigned*)sk_in, sk_out, (const int*)iota, sorder, (size_t)n, 0, end_bit, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(sparse_rowstart_kernel, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, s, (const unsigned*)sk_out, srs, nkeys, n);
+        int rows = kSparseEntries / (sh->y_res * sh->n_features);
+        if (rows < 1) return NVP_ERR_UNSUPPORTED;                 // y_res * F > 9000
+        if (rows > sh->x_res) rows = sh->x_res;
+        const int bands = (sh->x_res + rows - 1) / rows;
+        hipLaunchKernelGGL(sparse_band_kernel, dim3((unsigned)(sh->t_res * bands)), dim3(kSparseThreads), kSparseEntries * 8, s,
+                           coords, dz, dz_stride, col, (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, BA.headroom_bits + 2);
+    }
     return 0;
 }
 
@@ -455,19 +546,20 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
 
 extern "C" {
 
-int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt) {
-    if (n < 0 || !levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt)) return NVP_ERR_BADARG;
+int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                                       const nvp_sparse_shape* sh) {
+    if (n < 0 || !levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh) return NVP_ERR_BADARG;
     if (n == 0) return 256;
     const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
     Plan P;
     make_plan(P, lv, n);
     Ws W;
-    if (carve(W, P, lv, n)) return NVP_ERR_BADARG;
+    if (carve(W, P, lv, sh, n)) return NVP_ERR_BADARG;
     return (int64_t)W.total;
 }
 
 // dz: row-major latent gradient [>= n][dz_stride] (columns xy | yt | xt | sparse).
-// d_kf_*: every element is OVERWRITTEN (no zero-fill needed); d_emb: accumulate (caller zeroes).
+// d_kf_* and d_emb: every element is OVERWRITTEN (no zero-fill needed).
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
@@ -484,13 +576,14 @@ int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
             hipError_t e = hipMemsetAsync(g, 0, (size_t)lv[p]->offset[lv[p]->n_levels] * lv[p]->n_features * 4, s);
             if (e != hipSuccess) return (int)e;
         }
-        return 0;
+        hipError_t e = hipMemsetAsync(d_emb, 0, (size_t)sh->t_res * sh->x_res * sh->y_res * sh->n_features * 4, s);
+        return (int)e;
     }
     if (!coords || !dz || !d_kf_xy || !d_kf_yt || !d_kf_xt || !d_emb || !workspace) return NVP_ERR_BADARG;
     Plan P;
     make_plan(P, lv, n);
     Ws W;
-    int rc = carve(W, P, lv, n);
+    int rc = carve(W, P, lv, sh, n);
     if (rc) return rc;
     if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
     const int need = lv_xy->n_levels * lv_xy->n_features + lv_yt->n_levels * lv_yt->n_features + lv_xt->n_levels * lv_xt->n_features +

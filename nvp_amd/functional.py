@@ -270,11 +270,9 @@ class NVPFused(torch.autograd.Function):
             return (None, None, *z, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
         dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
-        # keyframe gradients are written exactly once per element by the sorted-band scatter
-        # (no zero-fill); the sparse grid still accumulates with atomics into zeros.
-        d_xy, d_yt, d_xt = (torch.empty_like(t) for t in (kf_xy, kf_yt, kf_xt))
-        d_emb = torch.zeros_like(emb)
-        ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]))
+        # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
+        d_xy, d_yt, d_xt, d_emb = (torch.empty_like(t) for t in (kf_xy, kf_yt, kf_xt, emb))
+        ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
         if ws_bytes < 0:
             raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
         ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
