@@ -155,17 +155,23 @@ def main():
     value = world * N_PX / (ms_per_step * 1e-3) / 1e6
     if rank == 0:
         kms = {k: round(v[0], 4) for k, v in kernels.items()}
+        # HBM bytes per launch measured with rocprofv3 PMC passes (tools/pmc.sh -> tools/pmc_summarize.py);
+        # bench.py cannot collect counters itself, so it reports the committed measurement if present.
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))
         dom = max(kms, key=kms.get) if kms else None
         roof = None
         if dom in FLOP_PX:
             ach = FLOP_PX[dom] * N_PX / (kms[dom] * 1e-3)
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": PEAK_MFMA_F32 / 1e12,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32, 4), "traffic": traffic.get(dom),
                     "ms_per_launch": kms[dom], "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
         elif dom in BYTES_PX:
             ach = BYTES_PX[dom] * N_PX / (kms[dom] * 1e-3)
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9,
-                    "unit": "GB/s", "frac": round(ach / PEAK_HBM, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM, 4), "traffic": traffic.get(dom),
                     "ms_per_launch": kms[dom], "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
         hot_ms = sum(kms.values())
         line = {

@@ -297,10 +297,11 @@ def test_batch_dim_and_param_rebinding_like_eval():
 # ----------------------------------------------------------------------------------------
 # Size-independent properties at BASELINE.json's full batch (N = 1 245 184)
 # ----------------------------------------------------------------------------------------
-def test_full_batch_properties():
+@pytest.mark.parametrize("F", [2, 4])          # config_nvp_s / config_nvp_l feature widths
+def test_full_batch_properties(F):
     from nvp_amd.modules import NVP
     n = 1245184
-    cfg = small_cfg(F=2, T=60, X=50, Y=50)
+    cfg = small_cfg(F=F, T=60, X=50, Y=50)
     torch.manual_seed(0)
     model = NVP(out_features=3, encoding_config=cfg).to(dev())
     with torch.no_grad():
@@ -327,7 +328,64 @@ def test_full_batch_properties():
     #     checked through a second, independent route (stand-alone SparseGrid module, ones as upstream grad)
     sg_out = model.sparse_grid(coords.reshape(-1, 3))
     (dE,) = torch.autograd.grad(sg_out.sum(), [model.sparse_grid.embeddings])
-    assert abs(float(dE.double().sum()) - 9 * 2 * n) / (9 * 2 * n) < 1e-6
+    assert abs(float(dE.double().sum()) - 9 * F * n) / (9 * F * n) < 1e-6
     kf_out = model.keyframes_xy(coords.reshape(-1, 3)[:, 1:].contiguous())
     (dP,) = torch.autograd.grad(kf_out.sum(), [model.keyframes_xy.params])
-    assert abs(float(dP.double().sum()) - 32 * n) / (32 * n) < 1e-5       # bilinear weights partition unity
+    assert abs(float(dP.double().sum()) - 16 * F * n) / (16 * F * n) < 1e-5       # bilinear weights partition unity
+
+
+# ----------------------------------------------------------------------------------------
+# PSNR at equal step count: the HIP path and the oracle trained on IDENTICAL batches
+# (BASELINE.json configs[0]: 64x64x16 synthetic RGB, config_nvp_s values; north_star: +-0.02 dB)
+# ----------------------------------------------------------------------------------------
+def test_psnr_at_equal_steps_matches_oracle():
+    import math
+    from nvp_amd import harness
+    from nvp_amd.modules import NVP
+    T, H, W, n, steps_total = 16, 64, 64, 16384, 60
+    cfg = small_cfg(F=2, T=T, X=20, Y=20)
+    sd = O.init_state(cfg, seed=3)                       # reference init distributions
+    model = NVP(out_features=3, encoding_config=cfg)
+    _load_state_into(model, sd)
+    model = model.to(dev())
+    video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=1)       # u8 [T,H,W,3]
+    vid_dev = video.to(dev())
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    keys = list(sd_ref)
+    opt_r = torch.optim.AdamW([sd_ref[k] for k in keys], lr=1e-2, weight_decay=0.001)
+    sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=steps_total, eta_min=1e-5)
+    opt_g = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.001)
+    sch_g = torch.optim.lr_scheduler.CosineAnnealingLR(opt_g, T_max=steps_total, eta_min=1e-5)
+    gen = torch.Generator().manual_seed(0)
+    flat = video.reshape(T, H * W, 3)
+    diffs = []
+    for it in range(steps_total):
+        ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)          # the reference's sampler order
+        gt_u8 = flat[ti, pi].unsqueeze(0)
+        # oracle step (training.py:50-76 order)
+        out_r = O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), sd_ref, cfg)
+        loss_r = O.image_mse(out_r, O.normalise_gt(gt_u8))
+        opt_r.zero_grad(); loss_r.backward(); opt_r.step(); sch_r.step()
+        # HIP step on the same batch
+        mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
+        out_g = model(mi)["model_out"]
+        loss_g = harness.image_mse_u8(out_g, gt_u8.to(dev()))
+        opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
+        psnr_r = 10 * math.log10(4 / float(loss_r)); psnr_g = 10 * math.log10(4 / float(loss_g))   # training.py:58
+        diffs.append(abs(psnr_r - psnr_g))
+    assert psnr_g > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
+    assert max(diffs) <= 0.02, f"train-PSNR gap {max(diffs):.4f} dB"
+    # evaluation PSNR on full frames (eval.py:243-256) with both final parameter sets
+    data = harness.DeviceVideo(vid_dev, n_samples=n, seed=0)
+    psnr_eval_g = harness.eval_psnr(model, data, frames=[0, 7, 15], n_slice=4)
+    with torch.no_grad():
+        se = 0.0
+        mg = O.get_mgrid_2d(H, W)
+        ps = []
+        for f in (0, 7, 15):
+            c = torch.cat((torch.linspace(0, 1, T)[f].expand(H * W, 1), mg), dim=1).unsqueeze(0)
+            s_ = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[f].expand(1, H * W)
+            img = torch.clamp((O.nvp_forward(c, s_, {k: v.detach() for k, v in sd_ref.items()}, cfg) + 1) / 2, 0, 1)
+            mse = float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())
+            ps.append(10 * math.log10(1 / mse))
+    assert abs(psnr_eval_g - sum(ps) / len(ps)) <= 0.02
