@@ -123,7 +123,8 @@ def main():
     data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank)   # rank-offset sampler seed
     total = args.steps + args.warmup
     opt, sched = harness.make_optimizer(model, total_steps=max(total, 1))
-    bucket = parallel.GradBucket(parallel.unique_parameters(model)) if world > 1 else None
+    # NVP_FORCE_BUCKET=1 exercises the flat-gradient-bucket code path on a single GPU (the collective is a no-op)
+    bucket = parallel.GradBucket(parallel.unique_parameters(model)) if (world > 1 or os.environ.get("NVP_FORCE_BUCKET")) else None
 
     def one_step():
         mi, gt = data.sample()

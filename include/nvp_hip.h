@@ -143,17 +143,18 @@ int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, co
 
 /* ---- R12: autograd of R8-R10 (reference training.py:74).
  * bwd_dx: drgb [N,3] -> dz_rows (latent gradient, ROW-MAJOR [ntiles*32][nvp_dz_stride(D)])
- *         + the nine PTM [ntiles][128][32] streams the weight-gradient GEMMs consume:
- *         dy = {dp0,dp1,dp2 (modulator pre-activation grads), dq0s (= 30*dq0), dq1, dq2},
- *         xs = {x0,x1,x2 (modulated sine outputs)}.
+ *         + the six PTM4 [ntiles][128][32] streams the weight-gradient GEMMs consume:
+ *         dy = {dp0,dp1,dp2 (modulator pre-activation grads), dq0s (= 30*dq0), dq1, dq2}.
+ *         (The modulated sine outputs x_k are NOT written: bwd_dw rebuilds x_k = sin(q_k) h_k
+ *         from `saved`, which removes 1.5 KB/px of HBM writes from a write-bound kernel.)
  * bwd_dw: all 14 parameter gradients = split-K GEMMs over the pixel axis into
  *         `partials` [n_chunks][nvp_mlp_param_floats], then a deterministic reduction
  *         into `g` (overwritten). */
 int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved,
                    const nvp_mlp_params* p, const float* packed_bwd,
-                   float* dy, float* xs, float* dz_rows, int64_t n, int32_t latent_dim, void* stream);
+                   float* dy, float* dz_rows, int64_t n, int32_t latent_dim, void* stream);
 int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
-                   const float* dy, const float* xs, float* partials, int32_t n_chunks,
+                   const float* dy, const nvp_mlp_params* p, float* partials, int32_t n_chunks,
                    const nvp_mlp_grads* g, int64_t n, int32_t latent_dim, void* stream);
 
 /* ---- R13: image_mse (reference loss_functions.py:1-3 with training.py:47-48) ---------

@@ -66,8 +66,8 @@ SIGNATURES = {
     "nvp_mlp_pack_fwd": [C.POINTER(MlpParams), _p, _i32, _vp],
     "nvp_mlp_pack_bwd": [C.POINTER(MlpParams), _p, _i32, _vp],
     "nvp_mlp_fwd": [_p, _p, C.POINTER(MlpParams), _p, _p, _p, _i64, _i32, _vp],
-    "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _i64, _i32, _vp],
-    "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
+    "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _i64, _i32, _vp],
+    "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
     "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
     "nvp_packed_fwd_floats": [_i32],

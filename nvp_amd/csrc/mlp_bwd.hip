@@ -15,7 +15,9 @@
 //   dx2 = V3^T drgb
 //   dq_k = dx_k h_k cos(q_k);  dh_k (+)= dx_k sin(q_k);  dp_k = dh_k lrelu'(p_k)
 //   dx_{k-1} = V_k^T dq_k;     dh_{k-1} = W_k[:, :128]^T dp_k;   dz += W_k[:, 128:]^T dp_k
-// Bound: fp32 MFMA; 219 392 FLOP/px (nvp_s) + HBM streams 2.5 KB/px in, 5.1 KB/px out.
+// Bound: fp32 MFMA nominally (219 392 FLOP/px, nvp_s), in practice HBM WRITE bandwidth: the six
+// dY streams are 3 KB/px out on top of 2.5 KB/px in.  The modulated sine outputs x_k are therefore NOT
+// written: the dW kernel rebuilds x_k = sin(q_k) h_k from the forward pass's saved streams.
 #include "mlp_chain.h"
 
 namespace {
@@ -31,7 +33,7 @@ constexpr int kWaves = 4;
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const float* __restrict__ packed,
-                                                                    float* __restrict__ dy, float* __restrict__ xs,
+                                                                    float* __restrict__ dy,
                                                                     int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
@@ -45,7 +47,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
     const int64_t tb = tile * (int64_t)NVP_H * 32;
     const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
     float* dyt = dy + tb;                  // dp0,dp1,dp2,dq0s,dq1,dq2
-    float* xst = xs + tb;                  // x0,x1,x2
     const float4* wp = reinterpret_cast<const float4*>(packed);
 
     f32x16 dx[4], dh[4];
@@ -74,27 +75,34 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
     for (int k = 2; k >= 1; --k) {
         const float* hk = sv + (int64_t)k * act;
         const float* qk = sv + (int64_t)(2 + k) * act;
+        // vmcnt retires in order: a wait for loads issued AFTER a store burst also waits for those stores
+        // (an HBM write round trip).  So block T+1's loads are issued before block T's stores.
+        f32x16 hv, qv;
+        load_ptm16(hv, hk, 0, lane);
+        load_ptm16(qv, qk, 0, lane);
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            f32x16 hv, qv, xv;
-            load_ptm16(hv, hk, T, lane);
-            load_ptm16(qv, qk, T, lane);
+            f32x16 hn, qn;
+            if (T < 3) {
+                load_ptm16(hn, hk, T + 1, lane);
+                load_ptm16(qn, qk, T + 1, lane);
+            }
+            NVP_LOAD_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float sn, cs;
                 nvp_sincos(qv[r], sn, cs);
                 const float dxv = dx[T][r];
-                xv[r] = sn * hv[r];
                 dx[T][r] = dxv * hv[r] * cs;                      // dq
                 const float dhv = dh[T][r] + dxv * sn;
                 dh[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;       // dp
             }
             nvp_pin(dx[T]);
             nvp_pin(dh[T]);
-            store_ptm16(xst + (int64_t)k * act, xv, T, lane);
             store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
             store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
             NVP_LOAD_FENCE();
+            if (T < 3) { hv = hn; qv = qn; }
         }
         // dx_{k-1} = V_k^T dq_k
         f32x16 acc[4];
@@ -117,10 +125,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         const float* w0 = p.sir_w[0];
         const float* c0 = p.sir_b[0];
         const float* h0 = sv;
+        f32x16 hv;
+        load_ptm16(hv, h0, 0, lane);
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            f32x16 hv, xv, dq0, dp0;
-            load_ptm16(hv, h0, T, lane);
+            f32x16 hn, dq0, dp0;
+            if (T < 3) load_ptm16(hn, h0, T + 1, lane);
+            NVP_LOAD_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * T + nvp_frag_row(r, h);
@@ -128,15 +139,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
                 float sn, cs;
                 nvp_sincos(q, sn, cs);
                 const float dxv = dx[T][r];
-                xv[r] = sn * hv[r];
                 dq0[r] = 30.0f * (dxv * hv[r] * cs);          // gradient w.r.t. (w s + c)
                 const float dhv = dh[T][r] + dxv * sn;
                 dp0[r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
             }
-            store_ptm16(xst, xv, T, lane);
             store_ptm16(dyt + 3 * act, dq0, T, lane);
             store_ptm16(dyt, dp0, T, lane);
             NVP_LOAD_FENCE();
+            if (T < 3) hv = hn;
         }
     }
 }
@@ -201,14 +211,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_kernel(const float*
 }  // namespace
 
 extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                              const float* packed_bwd, float* dy, float* xs, float* dz_rows, int64_t n, int32_t d, void* stream) {
-    if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !xs || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
+                              const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
+    if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     if (zt != 4 && zt != 8) return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, xs, n, ntiles, d);
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, n, ntiles, d);
     if (zt == 4)
         hipLaunchKernelGGL(mlp_bwd_dz_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
     else

@@ -23,8 +23,10 @@
 namespace {
 
 struct DwJob {
-    const float* a;       // dY stream (PTM, 128 rows) or nullptr for the "small" job
-    const float* b;       // X stream (PTM, b_rows rows)
+    const float* a;       // dY stream (PTM4, 128 rows)
+    const float* b;       // X stream (PTM4, b_rows rows): z, h_k, or the h factor of x_k = sin(q_k) h_k
+    const float* b2;      // mode 1: the q_k stream; otherwise == b (loaded but unused: L1 hit)
+    int mode;             // 0: B = b;  1: B = sin(b2) * b;  2: B = sin(30 (w0[row] s[px] + c0[row])) * b
     int b_rows;           // rows per tile in the B stream (its PTM stride)
     int b_row0;           // first B row of this job's 4 column tiles
     int n_cols;           // valid columns (features) from b_row0 on, <= 128
@@ -38,8 +40,8 @@ struct DwArgs {
     int n_jobs;           // the last job is the "small" one (last layer + SIREN layer 0)
     const float* drgb;
     const float* steps;
-    const float* x2;
-    const float* dq0s;
+    const float* sir0_wp;   // SIREN layer 0 weight / bias (mode 2)
+    const float* sir0_bp;
     int64_t last_w, last_b, sir0_w, sir0_b;
     int64_t total;        // floats per partial
 };
@@ -56,27 +58,56 @@ constexpr int kTileFloats = 128 * kRowStride;          // 4224 floats = 16.5 KiB
 struct Stage {
     float4 a[4];
     float4 b[4];
+    float4 b2[4];
 };
 
+template <bool XF>
 __device__ __forceinline__ void load_stage(Stage& s, const DwJob& J, int64_t t, int tid) {
     const float4* A4 = reinterpret_cast<const float4*>(J.a) + t * 1024;
     const float4* B4 = reinterpret_cast<const float4*>(J.b) + (t * (J.b_rows >> 2) + (J.b_row0 >> 2)) * 32;
+    const float4* Q4 = reinterpret_cast<const float4*>(J.b2) + (t * (J.b_rows >> 2) + (J.b_row0 >> 2)) * 32;
+    // rows past the end of the B stream (latent: 116 of 128) must read as zero: clamp the address here and
+    // select on the DATA in write_stage - a conditional load would become a branch with a vmcnt(0) wait
+    // per element, and a select right here would wait for the prefetch immediately
+    const int nvalid = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int f = k * 256 + tid;
         s.a[k] = A4[f];
-        const int row = J.b_row0 + 4 * (f >> 5);
-        s.b[k] = row < J.b_rows ? B4[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s.b[k] = B4[min(f, nvalid - 1)];          // zeroed (if past the end) when it is written to LDS
+    }
+    if (XF && J.mode == 1) {                      // wave-uniform (kernarg) branch: only x_k = sin(q_k) h_k jobs read q_k
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.b2[k] = Q4[min(k * 256 + tid, nvalid - 1)];
     }
 }
 
-__device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb, const Stage& s, int tid) {
+// `t` is the tile the stage holds (mode 2 needs its temporal steps)
+template <bool XF>
+__device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb, const Stage& s, const DwJob& J,
+                                            const DwArgs& A, int64_t t, int64_t n, int tid) {
+    const int nvalid = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32);
+    float sp = 0.f;
+    if (XF && J.mode == 2) sp = A.steps[min(t * 32 + (tid & 31), n - 1)];       // wave-uniform branch; px = f & 31 = tid & 31
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int f = k * 256 + tid;
         const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
+        const bool ok = f < nvalid;
+        float bv[4] = {s.b[k].x, s.b[k].y, s.b[k].z, s.b[k].w};
+        if (XF && J.mode == 1) {                 // x_k = sin(q_k) * h_k            (modulation.py:88-90)
+            const float qv[4] = {s.b2[k].x, s.b2[k].y, s.b2[k].z, s.b2[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = nvp_sin(qv[e]) * bv[e];
+        } else if (XF && J.mode == 2) {          // x_0 = sin(30 (w s + c)) * h_0
+            const int row = 4 * (f >> 5);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = nvp_sin(30.0f * __fmaf_rn(sp, A.sir0_wp[row + e], A.sir0_bp[row + e])) * bv[e];
+        }
         la[o] = s.a[k].x; la[o + kRowStride] = s.a[k].y; la[o + 2 * kRowStride] = s.a[k].z; la[o + 3 * kRowStride] = s.a[k].w;
-        lb[o] = s.b[k].x; lb[o + kRowStride] = s.b[k].y; lb[o + 2 * kRowStride] = s.b[k].z; lb[o + 3 * kRowStride] = s.b[k].w;
+        lb[o] = ok ? bv[0] : 0.f; lb[o + kRowStride] = ok ? bv[1] : 0.f;
+        lb[o + 2 * kRowStride] = ok ? bv[2] : 0.f; lb[o + 3 * kRowStride] = ok ? bv[3] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);       // one float4 at a time: keeps the sincos temporaries of 16 values from piling up
     }
 }
 
@@ -86,18 +117,41 @@ __device__ __forceinline__ void read_frag(float (&f)[16], const float* __restric
     for (int k = 0; k < 16; ++k) f[k] = p[k];
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk) {
+// KIND 0: the modulator jobs (plain operands); KIND 1: SIREN layers 1-2, whose B operand x_k is rebuilt
+// on the fly; KIND 2: the small job (last layer + SIREN layer 0).  Separate instantiations keep each
+// variant's register budget tight (the union spilled).
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // provably wave-uniform
     const int i = lane & 31, h = lane >> 5;
-    const int chunk = blockIdx.x;
+    // XCD-aware block mapping.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
+    // observed; only speed depends on it).  The jobs of one pixel chunk share streams (z is read by three
+    // jobs, h0/h1/dp1/dp2 by two), so they are given consecutive slots on the SAME XCD: they start together
+    // and the second reader of a stream finds it in that XCD's L2 instead of HBM.
+    int chunk, job;
+    {
+        const int L = blockIdx.x, nj = A.n_jobs;
+#ifndef NVP_DW_XCD
+#define NVP_DW_XCD 1
+#endif
+        if (NVP_DW_XCD && (n_chunks & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            chunk = (slot / nj) * 8 + xcd;
+            job = slot - (slot / nj) * nj;
+        } else {
+            chunk = L / nj;
+            job = L - chunk * nj;
+        }
+    }
     const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
     const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
     float* part = partials + (int64_t)chunk * A.total;
-    const bool small = (int)blockIdx.y == A.n_jobs - 1;
-    const DwJob J = A.job[blockIdx.y];
+    constexpr bool XF = KIND != 0;
+    constexpr bool small = KIND == 2;
+    const DwJob J = A.job[job];
     const int wr = w >> 1, wc = w & 1;                // regular jobs: wave owns rows 64wr.., columns 64wc..
 
     f32x16 acc[2][2];
@@ -109,34 +163,53 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
     float w0sum = 0.f;
     const bool want_bias = !small && (J.bias_off >= 0) && (wc == 0);
 
-    Stage st;
+    // Global loads run TWO tiles ahead of the MFMAs (one tile in LDS, the next two in registers st/st2):
+    // under load the HBM round trip exceeds one tile's 4096 MFMA cycles.
+#ifndef NVP_DW_DEPTH
+#define NVP_DW_DEPTH 1
+#endif
+    Stage st, st2;
     if (t0 < t1) {
-        load_stage(st, J, t0, tid);
-        write_stage(lds, lds + kTileFloats, st, tid);
+        load_stage<XF>(st, J, t0, tid);
+        write_stage<XF>(lds, lds + kTileFloats, st, J, A, t0, n, tid);
     }
+#if NVP_DW_DEPTH == 2
+    if (t0 + 1 < t1) load_stage<XF>(st, J, t0 + 1, tid);
+#endif
     __syncthreads();
     int cur = 0;
     for (int64_t t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
-        if (more) load_stage(st, J, t + 1, tid);       // global loads fly during this tile's MFMAs
+#if NVP_DW_DEPTH == 2
+        if (t + 2 < t1) load_stage<XF>(st2, J, t + 2, tid);
+#else
+        if (more) load_stage<XF>(st, J, t + 1, tid);
+#endif
         const float* la = lds + cur * 2 * kTileFloats;
         const float* lb = la + kTileFloats;
         if (!small) {
-            float fa[2][16], fb[2][16];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) read_frag(fa[r], la, 64 * wr + 32 * r + i, h);
+            float fa[16], fb[2][16];
+            read_frag(fa, la, 64 * wr + i, h);
 #pragma unroll
             for (int c = 0; c < 2; ++c) read_frag(fb[c], lb, 64 * wc + 32 * c + i, h);
             if (want_bias) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) { bsum0 += fa[0][k]; bsum1 += fa[1][k]; }
+                for (int k = 0; k < 16; ++k) bsum0 += fa[k];
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                acc[0][0] = nvp_mfma(fa[0][k], fb[0][k], acc[0][0]);
-                acc[0][1] = nvp_mfma(fa[0][k], fb[1][k], acc[0][1]);
-                acc[1][0] = nvp_mfma(fa[1][k], fb[0][k], acc[1][0]);
-                acc[1][1] = nvp_mfma(fa[1][k], fb[1][k], acc[1][1]);
+                acc[0][0] = nvp_mfma(fa[k], fb[0][k], acc[0][0]);
+                acc[0][1] = nvp_mfma(fa[k], fb[1][k], acc[0][1]);
+            }
+            read_frag(fa, la, 64 * wr + 32 + i, h);          // second row tile reuses the A registers
+            if (want_bias) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) bsum1 += fa[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[1][0] = nvp_mfma(fa[k], fb[0][k], acc[1][0]);
+                acc[1][1] = nvp_mfma(fa[k], fb[1][k], acc[1][1]);
             }
         } else {
             // small job: staged A = dq0s (for SIREN layer 0: dw0 = sum dq0s*s, dc0 = sum dq0s),
@@ -149,8 +222,11 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int64_t px = px0 + k;
-                a3[k] = (i < 3 && px < n) ? A.drgb[px * 3 + i] : 0.f;
-                sv[k] = px < n ? A.steps[px] : 0.f;
+                const int64_t pc = min(px, n - 1);                       // clamped address + data select (no branch)
+                const float g = A.drgb[pc * 3 + min(i, 2)];
+                const float sp = A.steps[pc];
+                a3[k] = (i < 3 && px < n) ? g : 0.f;
+                sv[k] = px < n ? sp : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -160,7 +236,10 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
                 bsum1 += q[k];
             }
         }
-        if (more) write_stage(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, tid);
+        if (more) write_stage<XF>(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, J, A, t + 1, n, tid);
+#if NVP_DW_DEPTH == 2
+        st = st2;
+#endif
         __syncthreads();
         cur ^= 1;
     }
@@ -223,9 +302,9 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
-                              const float* dy, const float* xs, float* partials, int32_t n_chunks,
+                              const float* dy, const nvp_mlp_params* p, float* partials, int32_t n_chunks,
                               const nvp_mlp_grads* g, int64_t n, int32_t d, void* stream) {
-    if (!drgb || !steps || !zt || !saved || !dy || !xs || !partials || !g || n < 0 || d < 1 || n_chunks < 1) return NVP_ERR_BADARG;
+    if (!drgb || !steps || !zt || !saved || !dy || !p || !partials || !g || n < 0 || d < 1 || n_chunks < 1) return NVP_ERR_BADARG;
     const NvpParamLayout P = nvp_param_layout(d);
     const int64_t ntiles = nvp_ntiles(n);
     const int rows = nvp_rows4(d);
@@ -240,37 +319,52 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
         bool bias_done = false;
         if (k > 0) {
             DwJob& J = A.job[nj++];
-            J.a = dy + (int64_t)k * act; J.b = saved + (int64_t)(k - 1) * act; J.b_rows = NVP_H; J.b_row0 = 0;
+            J.a = dy + (int64_t)k * act; J.b = saved + (int64_t)(k - 1) * act; J.b2 = J.b; J.mode = 0; J.b_rows = NVP_H; J.b_row0 = 0;
             J.n_cols = NVP_H; J.w_off = P.mod_w[k]; J.ld = ld; J.bias_off = P.mod_b[k];
             bias_done = true;
         }
         for (int c0 = 0; c0 < d; c0 += 128) {
             DwJob& J = A.job[nj++];
-            J.a = dy + (int64_t)k * act; J.b = zt; J.b_rows = rows; J.b_row0 = c0;
+            J.a = dy + (int64_t)k * act; J.b = zt; J.b2 = zt; J.mode = 0; J.b_rows = rows; J.b_row0 = c0;
             J.n_cols = (d - c0 < 128) ? d - c0 : 128;
             J.w_off = P.mod_w[k] + (k == 0 ? 0 : NVP_H) + c0; J.ld = ld;
             J.bias_off = bias_done ? -1 : P.mod_b[k];
             bias_done = true;
         }
     }
-    // SIREN layers 1, 2: A = dq_k; B = x_{k-1}
+    // SIREN layers 1, 2: A = dq_k; B = x_{k-1} = sin(q_{k-1}) h_{k-1}, rebuilt from the saved h (and q) streams
     for (int k = 1; k <= 2; ++k) {
         DwJob& J = A.job[nj++];
-        J.a = dy + (int64_t)(3 + k) * act; J.b = xs + (int64_t)(k - 1) * act; J.b_rows = NVP_H; J.b_row0 = 0;
+        J.a = dy + (int64_t)(3 + k) * act; J.b = saved + (int64_t)(k - 1) * act; J.b_rows = NVP_H; J.b_row0 = 0;
+        if (k == 1) { J.b2 = J.b; J.mode = 2; } else { J.b2 = saved + 3 * act; J.mode = 1; }
         J.n_cols = NVP_H; J.w_off = P.sir_w[k]; J.ld = NVP_H; J.bias_off = P.sir_b[k];
     }
-    {   // the small job stages dq0s as its A tile and x2 as its B tile
+    {   // the small job stages dq0s as its A tile and x2 = sin(q2) h2 as its B tile
         DwJob& J = A.job[nj];
-        J.a = dy + 3 * act; J.b = xs + 2 * act; J.b_rows = NVP_H; J.b_row0 = 0; J.n_cols = NVP_H;
+        J.a = dy + 3 * act; J.b = saved + 2 * act; J.b2 = saved + 4 * act; J.mode = 1; J.b_rows = NVP_H; J.b_row0 = 0; J.n_cols = NVP_H;
         J.w_off = 0; J.ld = NVP_H; J.bias_off = -1;
     }
     A.n_jobs = nj + 1;
-    A.drgb = drgb; A.steps = steps; A.x2 = xs + 2 * act; A.dq0s = dy + 3 * act;
+    A.drgb = drgb; A.steps = steps; A.sir0_wp = p->sir_w[0]; A.sir0_bp = p->sir_b[0];
     A.last_w = P.last_w; A.last_b = P.last_b; A.sir0_w = P.sir_w[0]; A.sir0_b = P.sir_b[0];
     A.total = P.total;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(n_chunks, A.n_jobs), dim3(256), 2 * 2 * kTileFloats * sizeof(float), (hipStream_t)stream, A, partials, n, ntiles, tiles_per_chunk);
+    // three launches: plain jobs (modulator layers), transform jobs (SIREN layers 1-2), the small job
+    DwArgs P0 = A, P1 = A, P2 = A;
+    int n0 = 0, n1 = 0;
+    for (int jx = 0; jx < A.n_jobs - 1; ++jx) {
+        if (A.job[jx].mode == 0) P0.job[n0++] = A.job[jx];
+        else P1.job[n1++] = A.job[jx];
+    }
+    P0.n_jobs = n0; P1.n_jobs = n1;
+    P2.job[0] = A.job[A.n_jobs - 1]; P2.n_jobs = 1;
+    const size_t lds_bytes = 2 * 2 * kTileFloats * sizeof(float);
+    hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    NVP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_dw_kernel<1>, dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    NVP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_dw_kernel<2>, dim3(n_chunks), dim3(256), lds_bytes, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
 
     ReduceArgs R;

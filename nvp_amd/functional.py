@@ -160,16 +160,15 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     packed = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32)
     L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
     dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
-    xs = torch.empty((3, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
     dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
     drgb = _f32c(drgb)
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
-                               L.ptr(dy), L.ptr(xs), L.ptr(dz_rows), n, d, stream), "nvp_mlp_bwd_dx")
+                               L.ptr(dy), L.ptr(dz_rows), n, d, stream), "nvp_mlp_bwd_dx")
     grads = [torch.empty_like(t) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
-    L.check(_call("nvp_mlp_bwd_dw", lib.nvp_mlp_bwd_dw, L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), L.ptr(xs),
+    L.check(_call("nvp_mlp_bwd_dw", lib.nvp_mlp_bwd_dw, L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), C.byref(pstruct),
                                L.ptr(partials), nch, C.byref(gstruct), n, d, stream), "nvp_mlp_bwd_dw")
     return dz_rows, grads
 

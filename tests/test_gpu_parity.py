@@ -342,7 +342,7 @@ def test_psnr_at_equal_steps_matches_oracle():
     import math
     from nvp_amd import harness
     from nvp_amd.modules import NVP
-    T, H, W, n, steps_total = 16, 64, 64, 16384, 60
+    T, H, W, n, steps_total = 16, 64, 64, 8192, 30
     cfg = small_cfg(F=2, T=T, X=20, Y=20)
     sd = O.init_state(cfg, seed=3)                       # reference init distributions
     model = NVP(out_features=3, encoding_config=cfg)
