@@ -47,6 +47,19 @@ class KernelTimer:
 
 TIMER = None      # set to a KernelTimer() to time launches
 
+# Optional gradient sink (data parallelism): {param.data_ptr(): preallocated tensor}.  When a
+# parameter has an entry, backward writes its gradient straight into that tensor (a view of the
+# flat all-reduce bucket) and returns it, so no zero-fill / accumulate / flatten pass exists.
+GRAD_SINK = None
+
+
+def _grad_buffer(param: torch.Tensor) -> torch.Tensor:
+    if GRAD_SINK is not None:
+        t = GRAD_SINK.get(param.data_ptr())
+        if t is not None and t.shape == param.shape and t.is_contiguous() and t.dtype == torch.float32:
+            return t.detach()      # fresh alias (use_count 1) so autograd adopts it as .grad without a clone
+    return torch.empty_like(param)
+
 
 def _call(name, fn, *args):
     if TIMER is not None:
@@ -164,7 +177,7 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     drgb = _f32c(drgb)
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
                                L.ptr(dy), L.ptr(dz_rows), n, d, stream), "nvp_mlp_bwd_dx")
-    grads = [torch.empty_like(t) for t in mlp]
+    grads = [_grad_buffer(t) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
@@ -270,7 +283,7 @@ class NVPFused(torch.autograd.Function):
         dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
-        d_xy, d_yt, d_xt, d_emb = (torch.empty_like(t) for t in (kf_xy, kf_yt, kf_xt, emb))
+        d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t) for t in (kf_xy, kf_yt, kf_xt, emb))
         ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
         if ws_bytes < 0:
             raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")

@@ -103,15 +103,20 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     """One iteration in the reference's order (training.py:50-76). Returns the (device) loss.
     `bucket` (parallel.GradBucket) turns on data parallelism: gradients live in one flat
     buffer that is zeroed here and all-reduced once between backward and the optimizer."""
+    from . import functional
     out = model(model_input)["model_out"]
     loss = image_mse_u8(out, gt["img"])
     if bucket is not None:
-        bucket.zero_()
+        bucket.detach_grads()                       # == zero_grad(set_to_none=True)
+        functional.GRAD_SINK = bucket.sink()        # backward writes straight into the flat buffer
     else:
         opt.zero_grad()
-    loss.backward()
+    try:
+        loss.backward()
+    finally:
+        functional.GRAD_SINK = None
     if bucket is not None:
-        bucket.all_reduce_mean()
+        bucket.all_reduce_mean()                    # copies back only if some grad did not land in the bucket
     opt.step()
     sched.step()
     return loss.detach()

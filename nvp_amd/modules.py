@@ -47,11 +47,9 @@ class NVP(nn.Module):
         b, t = timesteps.size(0), timesteps.size(1)
         steps = timesteps.reshape(b * t)
         coords = model_input['all_coords'].reshape(-1, 3)       # (t, x, y)
-        if self.sparse_grid.upsample:
-            self.sparse_grid._grid()                             # raises: not implemented
         out = NVPFused.apply(coords, steps,
                              self.keyframes_xy.params, self.keyframes_yt.params, self.keyframes_xt.params,
-                             self.sparse_grid.embeddings,
+                             self.sparse_grid._grid(),            # == embeddings unless upsample=True
                              self.keyframes_xy.levels, self.keyframes_yt.levels, self.keyframes_xt.levels,
                              bool(temporal_interp), torch.is_grad_enabled(), *self.wrapper.mlp_tensors())
         return {'model_out': out.reshape((b, t, 3))}

@@ -70,6 +70,16 @@ class GradBucket:
         self.flat.zero_()
         self.attach()
 
+    def sink(self) -> dict:
+        """{param.data_ptr(): bucket view} for nvp_amd.functional.GRAD_SINK: backward then writes each
+        gradient directly into the flat buffer (every element exactly once - no zero-fill needed)."""
+        return {p.data_ptr(): v for p, v in zip(self.params, self.views)}
+
+    def detach_grads(self) -> None:
+        """Drop .grad so autograd adopts the tensors backward returns (the bucket views) without a copy."""
+        for p in self.params:
+            p.grad = None
+
     def consistent(self) -> bool:
         return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 

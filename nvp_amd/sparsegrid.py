@@ -29,11 +29,15 @@ class SparseGrid(nn.Module):
         self.embeddings.data.uniform_(-std, std)
 
     def _grid(self) -> torch.Tensor:
-        if self.upsample:
-            # reference sparsegrid.py:26-34 (x2 bilinear pre-upsample of the whole grid every
-            # call).  Both shipped configs set "upsample": false; SURVEY 8f-N4 ranks it last.
-            raise NotImplementedError("SparseGrid(upsample=True) is not implemented on the HIP path yet")
-        return self.embeddings
+        """The grid the gather reads.  With upsample=True the reference bilinearly upsamples the (x,y)
+        axes of the WHOLE grid by 2 on every call (sparsegrid.py:26-34: F.interpolate over
+        [dim, T, X, Y], a stock ATen kernel there and here); the HIP gather / scatter then run on the
+        upsampled tensor and autograd carries the gradient back through the interpolation."""
+        if not self.upsample:
+            return self.embeddings
+        t = self.embeddings.permute(3, 0, 1, 2)
+        t = torch.nn.functional.interpolate(t, scale_factor=2, mode='bilinear')
+        return t.permute(1, 2, 3, 0).contiguous()
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         return SparseGrid3x3.apply(inputs, self._grid(), False)

@@ -252,6 +252,39 @@ def gen_init(seed):
     np.savez_compressed(os.path.join(OUT, f"init_seed{seed}.npz"), **blob)
 
 
+def gen_quant(seed):
+    """eval.py's quantize_keyframes / quantize_sparse_grid are plain functions at the top of a script that
+    cannot be imported (argparse + missing packages at module level).  Their two `def`s are extracted from
+    the reference file with `ast` and executed here, in the build container only, to capture golden
+    outputs; `.cuda()` is neutralised because this container has no GPU."""
+    import ast
+    import math
+    from torch import nn
+    src = open(os.path.join(REF, "experiment_scripts", "eval.py")).read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("quantize_keyframes", "quantize_sparse_grid")]
+    assert len(fns) == 2
+    env = {"torch": torch, "nn": nn, "math": math, "unit_multiplier": 2.0 ** 8 - 1.0}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "eval.py", "exec"), env)
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        gen = torch.Generator().manual_seed(seed)
+        cfg = {"n_levels": 5, "n_features_per_level": 2, "per_level_scale": 1.35, "base_resolution": 16}
+        n = O.dense_grid_n_params(cfg)
+        kf = torch.randn(n, generator=gen) * 0.1
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kq = env["quantize_keyframes"](kf.clone(), cfg).detach()
+            sg = torch.randn((5, 6, 7, 2), generator=gen) * 0.05
+            sq = env["quantize_sparse_grid"](sg.clone(), {"n_features_per_level": 2}).detach()
+    finally:
+        torch.Tensor.cuda = orig
+    np.savez_compressed(os.path.join(OUT, "quant.npz"), kf=kf.numpy(), kf_q=kq.numpy(), sg=sg.numpy(), sg_q=sq.numpy(),
+                        n_levels=np.array(5))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # deterministic reductions while generating
@@ -262,6 +295,7 @@ def main():
     gen_mlp(228, 256, seed=22)
     gen_e2e(seed=31)
     gen_init(seed=123)
+    gen_quant(seed=41)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"golden fixtures written to {OUT} ({tot / 1024:.0f} KiB); oracle == reference on all cases")
 

@@ -82,6 +82,24 @@ def test_sparse_grid_golden(tag):
     assert _eq(inter.cpu().numpy(), g["out_inter"]), "forward_inter incl. the NaN rows at t == 1"
 
 
+def test_sparse_grid_upsample_golden():
+    """upsample=True (sparsegrid.py:26-34) against the reference golden, and its gradient vs the oracle."""
+    from nvp_amd.sparsegrid import SparseGrid
+    g = _load("sparse_upsample.npz")
+    T, X, Y, Fd = g["emb"].shape
+    m = SparseGrid(level_dim=Fd, x_resolution=X, y_resolution=Y, t_resolution=T, upsample=True).to(dev())
+    with torch.no_grad():
+        m.embeddings.copy_(torch.from_numpy(g["emb"]))
+    coords = torch.from_numpy(g["coords"])
+    out = m(coords.to(dev()))
+    # the interpolation itself is an ATen kernel on both sides (CPU vs HIP): allow 1-ulp-level differences
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-6, atol=1e-6)
+    emb_ref = torch.from_numpy(g["emb"]).clone().requires_grad_(True)
+    (O.sparse_grid_forward(emb_ref, coords, upsample=True) ** 2).sum().backward()
+    (out ** 2).sum().backward()
+    assert _relerr(m.embeddings.grad.cpu().numpy(), emb_ref.grad.numpy()) < 1e-5
+
+
 def test_sparse_grid_border_multiplicity():
     """clamped border duplicates accumulate: a corner pixel hits the corner cell 4x."""
     from nvp_amd.sparsegrid import SparseGrid

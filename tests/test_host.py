@@ -135,3 +135,41 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "nvp_oracle" not in src and "oracle" not in re.findall(r"^\s*(?:from|import)\s+(\S+)", src, re.M), f
+
+
+def test_quantisation_matches_reference_eval_script():
+    """nvp_amd.quantize vs golden outputs of eval.py:19-109 (captured by oracle/make_golden.py)."""
+    from nvp_amd import quantize
+    g = np.load(os.path.join(GOLDEN, "quant.npz"))
+    cfg = {"n_levels": 5, "n_features_per_level": 2, "per_level_scale": 1.35, "base_resolution": 16}
+    kq = quantize.quantize_keyframes(torch.from_numpy(g["kf"]), cfg)
+    assert isinstance(kq, torch.nn.Parameter) and np.array_equal(kq.detach().numpy(), g["kf_q"])
+    sq = quantize.quantize_sparse_grid(torch.from_numpy(g["sg"]), {"n_features_per_level": 2})
+    assert np.array_equal(sq.detach().numpy(), g["sg_q"])
+    # 8-bit: at most 256 distinct values per (level, feature)
+    lv = L.make_levels(cfg)
+    blk = kq.detach().reshape(-1, 2)[int(lv.offset[4]):int(lv.offset[5]), 1]
+    assert blk.unique().numel() <= 256
+
+
+def test_quantised_bpp_reproduces_readme_operating_point():
+    """eval.py:189-190 on the 600-frame 1080p geometry gives 0.8754 bpp."""
+    from nvp_amd import quantize
+    n_all, n_mlp = 135807267, 110595
+    bpp = (n_all * 8 + n_mlp * 24) / (600 * 1080 * 1920)
+    assert abs(bpp - 0.8754) < 5e-4
+    m = modules.NVP(out_features=3, encoding_config=small_cfg())
+    assert quantize.quantized_bpp(m, 8, 64, 64) > 0
+
+
+def test_grad_sink_returns_fresh_alias():
+    from nvp_amd import functional
+    p = torch.nn.Parameter(torch.zeros(6))
+    buf = torch.zeros(6)
+    functional.GRAD_SINK = {p.data_ptr(): buf}
+    try:
+        g = functional._grad_buffer(p)
+    finally:
+        functional.GRAD_SINK = None
+    assert g is not buf and g.data_ptr() == buf.data_ptr()
+    assert functional._grad_buffer(p).data_ptr() != buf.data_ptr()      # no sink -> private buffer
