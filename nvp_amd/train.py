@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""End-to-end encode (= train) + evaluate driver on the HIP path: the repo's own counterpart of the
+reference's train_video.py -> training.train -> eval.py flow, without its
+tensorboard / checkpoint / argparse plumbing.
+
+    python -m nvp_amd.train --video procedural --frames 600 --height 1080 --width 1920 --seconds 90
+    python -m nvp_amd.train --video /path/to/video.npy --steps 4000         # uint8 [T,H,W,3]
+
+What it reproduces from the reference: model = NVP(config_nvp_s|l with t_resolution = #frames),
+N = 1 245 184 samples per step drawn as dataio.py:104-120, loss/PSNR as training.py:47-61,
+AdamW(1e-2, wd 1e-3) + CosineAnnealingLR(T_max = total steps, eta_min 1e-5), per-frame eval PSNR on
+[0,1] as eval.py:243-256, and the 8-bit grid quantisation of eval.py:19-109 for the final number.
+Prints one JSON line per report and a final summary line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from nvp_amd import harness, quantize  # noqa: E402
+from nvp_amd.modules import NVP  # noqa: E402
+
+
+def config(size: str, t_res: int) -> dict:
+    F = {"s": 2, "l": 4}[size]          # the only difference between config_nvp_s.json and config_nvp_l.json
+    enc = {"otype": "DenseGrid", "n_levels": 16, "n_features_per_level": F, "log2_hashmap_size": 32,
+           "base_resolution": 16, "per_level_scale": 1.35}
+    return {"2d_encoding_xy": dict(enc), "2d_encoding_xt": dict(enc), "2d_encoding_yt": dict(enc),
+            "3d_encoding": {"otype": "SparseGrid", "n_features_per_level": F, "x_resolution": 300, "y_resolution": 300,
+                            "t_resolution": t_res, "upsample": False},
+            "network": {"n_neurons": 128, "n_hidden_layers": 3}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["s", "l"], default="s")
+    ap.add_argument("--video", default="procedural", help="'procedural' or a .npy file with uint8 [T,H,W,3]")
+    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--steps", type=int, default=0, help="total optimisation steps (cosine horizon)")
+    ap.add_argument("--seconds", type=float, default=0, help="alternative to --steps: wall-clock budget; the cosine "
+                                                             "horizon is set from a short calibration of the step rate")
+    ap.add_argument("--report-every", type=int, default=500)
+    ap.add_argument("--eval-frames", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    assert torch.cuda.is_available(), "nvp_amd.train needs a HIP device"
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(args.seed)
+
+    if args.video == "procedural":
+        video = harness.procedural_video(args.frames, args.height, args.width, dev, seed=args.seed)
+        source = "procedural moving pattern (UVG frames are not shipped)"
+    else:
+        video = torch.from_numpy(np.load(args.video)[:args.frames]).to(dev)
+        source = args.video
+    T, H, W = (int(v) for v in video.shape[:3])
+    model = NVP(out_features=3, encoding_config=config(args.config, T)).to(dev)
+    data = harness.DeviceVideo(video, seed=args.seed)
+    frames = [int(round(i * (T - 1) / max(args.eval_frames - 1, 1))) for i in range(args.eval_frames)]
+
+    total = args.steps
+    if total <= 0:
+        # calibrate the step rate on throw-away optimiser state, then fix the cosine horizon
+        opt, sched = harness.make_optimizer(model, total_steps=1000)
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        for _ in range(5):
+            harness.train_step(model, opt, sched, *data.sample())
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            harness.train_step(model, opt, sched, *data.sample())
+        torch.cuda.synchronize(); rate = 20 / (time.perf_counter() - t0)
+        model.load_state_dict(state)
+        total = max(int(rate * args.seconds * 0.97), 10)
+    opt, sched = harness.make_optimizer(model, total_steps=total)
+
+    torch.cuda.synchronize()
+    train_s, seg = 0.0, time.perf_counter()          # evaluation time is excluded from the encode clock
+    for step in range(total):
+        loss = harness.train_step(model, opt, sched, *data.sample())
+        if (step + 1) % args.report_every == 0 or step + 1 == total:
+            torch.cuda.synchronize()
+            train_s += time.perf_counter() - seg
+            print(json.dumps({"step": step + 1, "seconds": round(train_s, 2), "train_psnr": round(harness.train_psnr(loss), 3),
+                              "eval_psnr": round(harness.eval_psnr(model, data, frames), 3),
+                              "mpx_per_s": round((step + 1) * data.n / train_s / 1e6, 2)}), flush=True)
+            torch.cuda.synchronize()
+            seg = time.perf_counter()
+    encode_s = train_s
+
+    psnr_fp32 = harness.eval_psnr(model, data, frames)
+    with torch.no_grad():                                   # eval.py:163-179: rebind 8-bit de-quantised grids
+        cfg = config(args.config, T)
+        for name, key in (("keyframes_xy", "2d_encoding_xy"), ("keyframes_xt", "2d_encoding_xt"), ("keyframes_yt", "2d_encoding_yt")):
+            enc = getattr(model, name)
+            enc.params = quantize.quantize_keyframes(enc.params.detach(), cfg[key])
+        model.sparse_grid.embeddings = quantize.quantize_sparse_grid(model.sparse_grid.embeddings.detach())
+    psnr_q8 = harness.eval_psnr(model, data, frames)
+    print(json.dumps({"summary": True, "video": source, "frames": T, "height": H, "width": W, "config": "nvp_" + args.config,
+                      "steps": total, "encode_seconds": round(encode_s, 2), "eval_frames": frames,
+                      "psnr_fp32": round(psnr_fp32, 3), "psnr_8bit_grids": round(psnr_q8, 3),
+                      "bpp_8bit": round(quantize.quantized_bpp(model, T, H, W), 4),
+                      "mpx_per_s": round(total * data.n / encode_s / 1e6, 2)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
