@@ -38,6 +38,9 @@ extern "C" {
 #define NVP_ERR_BADARG (-1)
 #define NVP_ERR_UNSUPPORTED (-2)
 
+/* nvp_encode_bwd flags */
+#define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: skips one radix sort */
+
 /* Geometry of one 2D multi-resolution dense grid (one "learnable keyframe" plane).
  * Built on the host exactly as the reference restates it, eval.py:28-35:
  *   a = exp(l*log(per_level_scale))*base - 1 (double); res = ceil(a)+1; offset += res^2.
@@ -117,13 +120,16 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
  * dz: ROW-MAJOR [>= N][dz_stride] latent gradient as written by nvp_mlp_bwd_dx (columns
  * xy | yt | xt | sparse).  d_kf_* and d_emb: every element is OVERWRITTEN (deterministic
  * sorted-band fixed-point accumulation: no atomics, no zero-fill needed, bit-reproducible).
- * workspace: device scratch of nvp_encode_bwd_workspace_bytes() bytes. */
+ * workspace: device scratch of nvp_encode_bwd_workspace_bytes() bytes.
+ * flags: NVP_COORDS_SORTED_BY_Y if the batch is already ordered by its y coordinate (the loss is
+ * permutation-invariant, so a sampler may deliver its batch that way; results are identical). */
 int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
                                        const nvp_levels* lv_xt, const nvp_sparse_shape* sh);
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, void* stream);
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
+                   void* stream);
 
 /* Row-major [N,D] <-> PTM [ntiles][rows][32] (used by the stand-alone SirenWrapper). */
 int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream);

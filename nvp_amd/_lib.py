@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnvp_hip.so")
 
 NVP_MAX_LEVELS = 16
+COORDS_SORTED_BY_Y = 1
 HIDDEN = 128
 TILE = 32
 
@@ -58,7 +59,7 @@ SIGNATURES = {
     "nvp_encode_fwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), C.c_int, _vp],
     "nvp_encode_bwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
-                       C.POINTER(SparseShape), _vp, _i64, _vp],
+                       C.POINTER(SparseShape), _vp, _i64, _i32, _vp],
     "nvp_encode_bwd_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],
     "nvp_dz_stride": [_i32],
     "nvp_rows_to_ptm": [_p, _p, _i64, _i32, _i32, _vp],

@@ -450,13 +450,15 @@ bool levels_ok(const nvp_levels* lv) {
 
 template <int F>
 int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
-               const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, hipStream_t s) {
+               const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s) {
     float* ky = (float*)(ws + W.keys_in[0]);
     float* kx = (float*)(ws + W.keys_in[1]);
     int* iota = (int*)(ws + W.iota);
     hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota, n);
     size_t tmp = W.sort_tmp_bytes;
+    const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     for (int k = 0; k < 2; ++k) {
+        if (k == 0 && y_sorted) continue;          // the batch already arrives in ascending y: identity order
         hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[k]), (float*)(ws + W.keys_out[k]),
                                                  (const int*)iota, (int*)(ws + W.order[k]), (size_t)n, 0, 32, s);
         if (e != hipSuccess) return (int)e;
@@ -469,7 +471,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     int col = 0;
     const int c0[3] = {1, 0, 0}, c1[3] = {2, 2, 1}, ord[3] = {0, 0, 1};
     for (int p = 0; p < 3; ++p) {
-        PA.order[p] = (const int*)(ws + W.order[ord[p]]);
+        PA.order[p] = (ord[p] == 0 && y_sorted) ? (const int*)iota : (const int*)(ws + W.order[ord[p]]);
         PA.cs[p] = (float2*)(ws + W.cs[p]);
         PA.dzs[p] = (float*)(ws + W.dzs[p]);
         PA.col0[p] = col; PA.nlev[p] = lv[p]->n_levels; PA.c0[p] = c0[p]; PA.c1[p] = c1[p];
@@ -563,7 +565,7 @@ int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, void* stream) {
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream) {
     if (!levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh || n < 0) return NVP_ERR_BADARG;
     if (lv_xy->n_features != lv_yt->n_features || lv_xy->n_features != lv_xt->n_features) return NVP_ERR_UNSUPPORTED;
     if (n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;
@@ -590,10 +592,10 @@ int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                      9 * sh->n_features;
     if (dz_stride < need) return NVP_ERR_BADARG;
     switch (lv_xy->n_features) {
-        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
-        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
-        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
-        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, s); break;
+        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
+        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
+        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
+        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
         default: return NVP_ERR_UNSUPPORTED;
     }
     if (rc) return rc;

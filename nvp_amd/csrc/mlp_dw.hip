@@ -284,16 +284,35 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
     }
 }
 
+// The small job (last layer + SIREN layer 0: 643 gradient values) runs on kSmallMul x finer pixel chunks
+// (it has almost no MFMA work, so it needs the parallelism to stream its operands) and writes a compact
+// per-chunk record: last_w[384] | last_b[3] | pad | sir0_w[128] | sir0_b[128].
+constexpr int kSmallMul = 4;
+constexpr int kSmallTotal = 644;
+constexpr int kSmLastW = 0, kSmLastB = 384, kSmSir0W = 388, kSmSir0B = 516;
+
 struct ReduceArgs {
     float* dst[14];
     int64_t off[15];
+    int64_t small_base;        // float offset of the small region inside `partials`
+    int small_slots;
+    int64_t p_last_w, p_last_b, p_sir0_w, p_sir0_b;
 };
 
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partials, ReduceArgs R, int n_chunks, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += partials[(int64_t)c * total + idx];
+    int so = -1;               // offset inside a small-job record, or -1
+    if (idx >= R.p_last_w && idx < R.p_last_w + 3 * NVP_H) so = kSmLastW + (int)(idx - R.p_last_w);
+    else if (idx >= R.p_last_b && idx < R.p_last_b + 3) so = kSmLastB + (int)(idx - R.p_last_b);
+    else if (idx >= R.p_sir0_w && idx < R.p_sir0_w + NVP_H) so = kSmSir0W + (int)(idx - R.p_sir0_w);
+    else if (idx >= R.p_sir0_b && idx < R.p_sir0_b + NVP_H) so = kSmSir0B + (int)(idx - R.p_sir0_b);
+    if (so >= 0) {
+        for (int c = 0; c < R.small_slots; ++c) s += partials[R.small_base + (int64_t)c * kSmallTotal + so];
+    } else {
+        for (int c = 0; c < n_chunks; ++c) s += partials[(int64_t)c * total + idx];
+    }
     int t = 0;
     while (idx >= R.off[t + 1]) ++t;
     R.dst[t][idx - R.off[t]] = s;
@@ -359,12 +378,16 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     }
     P0.n_jobs = n0; P1.n_jobs = n1;
     P2.job[0] = A.job[A.n_jobs - 1]; P2.n_jobs = 1;
+    P2.total = kSmallTotal; P2.last_w = kSmLastW; P2.last_b = kSmLastB; P2.sir0_w = kSmSir0W; P2.sir0_b = kSmSir0B;
+    const int small_chunks = n_chunks * kSmallMul;
+    const int small_tiles = (int)((ntiles + small_chunks - 1) / small_chunks);
+    float* small_part = partials + (int64_t)n_chunks * P.total;
     const size_t lds_bytes = 2 * 2 * kTileFloats * sizeof(float);
     hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_dw_kernel<1>, dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mlp_dw_kernel<2>, dim3(n_chunks), dim3(256), lds_bytes, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    hipLaunchKernelGGL(mlp_dw_kernel<2>, dim3(small_chunks), dim3(256), lds_bytes, (hipStream_t)stream, P2, small_part, n, ntiles, small_tiles, small_chunks);
     NVP_LAUNCH_CHECK();
 
     ReduceArgs R;
@@ -374,6 +397,8 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     R.dst[t] = g->last_w; R.off[t++] = P.last_w;
     R.dst[t] = g->last_b; R.off[t++] = P.last_b;
     R.off[t] = P.total;
+    R.small_base = (int64_t)n_chunks * P.total; R.small_slots = small_chunks;
+    R.p_last_w = P.last_w; R.p_last_b = P.last_b; R.p_sir0_w = P.sir_w[0]; R.p_sir0_b = P.sir_b[0];
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, R, n_chunks, P.total);
     NVP_LAUNCH_CHECK();
     return 0;

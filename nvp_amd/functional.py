@@ -239,7 +239,7 @@ class NVPFused(torch.autograd.Function):
     (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""
 
     @staticmethod
-    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, grad_mode, *mlp):
+    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, grad_mode, y_sorted, *mlp):
         lib = L.load()
         coords = _f32c(coords)
         steps = _f32c(steps).reshape(-1)
@@ -265,6 +265,7 @@ class NVPFused(torch.autograd.Function):
             if temporal_interp:
                 raise NotImplementedError("temporal_interp=True is an inference-only path (reference eval.py --t_interp)")
             ctx.n, ctx.d = n, d
+            ctx.flags = L.COORDS_SORTED_BY_Y if y_sorted else 0
             ctx.lv = (lv_xy, lv_yt, lv_xt)
             ctx.sh = sh
             if saved is None:
@@ -279,7 +280,7 @@ class NVPFused(torch.autograd.Function):
         n, d = ctx.n, ctx.d
         if n == 0:
             z = [torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb)]
-            return (None, None, *z, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
+            return (None, None, *z, None, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
         dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
@@ -291,6 +292,6 @@ class NVPFused(torch.autograd.Function):
         L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1],
                       L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
                       C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
-                      L.ptr(ws, torch.uint8), ws_bytes, L.stream_ptr()),
+                      L.ptr(ws, torch.uint8), ws_bytes, ctx.flags, L.stream_ptr()),
                 "nvp_encode_bwd")
-        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, *grads)
+        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, *grads)

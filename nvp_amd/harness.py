@@ -47,12 +47,13 @@ def image_mse_u8(model_out: torch.Tensor, gt_u8: torch.Tensor) -> torch.Tensor:
 class DeviceVideo:
     """u8 video [T, H, W, 3] kept on the device + the reference's per-step random sampler."""
 
-    def __init__(self, video_u8: torch.Tensor, n_samples: int = N_SAMPLES, seed: int = 0):
+    def __init__(self, video_u8: torch.Tensor, n_samples: int = N_SAMPLES, seed: int = 0, sort_by_y: bool = True):
         if video_u8.dtype != torch.uint8 or video_u8.dim() != 4 or video_u8.shape[-1] != 3:
             raise ValueError("video must be uint8 [T, H, W, 3]")
         self.video = video_u8.contiguous()
         self.T, self.H, self.W = (int(v) for v in video_u8.shape[:3])
         self.n = int(n_samples)
+        self.sort_by_y = bool(sort_by_y)
         dev = video_u8.device
         half_dt = 0.5 / self.T
         # dataio.py:93-99: modulation input and temporal coordinate tables
@@ -68,13 +69,22 @@ class DeviceVideo:
         n = self.n
         ti = torch.randint(0, self.T, (n,), device=dev, generator=self.gen)
         pi = torch.randint(0, self.H * self.W, (n,), device=dev, generator=self.gen)
+        if self.sort_by_y:
+            # Same i.i.d. draws as the reference, delivered in ascending-y (= image column) order.  The MSE
+            # is permutation-invariant; the order gives the grid gathers row locality and lets the
+            # gradient scatter skip one sort (NVP_COORDS_SORTED_BY_Y).
+            order = torch.argsort((pi % self.W).to(torch.int16))
+            ti, pi = ti[order], pi[order]
         coords = torch.empty((n, 3), device=dev, dtype=torch.float32)
         steps = torch.empty((n,), device=dev, dtype=torch.float32)
         gt = torch.empty((n, 3), device=dev, dtype=torch.uint8)
         L.check(lib.nvp_sample_gather(L.ptr(self.video, torch.uint8), L.ptr(ti, torch.int64), L.ptr(pi, torch.int64),
                                       L.ptr(self.tcoord_tab), L.ptr(self.tstep_tab), L.ptr(coords), L.ptr(steps),
                                       L.ptr(gt, torch.uint8), n, self.T, self.H, self.W, L.stream_ptr()), "nvp_sample_gather")
-        return ({"all_coords": coords.unsqueeze(0), "temporal_steps": steps.unsqueeze(0)}, {"img": gt.unsqueeze(0)})
+        mi = {"all_coords": coords.unsqueeze(0), "temporal_steps": steps.unsqueeze(0)}
+        if self.sort_by_y:
+            mi["sorted_by_y"] = True
+        return (mi, {"img": gt.unsqueeze(0)})
 
     def frame_batch(self, frame: int, lo: int, hi: int):
         """Whole-frame evaluation slice (eval.py:219-239): pixels [lo, hi) of one frame."""

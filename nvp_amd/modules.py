@@ -51,5 +51,7 @@ class NVP(nn.Module):
                              self.keyframes_xy.params, self.keyframes_yt.params, self.keyframes_xt.params,
                              self.sparse_grid._grid(),            # == embeddings unless upsample=True
                              self.keyframes_xy.levels, self.keyframes_yt.levels, self.keyframes_xt.levels,
-                             bool(temporal_interp), torch.is_grad_enabled(), *self.wrapper.mlp_tensors())
+                             bool(temporal_interp), torch.is_grad_enabled(),
+                             bool(model_input.get('sorted_by_y', False)),   # optional hint from nvp_amd's own sampler
+                             *self.wrapper.mlp_tensors())
         return {'model_out': out.reshape((b, t, 3))}

@@ -269,6 +269,29 @@ def test_nvp_forward_backward_vs_oracle(F, n):
         assert np.array_equal(got == 0, want == 0) or _relerr(got, want) < 3e-4
 
 
+def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
+    """NVP_COORDS_SORTED_BY_Y only skips a sort: gradients must be bit-identical with and without the
+    hint, and - integer fixed-point accumulation being order independent - across repeated runs."""
+    cfg, sd, model = _nvp_pair(2)
+    gen = torch.Generator().manual_seed(77)
+    n = 20000
+    coords = torch.rand((n, 3), generator=gen)
+    coords = coords[torch.argsort(coords[:, 2])].unsqueeze(0).to(dev())          # ascending y
+    steps = torch.rand((1, n), generator=gen).to(dev())
+    w = torch.randn((1, n, 3), generator=gen).to(dev())
+    grads = []
+    for hint in (False, True, True):
+        mi = {"all_coords": coords, "temporal_steps": steps}
+        if hint:
+            mi["sorted_by_y"] = True
+        model.zero_grad(set_to_none=True)
+        (model(mi)["model_out"] * w).sum().backward()
+        grads.append([p.grad.clone() for p in (model.keyframes_xy.params, model.keyframes_yt.params,
+                                               model.keyframes_xt.params, model.sparse_grid.embeddings)])
+    for a, b, c in zip(*grads):
+        assert torch.equal(a, b) and torch.equal(b, c)
+
+
 def test_nvp_empty_batch():
     cfg, sd, model = _nvp_pair(2)
     out = model({"all_coords": torch.zeros((1, 0, 3), device=dev()), "temporal_steps": torch.zeros((1, 0), device=dev())})
