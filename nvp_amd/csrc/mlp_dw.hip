@@ -44,6 +44,7 @@ struct DwArgs {
     const float* sir0_bp;
     int64_t last_w, last_b, sir0_w, sir0_b;
     int64_t total;        // floats per partial
+    int small_slots;      // KIND 2: records are stored transposed, element e of chunk c at [e * small_slots + c]
 };
 
 // ---- LDS staging ------------------------------------------------------------------------
@@ -269,17 +270,20 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
         }
     } else {
         // d last_w[c][32w + i]: D rows 0..2 live in lane half 0, registers 0..2
+        // transposed small records: element e of this chunk at partials[e * small_slots + chunk]
+        float* rec = partials + chunk;
+        const int64_t st = A.small_slots;
         if (h == 0) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) part[A.last_w + (int64_t)r * NVP_H + 32 * w + i] = acc[0][0][r];
+            for (int r = 0; r < 3; ++r) rec[(A.last_w + (int64_t)r * NVP_H + 32 * w + i) * st] = acc[0][0][r];
         }
         bsum0 += __shfl_xor(bsum0, 32);
         bsum1 += __shfl_xor(bsum1, 32);
         w0sum += __shfl_xor(w0sum, 32);
         if (h == 0) {
-            if (w == 0 && i < 3) part[A.last_b + i] = bsum0;
-            part[A.sir0_w + 32 * w + i] = w0sum;
-            part[A.sir0_b + 32 * w + i] = bsum1;
+            if (w == 0 && i < 3) rec[(A.last_b + i) * st] = bsum0;
+            rec[(A.sir0_w + 32 * w + i) * st] = w0sum;
+            rec[(A.sir0_b + 32 * w + i) * st] = bsum1;
         }
     }
 }
@@ -309,7 +313,9 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
     else if (idx >= R.p_sir0_w && idx < R.p_sir0_w + NVP_H) so = kSmSir0W + (int)(idx - R.p_sir0_w);
     else if (idx >= R.p_sir0_b && idx < R.p_sir0_b + NVP_H) so = kSmSir0B + (int)(idx - R.p_sir0_b);
     if (so >= 0) {
-        for (int c = 0; c < R.small_slots; ++c) s += partials[R.small_base + (int64_t)c * kSmallTotal + so];
+        // one wave-strided pass over the transposed records (contiguous in the slot index)
+        const float* rec = partials + R.small_base + (int64_t)so * R.small_slots;
+        for (int c = 0; c < R.small_slots; ++c) s += rec[c];
     } else {
         for (int c = 0; c < n_chunks; ++c) s += partials[(int64_t)c * total + idx];
     }
@@ -367,6 +373,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     A.drgb = drgb; A.steps = steps; A.sir0_wp = p->sir_w[0]; A.sir0_bp = p->sir_b[0];
     A.last_w = P.last_w; A.last_b = P.last_b; A.sir0_w = P.sir_w[0]; A.sir0_b = P.sir_b[0];
     A.total = P.total;
+    A.small_slots = 0;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
     // three launches: plain jobs (modulator layers), transform jobs (SIREN layers 1-2), the small job
@@ -378,6 +385,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     }
     P0.n_jobs = n0; P1.n_jobs = n1;
     P2.job[0] = A.job[A.n_jobs - 1]; P2.n_jobs = 1;
+    P2.small_slots = n_chunks * kSmallMul;
     P2.total = kSmallTotal; P2.last_w = kSmLastW; P2.last_b = kSmLastB; P2.sir0_w = kSmSir0W; P2.sir0_b = kSmSir0B;
     const int small_chunks = n_chunks * kSmallMul;
     const int small_tiles = (int)((ntiles + small_chunks - 1) / small_chunks);
