@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=262144)
+    ap.add_argument("--config", choices=["s", "l"], default="s",
+                    help="s = BASELINE.json configs[1] (the headline line); l = configs[2] geometry (nvp_l, 300 frames), informational")
     args = ap.parse_args()
 
     from nvp_amd import _lib, functional, harness, parallel
@@ -115,9 +117,26 @@ def main():
     _lib.load()
 
     torch.manual_seed(0)                       # identical parameters on every rank
-    model = NVP(out_features=3, encoding_config=CONFIG_NVP_S).to(dev)
-    parallel.broadcast_parameters(model)
+    cfg = CONFIG_NVP_S
     T, H, W = VIDEO
+    if args.config == "l":                     # config_nvp_l.json differs only in n_features_per_level = 4; ShakeNDry has 300 frames
+        import copy
+        cfg = copy.deepcopy(CONFIG_NVP_S)
+        for k in cfg:
+            if "n_features_per_level" in cfg[k]:
+                cfg[k]["n_features_per_level"] = 4
+        cfg["3d_encoding"]["t_resolution"] = 300
+        T = 300
+        global F, D
+        F, D = 4, 57 * 4
+        for k in FLOP_PX:
+            FLOP_PX[k] = {"nvp_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),
+                          "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 4 * 128 * 128 + 3 * 128),
+                          "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128)}[k]
+        for k in BYTES_PX:
+            BYTES_PX[k] = 12 + (192 + 9) * 4 * F + 4 * D
+    model = NVP(out_features=3, encoding_config=cfg).to(dev)
+    parallel.broadcast_parameters(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     video = torch.randint(0, 256, (T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)   # synthetic u8 RGB, 3.7 GB
     data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank)   # rank-offset sampler seed
@@ -180,7 +199,8 @@ def main():
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s, "
+            "config": {"workload": ("configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s, " if args.config == "s" else
+                                    "configs[2] geometry: 1920x1080x300 synthetic u8 RGB video, config_nvp_l, ") +
                                    f"{N_PX} (t,x,y) samples per GPU per step, random-init parameters",
                        "pixels_per_gpu_step": N_PX, "global_batch_pixels": world * N_PX,
                        "parallelism": f"dp{world}" if world > 1 else "single",
