@@ -13,7 +13,7 @@
 //     max|dz|, which fixes the fixed-point scale;
 //  3. row tables: for every level, the first sorted pixel of each grid row (binary searches);
 //  4. band kernel: a workgroup owns rows [r0, r1) of one level of one plane, keeps them as an
-//     int64 fixed-point table in LDS (<= 144 KB) and visits exactly the sorted pixel range that
+//     int64 fixed-point table in LDS (36 KB by default) and visits exactly the sorted pixel range that
 //     can touch those rows.  Bilinear corner weights x gradient are added with ds_add_u64:
 //     integer addition is exact and order-independent, so the result is bit-reproducible.
 //     Bands with few rows-per-pixel are additionally split over several workgroups
@@ -35,8 +35,17 @@
 
 namespace {
 
-constexpr int kBandThreads = 1024;
-constexpr int kLdsEntries = 18000;            // int64 entries -> 144 000 B of the 160 KB LDS
+#ifndef NVP_BAND_THREADS
+#define NVP_BAND_THREADS 512
+#endif
+#ifndef NVP_BAND_ENTRIES
+#define NVP_BAND_ENTRIES 4500
+#endif
+constexpr int kBandThreads = NVP_BAND_THREADS;
+constexpr int kLdsEntries = NVP_BAND_ENTRIES;   // target int64 entries per table (36 KB: four workgroups per CU overlap their
+                                                // zero / accumulate / flush phases; measured best of 4.5k..18k, tools/ablate_scatter.*);
+                                                // grows to one full grid row when a row is wider (nvp_l: 1443 x 4)
+constexpr int kMaxLdsEntries = 20000;           // 160 KB
 constexpr int kTargetVisits = 16384;          // pixel visits per band workgroup
 constexpr int kMaxSlots = 256;                // dzmax slots
 
@@ -55,9 +64,14 @@ struct Plan {
     int rs_total[3];         // row-start entries per plane
     long long slab_floats;   // total slab floats
     int reduce_items;        // number of (plane, level) pairs with splits > 1
+    int entries;             // int64 entries of the LDS table (>= the widest grid row)
 };
 
 void make_plan(Plan& P, const nvp_levels* lv[3], int64_t n) {
+    P.entries = kLdsEntries;
+    for (int p = 0; p < 3; ++p)
+        for (int l = 0; l < lv[p]->n_levels; ++l)
+            if (lv[p]->res[l] * lv[p]->n_features > P.entries) P.entries = lv[p]->res[l] * lv[p]->n_features;
     int blocks = 0;
     long long slab = 0;
     P.reduce_items = 0;
@@ -67,8 +81,8 @@ void make_plan(Plan& P, const nvp_levels* lv[3], int64_t n) {
         for (int l = 0; l < lv[p]->n_levels; ++l) {
             LevelPlan& L = P.lp[p][l];
             const int res = lv[p]->res[l];
-            int rows = kLdsEntries / (res * F);
-            if (rows < 1) rows = 1;               // (res*F <= 18000 for every supported config)
+            int rows = P.entries / (res * F);
+            if (rows < 1) rows = 1;
             if (rows > res) rows = res;
             L.rows = rows;
             L.bands = (res + rows - 1) / rows;
@@ -363,8 +377,11 @@ __device__ __forceinline__ int nearest_idx(float c, int res) {
     return min(max(i, 0), res - 1);
 }
 
+#ifndef NVP_SPARSE_ENTRIES
+#define NVP_SPARSE_ENTRIES 3000
+#endif
 constexpr int kSparseThreads = 256;
-constexpr int kSparseEntries = 9000;            // int64 entries -> 72 KB: two workgroups per CU
+constexpr int kSparseEntries = NVP_SPARSE_ENTRIES;   // target int64 entries per table (24 KB); grows to one x-row if wider
 
 __global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
                                                           unsigned* __restrict__ keys, unsigned* __restrict__ dzmax, int64_t n, nvp_sparse_shape sh) {
@@ -444,7 +461,7 @@ bool levels_ok(const nvp_levels* lv) {
     const int f = lv->n_features;
     if (!(f == 1 || f == 2 || f == 4 || f == 8)) return false;
     for (int l = 0; l < lv->n_levels; ++l)
-        if (lv->res[l] < 2 || lv->res[l] * f > kLdsEntries) return false;
+        if (lv->res[l] < 2 || lv->res[l] * f > kMaxLdsEntries) return false;
     return true;
 }
 
@@ -507,7 +524,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     int hb = 1;
     while (((int64_t)1 << hb) < n) ++hb;
     BA.headroom_bits = hb + 1;
-    hipLaunchKernelGGL((band_kernel<F>), dim3(P.total_blocks), dim3(kBandThreads), kLdsEntries * 8, s, BA, n);
+    hipLaunchKernelGGL((band_kernel<F>), dim3(P.total_blocks), dim3(kBandThreads), (size_t)P.entries * 8, s, BA, n);
 
     if (P.reduce_items > 0) {
         ReduceArgs R;
@@ -534,11 +551,13 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp2, (const unsigned*)sk_in, sk_out, (const int*)iota, sorder, (size_t)n, 0, end_bit, s);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(sparse_rowstart_kernel, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, s, (const unsigned*)sk_out, srs, nkeys, n);
-        int rows = kSparseEntries / (sh->y_res * sh->n_features);
-        if (rows < 1) return NVP_ERR_UNSUPPORTED;                 // y_res * F > 9000
+        int sentries = kSparseEntries;
+        if (sh->y_res * sh->n_features > sentries) sentries = sh->y_res * sh->n_features;
+        if (sentries > kMaxLdsEntries) return NVP_ERR_UNSUPPORTED;          // one x-row does not fit the LDS
+        int rows = sentries / (sh->y_res * sh->n_features);
         if (rows > sh->x_res) rows = sh->x_res;
         const int bands = (sh->x_res + rows - 1) / rows;
-        hipLaunchKernelGGL(sparse_band_kernel, dim3((unsigned)(sh->t_res * bands)), dim3(kSparseThreads), kSparseEntries * 8, s,
+        hipLaunchKernelGGL(sparse_band_kernel, dim3((unsigned)(sh->t_res * bands)), dim3(kSparseThreads), (size_t)sentries * 8, s,
                            coords, dz, dz_stride, col, (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, BA.headroom_bits + 2);
     }
     return 0;
