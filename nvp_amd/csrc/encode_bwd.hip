@@ -183,10 +183,24 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
         const float* src = dz + (int64_t)id * dz_stride + A.col0[plane];
         float* dst = A.dzs[plane];
         const int nl = A.nlev[plane];
-        for (int l = 0; l < nl; ++l) {
+        // the pixel's row segment of this plane (nl*F <= 16*F floats, 16-B aligned: col0 and dz_stride are
+        // multiples of 4) is fetched with independent 16-B loads first, then streamed out level-major
+        constexpr int NV = 16 * F / 4;
+        float4 seg[NV];
+        const int qmax = (nl * F - 1) >> 2;              // clamp instead of predicating: no branches, no early waits
+#pragma unroll
+        for (int q = 0; q < NV; ++q) seg[q] = reinterpret_cast<const float4*>(src)[min(q, qmax)];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            if (l >= nl) break;
             float v[F];
 #pragma unroll
-            for (int f = 0; f < F; ++f) { v[f] = src[l * F + f]; m = fmaxf(m, fabsf(v[f])); }
+            for (int f = 0; f < F; ++f) {
+                const int e = l * F + f;
+                const float4 t = seg[e >> 2];
+                v[f] = (e & 3) == 0 ? t.x : ((e & 3) == 1 ? t.y : ((e & 3) == 2 ? t.z : t.w));
+                m = fmaxf(m, fabsf(v[f]));
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) dst[((int64_t)l * n + p) * F + f] = v[f];
         }
@@ -609,7 +623,9 @@ int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
     if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
     const int need = lv_xy->n_levels * lv_xy->n_features + lv_yt->n_levels * lv_yt->n_features + lv_xt->n_levels * lv_xt->n_features +
                      9 * sh->n_features;
-    if (dz_stride < need) return NVP_ERR_BADARG;
+    if (dz_stride < need || (dz_stride & 3)) return NVP_ERR_BADARG;
+    if ((lv_xy->n_levels * lv_xy->n_features) & 3 || (lv_yt->n_levels * lv_yt->n_features) & 3 || (lv_xt->n_levels * lv_xt->n_features) & 3)
+        return NVP_ERR_UNSUPPORTED;             // 16-B aligned per-plane row segments (true for every 4-level-multiple config)
     switch (lv_xy->n_features) {
         case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
         case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
