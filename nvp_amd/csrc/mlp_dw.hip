@@ -121,8 +121,11 @@ __device__ __forceinline__ void read_frag(float (&f)[16], const float* __restric
 // KIND 0: the modulator jobs (plain operands); KIND 1: SIREN layers 1-2, whose B operand x_k is rebuilt
 // on the fly; KIND 2: the small job (last layer + SIREN layer 0).  Separate instantiations keep each
 // variant's register budget tight (the union spilled).
+#ifndef NVP_DW_BUFS
+#define NVP_DW_BUFS 2        // LDS tile buffers: 2 = double-buffered (one barrier per tile, 2 workgroups/CU), 1 = single (two barriers, 3-4 workgroups/CU)
+#endif
 template <int KIND>
-__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
+__global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];          // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
     const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
     const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
     float* part = partials + (int64_t)chunk * A.total;
+    constexpr int BUFS = (KIND == 0 && NVP_DW_BUFS == 1) ? 1 : 2;     // only the plain variant fits 3 waves/SIMD
     constexpr bool XF = KIND != 0;
     constexpr bool small = KIND == 2;
     const DwJob J = A.job[job];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
 #else
         if (more) load_stage<XF>(st, J, t + 1, tid);
 #endif
-        const float* la = lds + cur * 2 * kTileFloats;
+        const float* la = lds + (BUFS == 2 ? cur : 0) * 2 * kTileFloats;
         const float* lb = la + kTileFloats;
         if (!small) {
             float fa[16], fb[2][16];
@@ -237,7 +241,12 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs A, float* __restr
                 bsum1 += q[k];
             }
         }
-        if (more) write_stage<XF>(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, J, A, t + 1, n, tid);
+        if (BUFS == 1) {
+            __syncthreads();                        // everyone finished reading the single buffer
+            if (more) write_stage<XF>(lds, lds + kTileFloats, st, J, A, t + 1, n, tid);
+        } else {
+            if (more) write_stage<XF>(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, J, A, t + 1, n, tid);
+        }
 #if NVP_DW_DEPTH == 2
         st = st2;
 #endif
@@ -391,7 +400,8 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     const int small_tiles = (int)((ntiles + small_chunks - 1) / small_chunks);
     float* small_part = partials + (int64_t)n_chunks * P.total;
     const size_t lds_bytes = 2 * 2 * kTileFloats * sizeof(float);
-    hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    const size_t lds_bytes0 = (NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats * sizeof(float);
+    hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_dw_kernel<1>, dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
