@@ -12,24 +12,35 @@ KEYS = {"mlp_fwd_kernel": "nvp_mlp_fwd", "mlp_bwd_dx_kernel": "nvp_mlp_bwd_dx", 
         "mlp_dw_kernel": "nvp_mlp_bwd_dw", "dw_reduce_kernel": "nvp_mlp_bwd_dw", "encode_fwd_kernel": "nvp_encode_fwd",
         "band_kernel": "nvp_encode_bwd", "permute_kernel": "nvp_encode_bwd", "sparse_band_kernel": "nvp_encode_bwd",
         "sparse_keys_kernel": "nvp_encode_bwd", "slab_reduce_kernel": "nvp_encode_bwd", "rowstart_kernel": "nvp_encode_bwd", "keys_kernel": "nvp_encode_bwd"}
+def short(name):
+    """kernel name up to its argument list, keeping template arguments (mlp_dw_kernel<0> != mlp_dw_kernel<1>)"""
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].strip()
+
+
+def stage_of(name):
+    for k, v in KEYS.items():
+        if k in name and ("sparse_" in name) == ("sparse_" in k):
+            return v
+    return None
+
+
 def load(p):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     path = os.path.join(root, "gpurun_out", f"{tag}_{p}", "pmc_counter_collection.csv")
     if not os.path.exists(path): return d
     for r in csv.DictReader(open(path)):
-        for k in KEYS:
-            if k in r["Kernel_Name"] and ("sparse_" in r["Kernel_Name"]) == ("sparse_" in k):
-                d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if stage_of(r["Kernel_Name"]):
+            d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
 out = []
 stage = collections.defaultdict(float)
 fetch, write = load("fetch"), load("write")
-for k in KEYS:
+for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, {}).get("FETCH_SIZE", []); w = write.get(k, {}).get("WRITE_SIZE", [])
-    if not f and not w: continue
     fb = 2 * 1024 * sum(f) / max(len(f), 1); wb = 1024 * sum(w) / max(len(w), 1)
-    stage[KEYS[k]] += fb + wb
-    out.append(f"{k:22s} fetch(x2) {fb/1e9:7.3f} GB  write {wb/1e9:7.3f} GB  per launch")
+    stage[stage_of(k)] += fb + wb            # each distinct kernel runs once per step
+    out.append(f"{k:28s} fetch(x2) {fb/1e9:7.3f} GB  write {wb/1e9:7.3f} GB  per launch")
 for p in ("sq1", "sq2"):
     d = load(p)
     for k in d:
