@@ -47,6 +47,10 @@ class KernelTimer:
 
 TIMER = None      # set to a KernelTimer() to time launches
 
+# Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
+# (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
+GRIDS_READY_HOOK = None
+
 # Optional gradient sink (data parallelism): {param.data_ptr(): preallocated tensor}.  When a
 # parameter has an entry, backward writes its gradient straight into that tensor (a view of the
 # flat all-reduce bucket) and returns it, so no zero-fill / accumulate / flatten pass exists.
@@ -164,7 +168,10 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
 
 
 def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, saved: torch.Tensor,
-                  mlp: Sequence[torch.Tensor], n: int, d: int) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """dX chain (+ latent gradient), then the dW GEMMs.  `between(dz_rows)`, if given, runs after the
+    dX kernels are enqueued and before the dW kernels: the fused NVP path uses it to enqueue the grid
+    scatter (which only needs dz) first, so its gradients can be all-reduced underneath the dW GEMMs."""
     lib = L.load()
     dev = zt.device
     stream = L.stream_ptr()
@@ -177,6 +184,8 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     drgb = _f32c(drgb)
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
                                L.ptr(dy), L.ptr(dz_rows), n, d, stream), "nvp_mlp_bwd_dx")
+    if between is not None:
+        between(dz_rows)
     grads = [_grad_buffer(t) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
@@ -281,17 +290,23 @@ class NVPFused(torch.autograd.Function):
         if n == 0:
             z = [torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb)]
             return (None, None, *z, None, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
-        dz_rows, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d)
         lv = ctx.lv
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
         d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t) for t in (kf_xy, kf_yt, kf_xt, emb))
-        ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
-        if ws_bytes < 0:
-            raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
-        ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
-        L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1],
-                      L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
-                      C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
-                      L.ptr(ws, torch.uint8), ws_bytes, ctx.flags, L.stream_ptr()),
-                "nvp_encode_bwd")
+
+        def scatter(dz_rows):
+            ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
+            if ws_bytes < 0:
+                raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
+            ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
+            L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1],
+                          L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
+                          C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
+                          L.ptr(ws, torch.uint8), ws_bytes, ctx.flags, L.stream_ptr()),
+                    "nvp_encode_bwd")
+            if GRIDS_READY_HOOK is not None:
+                GRIDS_READY_HOOK()            # e.g. start the (async) all-reduce of the grid gradients
+
+        # order: dX chain -> grid scatter (needs only dz) -> dW GEMMs (independent of the scatter)
+        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter)
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, *grads)

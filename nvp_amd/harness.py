@@ -119,12 +119,14 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     if bucket is not None:
         bucket.detach_grads()                       # == zero_grad(set_to_none=True)
         functional.GRAD_SINK = bucket.sink()        # backward writes straight into the flat buffer
+        functional.GRIDS_READY_HOOK = bucket.start_early   # grid grads all-reduce underneath the dW GEMMs
     else:
         opt.zero_grad()
     try:
         loss.backward()
     finally:
         functional.GRAD_SINK = None
+        functional.GRIDS_READY_HOOK = None
     if bucket is not None:
         bucket.all_reduce_mean()                    # copies back only if some grad did not land in the bucket
     opt.step()

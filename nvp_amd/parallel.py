@@ -44,7 +44,10 @@ def unique_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
 class GradBucket:
     """All gradients of a module as views into one flat fp32 buffer + the per-step all-reduce."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], early: Optional[Iterable[torch.nn.Parameter]] = None):
+        """`early`: parameters whose gradients are complete before the rest of backward has run (NVP's four
+        grids: 99.9 % of the bytes).  If they occupy one contiguous range of the flat buffer, their all-reduce
+        can be started early and asynchronously (`start_early`) and overlaps the remaining backward kernels."""
         self.params = list(params)
         if not self.params:
             raise ValueError("no parameters")
@@ -60,6 +63,28 @@ class GradBucket:
             self.views.append(v)
             off += p.numel()
         self.attach()
+        self._early_range = None
+        self._early_work = None
+        if early is not None:
+            ids = {id(p) for p in early}
+            offs, o = [], 0
+            for p in self.params:
+                if id(p) in ids:
+                    offs.append((o, o + p.numel()))
+                o += p.numel()
+            if offs and len(offs) == len(ids):
+                lo, hi = min(a for a, _ in offs), max(b for _, b in offs)
+                if sum(b - a for a, b in offs) == hi - lo:            # contiguous: nothing else in between
+                    self._early_range = (lo, hi)
+
+    def start_early(self) -> None:
+        """Asynchronous all-reduce of the early range (call once its gradients are enqueued on the current
+        stream; torch.distributed orders the collective after that work).  No-op without a process group."""
+        if self._early_range is None or self._early_work is not None:
+            return
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            lo, hi = self._early_range
+            self._early_work = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
 
     def attach(self) -> None:
         """(Re)bind .grad to the bucket views (after zero_grad(set_to_none=True) or a rebuild)."""
@@ -86,7 +111,12 @@ class GradBucket:
     def all_reduce_mean(self) -> None:
         """One collective over the whole gradient; no-op for a single process."""
         if not self.consistent():
-            # a grad tensor was replaced (e.g. zero_grad(set_to_none=True)): copy back into the bucket
+            # a grad tensor was replaced (e.g. zero_grad(set_to_none=True)): copy back into the bucket.
+            # An early all-reduce that already ran on stale bucket memory is joined and discarded: the
+            # copy below restores the local gradients and the full all-reduce redoes the sum.
+            if self._early_work is not None:
+                self._early_work.wait()
+                self._early_work = None
             for p, v in zip(self.params, self.views):
                 if p.grad is None:
                     v.zero_()
@@ -94,7 +124,17 @@ class GradBucket:
                     v.copy_(p.grad)
             self.attach()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self._early_work is not None:
+                # the big range is already in flight (overlapping the dW GEMMs): reduce the rest, then join
+                lo, hi = self._early_range
+                if lo > 0:
+                    dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM)
+                if hi < self.numel:
+                    dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM)
+                self._early_work.wait()
+                self._early_work = None
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)       # one collective over the whole gradient
             self.flat.mul_(1.0 / dist.get_world_size())
 
 

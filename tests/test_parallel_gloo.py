@@ -64,6 +64,30 @@ def _worker(rank, world, port, q):
     want = sum(10 * (k + 1) for k in range(world)) / world
     assert bucket.consistent() and torch.allclose(bucket.flat, torch.full_like(bucket.flat, want))
 
+    # early (asynchronous) all-reduce of the grid range + the remainder afterwards == one full all-reduce
+    early = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings]
+    b2 = parallel.GradBucket(params, early=early)
+    assert b2._early_range == (0, sum(p.numel() for p in early))        # the grids are the first, contiguous params
+    for k, p in enumerate(params):
+        p.grad.fill_(float((rank + 1) * (k + 1)))
+    b2.start_early()                         # grids in flight ...
+    b2.start_early()                         # (idempotent)
+    b2.all_reduce_mean()                     # ... MLP range reduced, early work joined, everything scaled
+    for k, p in enumerate(params):
+        want_k = sum((r + 1) * (k + 1) for r in range(world)) / world
+        assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), k
+    # early range reduced on stale memory (grads replaced afterwards) must still give the right answer
+    for p in params:
+        p.grad.zero_()
+    b2.start_early()
+    for k, p in enumerate(params):
+        p.grad = torch.full_like(p, float((rank + 1) * (k + 2)))
+    b2.all_reduce_mean()
+    for k, p in enumerate(params):
+        want_k = sum((r + 1) * (k + 2) for r in range(world)) / world
+        assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), k
+    bucket.attach()
+
     # identical AdamW steps from identical averaged grads keep the replicas bit-identical
     opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=1e-3)
     opt.step()
