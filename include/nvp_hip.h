@@ -179,6 +179,21 @@ int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi
                       float* coords, float* steps, uint8_t* gt_u8,
                       int64_t n, int32_t t_frames, int32_t height, int32_t width, void* stream);
 
+/* ---- dense AdamW (reference training.py:13-14 `torch.optim.AdamW(lr=1e-2,
+ * weight_decay=1e-3)`, stepped at training.py:75) over a list of fp32 tensors in one launch.
+ * torch.optim.AdamW's update rule (decoupled decay, no amsgrad), `step` = 1-based iteration
+ * count (bias corrections 1-beta^step), grad_scale multiplies the gradient first (1/world
+ * after a SUM all-reduce; pass 1.0 otherwise).  Updates param, exp_avg, exp_avg_sq in place. */
+typedef struct nvp_adamw_seg {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+} nvp_adamw_seg;
+int nvp_adamw_step(const nvp_adamw_seg* segs, int32_t n_segs, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int64_t step, double grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,11 @@ class MlpParams(C.Structure):
 
 MlpGrads = MlpParams  # identical layout (const-ness only differs in C)
 
+
+class AdamwSeg(C.Structure):
+    """struct nvp_adamw_seg - one tensor of an AdamW step."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64)]
+
 _p, _i64, _i32, _vp = C.c_void_p, C.c_int64, C.c_int32, C.c_void_p
 
 # name -> argtypes; every entry point returns int unless listed in _RESTYPES
@@ -71,6 +76,7 @@ SIGNATURES = {
     "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
     "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
+    "nvp_adamw_step": [C.POINTER(AdamwSeg), _i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _vp],
     "nvp_packed_fwd_floats": [_i32],
     "nvp_packed_bwd_floats": [_i32],
     "nvp_dw_partial_floats": [_i32, _i32],

@@ -20,6 +20,13 @@
 // written: the dW kernel rebuilds x_k = sin(q_k) h_k from the forward pass's saved streams.
 #include "mlp_chain.h"
 
+#ifndef NVP_BWD_STORES
+#define NVP_BWD_STORES 0     // where the dq/dp stream stores of a layer are issued: 0 per 32-row block inside the element-wise
+#endif                       // stage; 1 one burst after it; 2 one burst behind preloaded weights; 3 two bursts (one per chain)
+#ifndef NVP_BWD_PRE
+#define NVP_BWD_PRE 8
+#endif
+
 namespace {
 
 constexpr int kWaves = 4;
@@ -99,24 +106,77 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
             }
             nvp_pin(dx[T]);
             nvp_pin(dh[T]);
+#if NVP_BWD_STORES == 0
             store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
             store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
+#endif
             NVP_LOAD_FENCE();
             if (T < 3) { hv = hn; qv = qn; }
         }
-        // dx_{k-1} = V_k^T dq_k
+        const float4* w1 = wp + L.off[2 - k] / 4;                  // streams 0 (sir2^T), 1 (sir1^T)
+        const float4* w2 = wp + L.off[4 - k] / 4;                  // streams 2 (mod2h^T), 3 (mod1h^T)
         f32x16 acc[4];
+#if NVP_BWD_STORES <= 1
+#if NVP_BWD_STORES == 1
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
+            store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
+        }
+        NVP_LOAD_FENCE();
+#endif
+        // dx_{k-1} = V_k^T dq_k
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h<2>(acc, dx, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
+        chain_h<2>(acc, dx, w1, lane);
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
         // dh_{k-1} = W_k[:, :128]^T dp_k
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h<2>(acc, dh, wp + L.off[4 - k] / 4, lane);          // streams 2 (mod2h^T), 3 (mod1h^T)
+        chain_h<2>(acc, dh, w2, lane);
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
+#else
+        // The dq / dp registers stay live through the chains, so their stream stores can be issued as ONE
+        // burst right after the first weights of the following chain have been requested (see chain_h_pre).
+        {
+            float4 pre[NVP_BWD_PRE];
+            chain_preload(pre, w1, lane);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
+#if NVP_BWD_STORES == 2
+#pragma unroll
+            for (int T = 0; T < 4; ++T) store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
+#endif
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            chain_h_pre<2, NVP_BWD_PRE>(acc, dx, w1, lane, pre);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+        }
+        {
+#if NVP_BWD_STORES == 3
+            float4 pre[NVP_BWD_PRE];
+            chain_preload(pre, w2, lane);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            chain_h_pre<2, NVP_BWD_PRE>(acc, dh, w2, lane, pre);
+#else
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            chain_h<2>(acc, dh, w2, lane);
+#endif
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
+        }
+#endif
     }
 
     // ---- layer 0: q0 = 30 (w s + c) is recomputed

@@ -312,25 +312,50 @@ struct ReduceArgs {
     int64_t p_last_w, p_last_b, p_sir0_w, p_sir0_b;
 };
 
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partials, ReduceArgs R, int n_chunks, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    float s = 0.f;
-    int so = -1;               // offset inside a small-job record, or -1
-    if (idx >= R.p_last_w && idx < R.p_last_w + 3 * NVP_H) so = kSmLastW + (int)(idx - R.p_last_w);
-    else if (idx >= R.p_last_b && idx < R.p_last_b + 3) so = kSmLastB + (int)(idx - R.p_last_b);
-    else if (idx >= R.p_sir0_w && idx < R.p_sir0_w + NVP_H) so = kSmSir0W + (int)(idx - R.p_sir0_w);
-    else if (idx >= R.p_sir0_b && idx < R.p_sir0_b + NVP_H) so = kSmSir0B + (int)(idx - R.p_sir0_b);
-    if (so >= 0) {
-        // one wave-strided pass over the transposed records (contiguous in the slot index)
-        const float* rec = partials + R.small_base + (int64_t)so * R.small_slots;
-        for (int c = 0; c < R.small_slots; ++c) s += rec[c];
-    } else {
-        for (int c = 0; c < n_chunks; ++c) s += partials[(int64_t)c * total + idx];
-    }
+__device__ __forceinline__ void dw_reduce_store(const ReduceArgs& R, int64_t idx, float s) {
     int t = 0;
     while (idx >= R.off[t + 1]) ++t;
     R.dst[t][idx - R.off[t]] = s;
+}
+
+// Regular gradients: element idx of every chunk's partial, summed in chunk order (fixed order -> deterministic).
+// 16 independent loads are kept in flight per thread; the additions stay sequential.
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partials, ReduceArgs R, int n_chunks, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    if ((idx >= R.p_last_w && idx < R.p_last_w + 3 * NVP_H) || (idx >= R.p_last_b && idx < R.p_last_b + 3) ||
+        (idx >= R.p_sir0_w && idx < R.p_sir0_w + NVP_H) || (idx >= R.p_sir0_b && idx < R.p_sir0_b + NVP_H)) return;   // dw_reduce_small_kernel
+    const float* src = partials + idx;
+    float s = 0.f;
+    int c = 0;
+    for (; c + 16 <= n_chunks; c += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(c + u) * total];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; c < n_chunks; ++c) s += src[(int64_t)c * total];
+    dw_reduce_store(R, idx, s);
+}
+
+// Small-job gradients: one wavefront per value; its transposed record (small_slots contiguous floats) is
+// summed lane-strided and combined with a fixed butterfly -> deterministic.
+__global__ __launch_bounds__(256) void dw_reduce_small_kernel(const float* __restrict__ partials, ReduceArgs R) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= kSmallTotal || e == kSmLastB + 3) return;        // the pad slot
+    int64_t idx;
+    if (e < kSmLastB) idx = R.p_last_w + e;
+    else if (e < kSmSir0W) idx = R.p_last_b + (e - kSmLastB);
+    else if (e < kSmSir0B) idx = R.p_sir0_w + (e - kSmSir0W);
+    else idx = R.p_sir0_b + (e - kSmSir0B);
+    const float* rec = partials + R.small_base + (int64_t)e * R.small_slots;
+    float s = 0.f;
+    for (int c = lane; c < R.small_slots; c += 64) s += rec[c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) dw_reduce_store(R, idx, s);
 }
 
 }  // namespace
@@ -418,6 +443,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     R.small_base = (int64_t)n_chunks * P.total; R.small_slots = small_chunks;
     R.p_last_w = P.last_w; R.p_last_b = P.last_b; R.p_sir0_w = P.sir_w[0]; R.p_sir0_b = P.sir_b[0];
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, R, n_chunks, P.total);
+    hipLaunchKernelGGL(dw_reduce_small_kernel, dim3((kSmallTotal + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, R);
     NVP_LAUNCH_CHECK();
     return 0;
 }

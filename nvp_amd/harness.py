@@ -100,20 +100,24 @@ class DeviceVideo:
 
 def make_optimizer(model: torch.nn.Module, total_steps: int, lr: float = 1e-2):
     """AdamW(lr, weight_decay=1e-3) + CosineAnnealingLR(T_max=steps, eta_min=1e-5): training.py:13-14."""
-    # same update rule as the reference's torch.optim.AdamW; on a HIP device the single-pass
-    # "fused" implementation is used instead of the multi-pass foreach one (K13: 3.8 GB/step)
+    # same update rule as the reference's torch.optim.AdamW.  On a HIP device the whole step is one launch of
+    # nvp_adamw_step (K13: 3.8 GB/step, one pass); CPU modules (host-logic tests only) get torch's own AdamW.
     params = list(model.parameters())
-    fused = bool(params) and all(p.is_cuda for p in params)
-    opt = torch.optim.AdamW(lr=lr, params=params, weight_decay=0.001, fused=fused)
+    if params and all(p.is_cuda for p in params):
+        from .optim import AdamW
+        opt = AdamW(params, lr=lr, weight_decay=0.001)
+    else:
+        opt = torch.optim.AdamW(lr=lr, params=params, weight_decay=0.001)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=total_steps, eta_min=1e-5)
     return opt, sched
 
 
 def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     """One iteration in the reference's order (training.py:50-76). Returns the (device) loss.
-    `bucket` (parallel.GradBucket) turns on data parallelism: gradients live in one flat
-    buffer that is zeroed here and all-reduced once between backward and the optimizer."""
+    `bucket` (parallel.GradBucket) turns on data parallelism: backward writes the gradients into one flat
+    buffer, which is all-reduced once (grid range early and asynchronously) before the optimizer."""
     from . import functional
+    from .optim import AdamW
     out = model(model_input)["model_out"]
     loss = image_mse_u8(out, gt["img"])
     if bucket is not None:
@@ -127,9 +131,13 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     finally:
         functional.GRAD_SINK = None
         functional.GRIDS_READY_HOOK = None
-    if bucket is not None:
-        bucket.all_reduce_mean()                    # copies back only if some grad did not land in the bucket
-    opt.step()
+    if bucket is not None and isinstance(opt, AdamW):
+        bucket.all_reduce(scale=False)              # SUM only; the 1/world factor is applied inside the AdamW kernel
+        opt.step(grad_scale=1.0 / bucket.world_size())
+    else:
+        if bucket is not None:
+            bucket.all_reduce_mean()                # copies back only if some grad did not land in the bucket
+        opt.step()
     sched.step()
     return loss.detach()
 

@@ -1,0 +1,55 @@
+"""AdamW on the HIP path: the reference's `torch.optim.AdamW(lr=lr, params=model.parameters(),
+weight_decay=0.001)` (training.py:13) with the whole step - every parameter tensor - in ONE kernel launch
+(`nvp_adamw_step`, nvp_amd/csrc/optim.hip) instead of torch's multi-tensor chunks.
+
+It is a regular `torch.optim.Optimizer`: `param_groups[i]['lr']` is what `CosineAnnealingLR` drives
+(training.py:14), `state[p]` holds `step`, `exp_avg`, `exp_avg_sq` under torch's names, `zero_grad()` works.
+Same update rule as torch.optim.AdamW (decoupled weight decay, bias-corrected, no amsgrad/maximize).
+There is no CPU path: parameters must live on a HIP device.
+"""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+
+from . import _lib
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        """One AdamW update.  `grad_scale` multiplies every gradient inside the kernel (data parallel: 1/world
+        after a SUM all-reduce of the flat gradient, which saves a separate scaling pass over 543 MB)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("nvp_amd.optim.AdamW does not support sparse gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                seg = _lib.AdamwSeg(_lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel())
+                by_step.setdefault(int(st["step"]), []).append(seg)
+            b1, b2 = group["betas"]
+            for step, segs in by_step.items():
+                arr = (_lib.AdamwSeg * len(segs))(*segs)
+                _lib.check(lib.nvp_adamw_step(arr, len(segs), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                              float(group["weight_decay"]), step, float(grad_scale), _lib.stream_ptr()),
+                           "nvp_adamw_step")
+        return loss

@@ -108,8 +108,17 @@ class GradBucket:
     def consistent(self) -> bool:
         return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(self.params, self.views))
 
+    @staticmethod
+    def world_size() -> int:
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
     def all_reduce_mean(self) -> None:
-        """One collective over the whole gradient; no-op for a single process."""
+        """One collective over the whole gradient, then 1/world; no-op for a single process."""
+        self.all_reduce(scale=True)
+
+    def all_reduce(self, scale: bool = True) -> None:
+        """SUM all-reduce of the flat gradient.  scale=False leaves the sum (the caller folds 1/world into
+        the optimizer kernel: nvp_amd.optim.AdamW.step(grad_scale=...))."""
         if not self.consistent():
             # a grad tensor was replaced (e.g. zero_grad(set_to_none=True)): copy back into the bucket.
             # An early all-reduce that already ran on stale bucket memory is joined and discarded: the
@@ -135,7 +144,8 @@ class GradBucket:
                 self._early_work = None
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)       # one collective over the whole gradient
-            self.flat.mul_(1.0 / dist.get_world_size())
+            if scale:
+                self.flat.mul_(1.0 / dist.get_world_size())
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

@@ -430,3 +430,47 @@ def test_psnr_at_equal_steps_matches_oracle():
             mse = float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())
             ps.append(10 * math.log10(1 / mse))
     assert abs(psnr_eval_g - sum(ps) / len(ps)) <= 0.02
+
+
+@pytest.mark.gpu
+def test_adamw_kernel_matches_torch_adamw():
+    """nvp_adamw_step against the reference's optimizer, torch.optim.AdamW (training.py:13),
+    run on the CPU as the checker: odd sizes, a 4-byte-aligned (not 16-byte) view, tiny gradients (eps
+    regime), a cosine schedule, and the data-parallel grad_scale."""
+    from nvp_amd.optim import AdamW
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    sizes = [(1000,), (7,), (33, 5), (4099,), (128, 114), (3,)]
+    flat = torch.randn(sum(int(np.prod(s)) for s in sizes) + 1)
+    cpu, gpu, off = [], [], 1                                   # offset 1 float: views are not 16-B aligned
+    gflat = flat.to(dev)
+    for s in sizes:
+        n = int(np.prod(s))
+        cpu.append(torch.nn.Parameter(flat[off:off + n].clone().view(s)))
+        gpu.append(torch.nn.Parameter(gflat[off:off + n].view(s)))     # views into one buffer, like GradBucket
+        off += n
+    gpu.append(torch.nn.Parameter(torch.randn(5000, device=dev)))       # an aligned tensor with a ragged tail
+    cpu.append(torch.nn.Parameter(gpu[-1].detach().cpu().clone()))
+    ref = torch.optim.AdamW(cpu, lr=1e-2, weight_decay=1e-3, foreach=False)
+    opt = AdamW(gpu, lr=1e-2, weight_decay=1e-3)
+    s_ref = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=6, eta_min=1e-5)
+    s_opt = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=6, eta_min=1e-5)
+    for it in range(6):
+        scale = 0.5 if it >= 3 else 1.0
+        for pc, pg in zip(cpu, gpu):
+            g = torch.randn(pc.shape) * (10.0 ** float(torch.randint(-9, 1, (1,))))
+            pc.grad = g * scale
+            pg.grad = g.to(dev)
+        ref.step(); s_ref.step()
+        opt.step(grad_scale=scale); s_opt.step()
+        for pc, pg in zip(cpu, gpu):
+            for a, b in ((pc.detach(), pg.detach()), (ref.state[pc]["exp_avg"], opt.state[pg]["exp_avg"]),
+                         (ref.state[pc]["exp_avg_sq"], opt.state[pg]["exp_avg_sq"])):
+                # rtol for the bulk; atol scaled to the tensor covers cancellation in m + (g - m)(1 - b1), where
+                # torch's CPU lerp and the kernel may round the two halves differently
+                torch.testing.assert_close(b.cpu(), a, rtol=3e-6, atol=2e-7 * float(a.abs().max()))
+        assert abs(ref.param_groups[0]["lr"] - opt.param_groups[0]["lr"]) < 1e-15
+    with pytest.raises(RuntimeError):                              # no CPU path
+        bad = AdamW([torch.nn.Parameter(torch.zeros(4))], lr=1e-2)
+        bad.param_groups[0]["params"][0].grad = torch.zeros(4)
+        bad.step()
