@@ -149,8 +149,10 @@ int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, co
 
 /* ---- R12: autograd of R8-R10 (reference training.py:74).
  * bwd_dx: drgb [N,3] -> dz_rows (latent gradient, ROW-MAJOR [ntiles*32][nvp_dz_stride(D)])
- *         + the six PTM4 [ntiles][128][32] streams the weight-gradient GEMMs consume:
- *         dy = {dp0,dp1,dp2 (modulator pre-activation grads), dq0s (= 30*dq0), dq1, dq2}.
+ *         + `dy`, six slots of [ntiles][128][32] floats: slots 0,1,2,4,5 are the PTM4 streams
+ *         dp0,dp1,dp2 (modulator pre-activation grads), dq1, dq2 the weight-gradient GEMMs
+ *         consume; slot 3 holds, per 32-pixel tile, a 644-float record of the last layer's and
+ *         SIREN layer 0's gradients already summed over the tile (layout kRec* in mlp_layout.h).
  *         (The modulated sine outputs x_k are NOT written: bwd_dw rebuilds x_k = sin(q_k) h_k
  *         from `saved`, which removes 1.5 KB/px of HBM writes from a write-bound kernel.)
  * bwd_dw: all 14 parameter gradients = split-K GEMMs over the pixel axis into

@@ -1,6 +1,7 @@
 // Backward of the modulator MLP + modulated SIREN w.r.t. activations (the "dX chain" of
-// R12): from dL/drgb produce the latent gradient and the nine per-pixel streams the
-// weight-gradient GEMMs (mlp_dw.hip) contract over the pixel axis.
+// R12): from dL/drgb produce the latent gradient, the five per-pixel dY streams the
+// weight-gradient GEMMs (mlp_dw.hip) contract over the pixel axis, and - already reduced over
+// the tile's 32 pixels - the gradients of the two tiny layers (last layer, SIREN layer 0).
 //
 // Same structure as mlp_fwd.hip: one wavefront = one 32-pixel tile, every transposed GEMM
 //   dX[in][pixel] = sum_out W[out][in] * dY[out][pixel]
@@ -19,13 +20,6 @@
 // dY streams are 3 KB/px out on top of 2.5 KB/px in.  The modulated sine outputs x_k are therefore NOT
 // written: the dW kernel rebuilds x_k = sin(q_k) h_k from the forward pass's saved streams.
 #include "mlp_chain.h"
-
-#ifndef NVP_BWD_STORES
-#define NVP_BWD_STORES 0     // where the dq/dp stream stores of a layer are issued: 0 per 32-row block inside the element-wise
-#endif                       // stage; 1 one burst after it; 2 one burst behind preloaded weights; 3 two bursts (one per chain)
-#ifndef NVP_BWD_PRE
-#define NVP_BWD_PRE 8
-#endif
 
 namespace {
 
@@ -53,15 +47,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
     const int64_t tb = tile * (int64_t)NVP_H * 32;
     const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
-    float* dyt = dy + tb;                  // dp0,dp1,dp2,dq0s,dq1,dq2
+    float* dyt = dy + tb;                  // dp0,dp1,dp2,(records),dq1,dq2
     const float4* wp = reinterpret_cast<const float4*>(packed);
 
+    // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
+    // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
+    extern __shared__ __attribute__((aligned(16))) float xl_all[];
+    float* xl = xl_all + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kRecTileFloats;
+    float* rec = dy + 3 * act + tile * (int64_t)NVP_H * 32;      // this tile's record (stream-3 slot)
+
     f32x16 dx[4], dh[4];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (valid) { g0 = drgb[px * 3 + 0]; g1 = drgb[px * 3 + 1]; g2 = drgb[px * 3 + 2]; }
 
     // ---- last layer: dx2 = V3^T drgb (VALU, 3 terms)
     {
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if (valid) { g0 = drgb[px * 3 + 0]; g1 = drgb[px * 3 + 1]; g2 = drgb[px * 3 + 2]; }
         const float* w3 = p.last_w;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
@@ -103,80 +103,54 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
                 dx[T][r] = dxv * hv[r] * cs;                      // dq
                 const float dhv = dh[T][r] + dxv * sn;
                 dh[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;       // dp
+                if (k == 2) xl[(32 * T + nvp_frag_row(r, h)) * kRecRowStride + j] = sn * hv[r];     // x2 = sin(q2) h2
             }
             nvp_pin(dx[T]);
             nvp_pin(dh[T]);
-#if NVP_BWD_STORES == 0
             store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
             store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
-#endif
             NVP_LOAD_FENCE();
             if (T < 3) { hv = hn; qv = qn; }
         }
-        const float4* w1 = wp + L.off[2 - k] / 4;                  // streams 0 (sir2^T), 1 (sir1^T)
-        const float4* w2 = wp + L.off[4 - k] / 4;                  // streams 2 (mod2h^T), 3 (mod1h^T)
-        f32x16 acc[4];
-#if NVP_BWD_STORES <= 1
-#if NVP_BWD_STORES == 1
+        if (k == 2) {
+            // d last_w[c][f] = sum_px drgb[c][px] x2[f][px],  d last_b[c] = sum_px drgb[c][px]      (modulation.py:92)
+            // lane l owns features l and l + 64; pixel px's drgb sits in lane px (readlane -> SGPR broadcast)
+            NVP_LOAD_FENCE();
+            float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            const float* r0 = xl + lane * kRecRowStride;
+            const float* r1 = xl + (lane + 64) * kRecRowStride;
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
-            store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
+            for (int q = 0; q < 32; ++q) {
+                const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0), q));
+                const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1), q));
+                const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2), q));
+                const float x0 = r0[q], x1 = r1[q];
+                a[0][0] = __fmaf_rn(c0, x0, a[0][0]); a[0][1] = __fmaf_rn(c1, x0, a[0][1]); a[0][2] = __fmaf_rn(c2, x0, a[0][2]);
+                a[1][0] = __fmaf_rn(c0, x1, a[1][0]); a[1][1] = __fmaf_rn(c1, x1, a[1][1]); a[1][2] = __fmaf_rn(c2, x1, a[1][2]);
+                b0 += c0; b1 += c1; b2 += c2;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rec[kRecLastW + c * NVP_H + lane] = a[0][c];
+                rec[kRecLastW + c * NVP_H + 64 + lane] = a[1][c];
+            }
+            if (lane < 3) rec[kRecLastB + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : b2);
+            NVP_LOAD_FENCE();
         }
-        NVP_LOAD_FENCE();
-#endif
         // dx_{k-1} = V_k^T dq_k
+        f32x16 acc[4];
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h<2>(acc, dx, w1, lane);
+        chain_h<2>(acc, dx, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
         // dh_{k-1} = W_k[:, :128]^T dp_k
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h<2>(acc, dh, w2, lane);
+        chain_h<2>(acc, dh, wp + L.off[4 - k] / 4, lane);          // streams 2 (mod2h^T), 3 (mod1h^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
-#else
-        // The dq / dp registers stay live through the chains, so their stream stores can be issued as ONE
-        // burst right after the first weights of the following chain have been requested (see chain_h_pre).
-        {
-            float4 pre[NVP_BWD_PRE];
-            chain_preload(pre, w1, lane);
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
-#if NVP_BWD_STORES == 2
-#pragma unroll
-            for (int T = 0; T < 4; ++T) store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
-#endif
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            chain_h_pre<2, NVP_BWD_PRE>(acc, dx, w1, lane, pre);
-#pragma unroll
-            for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
-        }
-        {
-#if NVP_BWD_STORES == 3
-            float4 pre[NVP_BWD_PRE];
-            chain_preload(pre, w2, lane);
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            chain_h_pre<2, NVP_BWD_PRE>(acc, dh, w2, lane, pre);
-#else
-#pragma unroll
-            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            chain_h<2>(acc, dh, w2, lane);
-#endif
-#pragma unroll
-            for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
-        }
-#endif
     }
 
     // ---- layer 0: q0 = 30 (w s + c) is recomputed
@@ -203,11 +177,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
                 const float dhv = dh[T][r] + dxv * sn;
                 dp0[r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
             }
-            store_ptm16(dyt + 3 * act, dq0, T, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xl[(32 * T + nvp_frag_row(r, h)) * kRecRowStride + j] = dq0[r];
             store_ptm16(dyt, dp0, T, lane);
             NVP_LOAD_FENCE();
             if (T < 3) hv = hn;
         }
+        // d sir_w0[f] = sum_px dq0[f][px] s[px],  d sir_b0[f] = sum_px dq0[f][px]        (modulation.py:53-56)
+        float wl = 0.f, wh = 0.f, cl = 0.f, ch = 0.f;
+        const float* r0 = xl + lane * kRecRowStride;
+        const float* r1 = xl + (lane + 64) * kRecRowStride;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float sp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), q));
+            const float d0 = r0[q], d1 = r1[q];
+            wl = __fmaf_rn(d0, sp, wl); wh = __fmaf_rn(d1, sp, wh);
+            cl += d0; ch += d1;
+        }
+        rec[kRecSir0W + lane] = wl; rec[kRecSir0W + 64 + lane] = wh;
+        rec[kRecSir0B + lane] = cl; rec[kRecSir0B + 64 + lane] = ch;
     }
 }
 
@@ -278,7 +266,7 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     if (zt != 4 && zt != 8) return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, n, ntiles, d);
+    hipLaunchKernelGGL(mlp_bwd_dx_kernel, grid, dim3(kWaves * 64), kWaves * kRecTileFloats * sizeof(float), (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, n, ntiles, d);
     if (zt == 4)
         hipLaunchKernelGGL(mlp_bwd_dz_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
     else

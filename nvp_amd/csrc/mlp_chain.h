@@ -79,42 +79,6 @@ __device__ __forceinline__ void chain_h(f32x16 (&acc)[4], const f32x16 (&hin)[4]
     }
 }
 
-// chain_h whose first PRE k-steps use weights the caller loaded EARLIER (before a burst of stream stores):
-// vmcnt retires in order, so a wait for a load issued after a store also waits for that store's write
-// acknowledgement; the preloaded steps give the burst time to drain before the first such wait.
-template <int GG, int PRE>
-__device__ __forceinline__ void chain_h_pre(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float4* __restrict__ wp, int lane,
-                                            const float4 (&pre)[PRE]) {
-    static_assert((64 - PRE) % GG == 0, "PRE must leave whole groups");
-    constexpr int NG = (64 - PRE) / GG;
-    float4 a[2][GG];
-    const unsigned ul = (unsigned)lane;
-#pragma unroll
-    for (int i = 0; i < GG; ++i) a[0][i] = NVP_WLOAD((wp + (PRE + i) * 64)[ul]);
-    NVP_CHAIN_FENCE();
-#pragma unroll
-    for (int i = 0; i < PRE; ++i) mfma4(acc, pre[i], hin[i >> 4][i & 15]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
-#pragma unroll
-            for (int i = 0; i < GG; ++i) a[(g + 1) & 1][i] = NVP_WLOAD((wp + (PRE + (g + 1) * GG + i) * 64)[ul]);
-        }
-        NVP_CHAIN_FENCE();
-#pragma unroll
-        for (int i = 0; i < GG; ++i) {
-            const int step = PRE + g * GG + i;
-            mfma4(acc, a[g & 1][i], hin[step >> 4][step & 15]);
-        }
-    }
-}
-
-template <int PRE>
-__device__ __forceinline__ void chain_preload(float4 (&pre)[PRE], const float4* __restrict__ wp, int lane) {
-#pragma unroll
-    for (int i = 0; i < PRE; ++i) pre[i] = NVP_WLOAD((wp + i * 64)[(unsigned)lane]);
-}
-
 // Stage this wave's latent tile (PTM4, contiguous n4 float4) into its private LDS region with
 // coalesced 16-B loads.  Only the owning wave reads it back, so a wave barrier suffices.
 __device__ __forceinline__ void stage_z(float4* __restrict__ zl, const float4* __restrict__ z4, int n4, int lane) {

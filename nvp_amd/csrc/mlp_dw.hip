@@ -17,7 +17,11 @@
 //    (a D fragment row is 32 consecutive `in` columns = one 128-B line), then summed over
 //    chunks by a second kernel in a fixed order -> deterministic gradients.
 //
-// Bound: fp32 MFMA (219 648 FLOP/px for nvp_s) with ~7 KB/px of HBM reads riding along.
+//  * the two tiny layers (last layer 3 x 128, SIREN layer 0: 643 values) are not GEMM jobs: the backward
+//    chain kernel already reduced them over each tile's 32 pixels (mlp_bwd.hip, kRec* records); here
+//    the records are summed per pixel chunk into the same partials.
+//
+// Bound: fp32 MFMA (219 648 FLOP/px for nvp_s) with ~6 KB/px of HBM reads riding along.
 #include "mlp_layout.h"
 
 namespace {
@@ -25,7 +29,7 @@ namespace {
 struct DwJob {
     const float* a;       // dY stream (PTM4, 128 rows)
     const float* b;       // X stream (PTM4, b_rows rows): z, h_k, or the h factor of x_k = sin(q_k) h_k
-    const float* b2;      // mode 1: the q_k stream; otherwise == b (loaded but unused: L1 hit)
+    const float* b2;      // mode 1: the q_k stream; otherwise == b
     int mode;             // 0: B = b;  1: B = sin(b2) * b;  2: B = sin(30 (w0[row] s[px] + c0[row])) * b
     int b_rows;           // rows per tile in the B stream (its PTM stride)
     int b_row0;           // first B row of this job's 4 column tiles
@@ -37,14 +41,11 @@ struct DwJob {
 
 struct DwArgs {
     DwJob job[12];
-    int n_jobs;           // the last job is the "small" one (last layer + SIREN layer 0)
-    const float* drgb;
+    int n_jobs;
     const float* steps;
     const float* sir0_wp;   // SIREN layer 0 weight / bias (mode 2)
     const float* sir0_bp;
-    int64_t last_w, last_b, sir0_w, sir0_b;
     int64_t total;        // floats per partial
-    int small_slots;      // KIND 2: records are stored transposed, element e of chunk c at [e * small_slots + c]
 };
 
 // ---- LDS staging ------------------------------------------------------------------------
@@ -119,8 +120,7 @@ __device__ __forceinline__ void read_frag(float (&f)[16], const float* __restric
 }
 
 // KIND 0: the modulator jobs (plain operands); KIND 1: SIREN layers 1-2, whose B operand x_k is rebuilt
-// on the fly; KIND 2: the small job (last layer + SIREN layer 0).  Separate instantiations keep each
-// variant's register budget tight (the union spilled).
+// on the fly.  Separate instantiations keep each variant's register budget tight (the union spilled).
 #ifndef NVP_DW_BUFS
 #define NVP_DW_BUFS 2        // LDS tile buffers: 2 = double-buffered (one barrier per tile, 2 workgroups/CU), 1 = single (two barriers, 3-4 workgroups/CU)
 #endif
@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
     float* part = partials + (int64_t)chunk * A.total;
     constexpr int BUFS = (KIND == 0 && NVP_DW_BUFS == 1) ? 1 : 2;     // only the plain variant fits 3 waves/SIMD
     constexpr bool XF = KIND != 0;
-    constexpr bool small = KIND == 2;
     const DwJob J = A.job[job];
     const int wr = w >> 1, wc = w & 1;                // regular jobs: wave owns rows 64wr.., columns 64wc..
 
@@ -164,9 +163,8 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
-    float bsum0 = 0.f, bsum1 = 0.f;                   // bias sums (regular) / last_b, sir0 sums (small)
-    float w0sum = 0.f;
-    const bool want_bias = !small && (J.bias_off >= 0) && (wc == 0);
+    float bsum0 = 0.f, bsum1 = 0.f;                   // bias sums
+    const bool want_bias = (J.bias_off >= 0) && (wc == 0);
 
     // Global loads run TWO tiles ahead of the MFMAs (one tile in LDS, the next two in registers st/st2):
     // under load the HBM round trip exceeds one tile's 4096 MFMA cycles.
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
 #endif
         const float* la = lds + (BUFS == 2 ? cur : 0) * 2 * kTileFloats;
         const float* lb = la + kTileFloats;
-        if (!small) {
+        {
             float fa[16], fb[2][16];
             read_frag(fa, la, 64 * wr + i, h);
 #pragma unroll
@@ -216,30 +214,6 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
                 acc[1][0] = nvp_mfma(fa[k], fb[0][k], acc[1][0]);
                 acc[1][1] = nvp_mfma(fa[k], fb[1][k], acc[1][1]);
             }
-        } else {
-            // small job: staged A = dq0s (for SIREN layer 0: dw0 = sum dq0s*s, dc0 = sum dq0s),
-            // staged B = x2 (for the last layer: dV3[c][col] = sum drgb[c] * x2[col]); wave w owns
-            // rows / columns 32w..32w+31
-            float q[16], xb[16], a3[16], sv[16];
-            read_frag(q, la, 32 * w + i, h);
-            read_frag(xb, lb, 32 * w + i, h);
-            const int64_t px0 = t * 32 + 16 * h;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int64_t px = px0 + k;
-                const int64_t pc = min(px, n - 1);                       // clamped address + data select (no branch)
-                const float g = A.drgb[pc * 3 + min(i, 2)];
-                const float sp = A.steps[pc];
-                a3[k] = (i < 3 && px < n) ? g : 0.f;
-                sv[k] = px < n ? sp : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                acc[0][0] = nvp_mfma(a3[k], xb[k], acc[0][0]);
-                bsum0 += a3[k];
-                w0sum = __fmaf_rn(q[k], sv[k], w0sum);
-                bsum1 += q[k];
-            }
         }
         if (BUFS == 1) {
             __syncthreads();                        // everyone finished reading the single buffer
@@ -254,7 +228,7 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
         cur ^= 1;
     }
 
-    if (!small) {
+    {
         // D[row = out][col = in]: lane holds column i of each tile, rows 8g+4h+e
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -277,54 +251,49 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
                 part[J.bias_off + 64 * wr + 32 + i] = bsum1;
             }
         }
-    } else {
-        // d last_w[c][32w + i]: D rows 0..2 live in lane half 0, registers 0..2
-        // transposed small records: element e of this chunk at partials[e * small_slots + chunk]
-        float* rec = partials + chunk;
-        const int64_t st = A.small_slots;
-        if (h == 0) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) rec[(A.last_w + (int64_t)r * NVP_H + 32 * w + i) * st] = acc[0][0][r];
-        }
-        bsum0 += __shfl_xor(bsum0, 32);
-        bsum1 += __shfl_xor(bsum1, 32);
-        w0sum += __shfl_xor(w0sum, 32);
-        if (h == 0) {
-            if (w == 0 && i < 3) rec[(A.last_b + i) * st] = bsum0;
-            rec[(A.sir0_w + 32 * w + i) * st] = w0sum;
-            rec[(A.sir0_b + 32 * w + i) * st] = bsum1;
-        }
     }
 }
 
-// The small job (last layer + SIREN layer 0: 643 gradient values) runs on kSmallMul x finer pixel chunks
-// (it has almost no MFMA work, so it needs the parallelism to stream its operands) and writes a compact
-// per-chunk record: last_w[384] | last_b[3] | pad | sir0_w[128] | sir0_b[128].
-constexpr int kSmallMul = 4;
-constexpr int kSmallTotal = 644;
-constexpr int kSmLastW = 0, kSmLastB = 384, kSmSir0W = 388, kSmSir0B = 516;
+// Sum the per-tile small-gradient records of one pixel chunk into that chunk's partial (the chain kernel
+// wrote one kRecFloats record per 32-pixel tile into stream 3 of `dy`).  Thread = one record element:
+// consecutive threads read consecutive floats of a record, tiles are visited in order -> deterministic.
+__global__ __launch_bounds__(256) void dw_records_kernel(const float* __restrict__ records, float* __restrict__ partials,
+                                                          int64_t ntiles, int tiles_per_chunk, int64_t total,
+                                                          int64_t p_last_w, int64_t p_last_b, int64_t p_sir0_w, int64_t p_sir0_b) {
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= kRecFloats || e == kRecLastB + 3) return;
+    const int chunk = blockIdx.x;
+    const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
+    const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
+    const float* src = records + e;
+    float s = 0.f;
+    int64_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(t + u) * (int64_t)(NVP_H * 32)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; t < t1; ++t) s += src[t * (int64_t)(NVP_H * 32)];
+    int64_t idx;
+    if (e < kRecLastB) idx = p_last_w + e;
+    else if (e < kRecSir0W) idx = p_last_b + (e - kRecLastB);
+    else if (e < kRecSir0B) idx = p_sir0_w + (e - kRecSir0W);
+    else idx = p_sir0_b + (e - kRecSir0B);
+    partials[(int64_t)chunk * total + idx] = s;
+}
 
 struct ReduceArgs {
     float* dst[14];
     int64_t off[15];
-    int64_t small_base;        // float offset of the small region inside `partials`
-    int small_slots;
-    int64_t p_last_w, p_last_b, p_sir0_w, p_sir0_b;
 };
 
-__device__ __forceinline__ void dw_reduce_store(const ReduceArgs& R, int64_t idx, float s) {
-    int t = 0;
-    while (idx >= R.off[t + 1]) ++t;
-    R.dst[t][idx - R.off[t]] = s;
-}
-
-// Regular gradients: element idx of every chunk's partial, summed in chunk order (fixed order -> deterministic).
+// Element idx of every chunk's partial, summed in chunk order (fixed order -> deterministic).
 // 16 independent loads are kept in flight per thread; the additions stay sequential.
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partials, ReduceArgs R, int n_chunks, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
-    if ((idx >= R.p_last_w && idx < R.p_last_w + 3 * NVP_H) || (idx >= R.p_last_b && idx < R.p_last_b + 3) ||
-        (idx >= R.p_sir0_w && idx < R.p_sir0_w + NVP_H) || (idx >= R.p_sir0_b && idx < R.p_sir0_b + NVP_H)) return;   // dw_reduce_small_kernel
     const float* src = partials + idx;
     float s = 0.f;
     int c = 0;
@@ -336,26 +305,9 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
         for (int u = 0; u < 16; ++u) s += v[u];
     }
     for (; c < n_chunks; ++c) s += src[(int64_t)c * total];
-    dw_reduce_store(R, idx, s);
-}
-
-// Small-job gradients: one wavefront per value; its transposed record (small_slots contiguous floats) is
-// summed lane-strided and combined with a fixed butterfly -> deterministic.
-__global__ __launch_bounds__(256) void dw_reduce_small_kernel(const float* __restrict__ partials, ReduceArgs R) {
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (e >= kSmallTotal || e == kSmLastB + 3) return;        // the pad slot
-    int64_t idx;
-    if (e < kSmLastB) idx = R.p_last_w + e;
-    else if (e < kSmSir0W) idx = R.p_last_b + (e - kSmLastB);
-    else if (e < kSmSir0B) idx = R.p_sir0_w + (e - kSmSir0W);
-    else idx = R.p_sir0_b + (e - kSmSir0B);
-    const float* rec = partials + R.small_base + (int64_t)e * R.small_slots;
-    float s = 0.f;
-    for (int c = lane; c < R.small_slots; c += 64) s += rec[c];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    if (lane == 0) dw_reduce_store(R, idx, s);
+    int t = 0;
+    while (idx >= R.off[t + 1]) ++t;
+    R.dst[t][idx - R.off[t]] = s;
 }
 
 }  // namespace
@@ -398,39 +350,27 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
         if (k == 1) { J.b2 = J.b; J.mode = 2; } else { J.b2 = saved + 3 * act; J.mode = 1; }
         J.n_cols = NVP_H; J.w_off = P.sir_w[k]; J.ld = NVP_H; J.bias_off = P.sir_b[k];
     }
-    {   // the small job stages dq0s as its A tile and x2 = sin(q2) h2 as its B tile
-        DwJob& J = A.job[nj];
-        J.a = dy + 3 * act; J.b = saved + 2 * act; J.b2 = saved + 4 * act; J.mode = 1; J.b_rows = NVP_H; J.b_row0 = 0; J.n_cols = NVP_H;
-        J.w_off = 0; J.ld = NVP_H; J.bias_off = -1;
-    }
-    A.n_jobs = nj + 1;
-    A.drgb = drgb; A.steps = steps; A.sir0_wp = p->sir_w[0]; A.sir0_bp = p->sir_b[0];
-    A.last_w = P.last_w; A.last_b = P.last_b; A.sir0_w = P.sir_w[0]; A.sir0_b = P.sir_b[0];
+    A.n_jobs = nj;
+    A.steps = steps; A.sir0_wp = p->sir_w[0]; A.sir0_bp = p->sir_b[0];
     A.total = P.total;
-    A.small_slots = 0;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
-    // three launches: plain jobs (modulator layers), transform jobs (SIREN layers 1-2), the small job
-    DwArgs P0 = A, P1 = A, P2 = A;
+    // two GEMM launches: plain jobs (modulator layers), transform jobs (SIREN layers 1-2); plus the record sums
+    DwArgs P0 = A, P1 = A;
     int n0 = 0, n1 = 0;
-    for (int jx = 0; jx < A.n_jobs - 1; ++jx) {
+    for (int jx = 0; jx < A.n_jobs; ++jx) {
         if (A.job[jx].mode == 0) P0.job[n0++] = A.job[jx];
         else P1.job[n1++] = A.job[jx];
     }
     P0.n_jobs = n0; P1.n_jobs = n1;
-    P2.job[0] = A.job[A.n_jobs - 1]; P2.n_jobs = 1;
-    P2.small_slots = n_chunks * kSmallMul;
-    P2.total = kSmallTotal; P2.last_w = kSmLastW; P2.last_b = kSmLastB; P2.sir0_w = kSmSir0W; P2.sir0_b = kSmSir0B;
-    const int small_chunks = n_chunks * kSmallMul;
-    const int small_tiles = (int)((ntiles + small_chunks - 1) / small_chunks);
-    float* small_part = partials + (int64_t)n_chunks * P.total;
     const size_t lds_bytes = 2 * 2 * kTileFloats * sizeof(float);
     const size_t lds_bytes0 = (NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats * sizeof(float);
     hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_dw_kernel<1>, dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mlp_dw_kernel<2>, dim3(small_chunks), dim3(256), lds_bytes, (hipStream_t)stream, P2, small_part, n, ntiles, small_tiles, small_chunks);
+    hipLaunchKernelGGL(dw_records_kernel, dim3(n_chunks, (kRecFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy + 3 * act, partials,
+                       ntiles, tiles_per_chunk, P.total, P.last_w, P.last_b, P.sir_w[0], P.sir_b[0]);
     NVP_LAUNCH_CHECK();
 
     ReduceArgs R;
@@ -440,10 +380,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     R.dst[t] = g->last_w; R.off[t++] = P.last_w;
     R.dst[t] = g->last_b; R.off[t++] = P.last_b;
     R.off[t] = P.total;
-    R.small_base = (int64_t)n_chunks * P.total; R.small_slots = small_chunks;
-    R.p_last_w = P.last_w; R.p_last_b = P.last_b; R.p_sir0_w = P.sir_w[0]; R.p_sir0_b = P.sir_b[0];
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, R, n_chunks, P.total);
-    hipLaunchKernelGGL(dw_reduce_small_kernel, dim3((kSmallTotal + 3) / 4), dim3(256), 0, (hipStream_t)stream, partials, R);
     NVP_LAUNCH_CHECK();
     return 0;
 }

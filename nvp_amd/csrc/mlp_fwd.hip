@@ -16,10 +16,6 @@
 // Bound: fp32 MFMA (157.3 TFLOP/s).  Algorithmic work: 219 648 FLOP/px (nvp_s).
 #include "mlp_chain.h"
 
-#ifndef NVP_FWD_LATE_H
-#define NVP_FWD_LATE_H 0
-#endif
-
 namespace {
 
 constexpr int kWaves = 4;
@@ -92,9 +88,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
             lrelu4(acc);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
-#if !NVP_FWD_LATE_H
             if (SAVE) store_ptm(sv + (int64_t)k * act, hm, lane);
-#endif
         }
         // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
         {
@@ -104,12 +98,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
             mfma4(acc, w[(unsigned)lane], 1.0f);
             chain_h(acc, x, w + 64, lane);
             if (SAVE) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
-#if NVP_FWD_LATE_H
-            // h_k is stored here rather than right after it is produced: vmcnt retires in order, so the SIREN chain's
-            // weight loads would otherwise queue behind the write acknowledgements of that store burst; here the
-            // sine stage (no memory waits) follows both bursts.
-            if (SAVE) store_ptm(sv + (int64_t)k * act, hm, lane);
-#endif
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll

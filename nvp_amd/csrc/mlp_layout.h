@@ -76,3 +76,15 @@ __host__ __device__ inline NvpParamLayout nvp_param_layout(int d) {
     P.total = o;
     return P;
 }
+
+// Per-tile record of the "small" gradients (last layer + SIREN layer 0: 643 values) that the backward chain
+// kernel reduces over its 32 pixels itself (mlp_bwd.hip) and the dW stage only has to sum over tiles
+// (mlp_dw.hip).  The record of tile t occupies the first kRecFloats floats of tile t's slot in stream 3 of
+// the `dy` buffer (the slot that used to hold the dq0 stream).
+constexpr int kRecLastW = 0;          // [3][128]
+constexpr int kRecLastB = 384;        // [3] (+1 pad)
+constexpr int kRecSir0W = 388;        // [128]
+constexpr int kRecSir0B = 516;        // [128]
+constexpr int kRecFloats = 644;
+constexpr int kRecRowStride = 33;     // LDS transpose tile [128 features][32 px], conflict-free both ways
+constexpr int kRecTileFloats = 128 * kRecRowStride;

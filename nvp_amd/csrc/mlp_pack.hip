@@ -77,8 +77,7 @@ int64_t nvp_packed_fwd_floats(int32_t d) { return nvp_fwd_layout(d).off[5]; }
 int64_t nvp_packed_bwd_floats(int32_t d) { return nvp_bwd_layout(d).off[7]; }
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
-    // per-chunk gradient records + the compact records of the small job (4 x finer chunks, 644 floats each)
-    return nvp_param_layout(d).total * (int64_t)n_chunks + (int64_t)4 * n_chunks * 644;
+    return nvp_param_layout(d).total * (int64_t)n_chunks;       // one full gradient record per pixel chunk
 }
 int32_t nvp_latent_rows(int32_t d) { return nvp_rows4(d); }
 int32_t nvp_dz_stride(int32_t d) { return nvp_dz_stride_dev(d); }

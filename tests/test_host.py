@@ -37,7 +37,7 @@ def test_library_size_queries_match_layout_arithmetic():
         H = 128
         total = H * d + H + 2 * (H * (H + d) + H) + (H + H) + 2 * (H * H + H) + 3 * H + 3
         assert lib.nvp_mlp_param_floats(d) == total
-        assert lib.nvp_dw_partial_floats(d, 7) == 7 * total + 4 * 7 * 644
+        assert lib.nvp_dw_partial_floats(d, 7) == 7 * total
         assert lib.nvp_latent_rows(d) == (d + 3) // 4 * 4
     assert lib.nvp_mlp_param_floats(114) == 110595      # MLP params of nvp_s
     assert lib.nvp_mlp_param_floats(228) == 154371      # nvp_l

@@ -6,10 +6,5 @@ OUT=../../tools/bin; mkdir -p $OUT; rm -f $OUT/libmlp_*.so
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
 build() { name=$1; shift; for f in mlp_fwd mlp_bwd mlp_dw mlp_pack; do hipcc $FL "$@" -c $f.hip -o $OUT/${f}_$name.o; done; hipcc --offload-arch=gfx950 -shared -fPIC $OUT/mlp_fwd_$name.o $OUT/mlp_bwd_$name.o $OUT/mlp_dw_$name.o $OUT/mlp_pack_$name.o -o $OUT/libmlp_$name.so; }
 build a_base &
-build b_st1 -DNVP_BWD_STORES=1 -DNVP_FWD_LATE_H=1 &
-build c_st2 -DNVP_BWD_STORES=2 -DNVP_FWD_LATE_H=1 &
-build d_st3 -DNVP_BWD_STORES=3 &
-build e_st3p4 -DNVP_BWD_STORES=3 -DNVP_BWD_PRE=4 &
-build f_nostore -DNVP_ABL_NOSTORE &
 wait
 ls $OUT/libmlp_*.so

@@ -40,13 +40,13 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tools", "bin", "libmlp_*.so")))
     f = lambda: lib.nvp_mlp_fwd(vp(zt), vp(steps), C.byref(ps), vp(pf), vp(rgb), vp(saved), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
     g = lambda: lib.nvp_mlp_bwd_dx(vp(drgb), vp(steps), vp(saved), C.byref(ps), vp(pb), vp(dy), vp(dz), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
     lib.nvp_dw_partial_floats.restype = C.c_int64
-    nch = 256
-    part = torch.empty(lib.nvp_dw_partial_floats(C.c_int32(d), C.c_int32(nch)), device=dev)
     grads = [torch.empty_like(t) for t in mlp]
     gs = L.mlp_params_struct(grads)
-    hdw = lambda: lib.nvp_mlp_bwd_dw(vp(drgb), vp(steps), vp(zt), vp(saved), vp(dy), C.byref(ps), vp(part), C.c_int32(nch), C.byref(gs), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
-    res = []
-    for rep in range(3):          # interleaved repeats: same box, same process
-        res.append((timeit(f), timeit(g), timeit(hdw)))
-    tf, tb, tw = (min(r[i] for r in res) for i in range(3))
-    print(f"{os.path.basename(path):18s} fwd {tf:6.3f} ms {219648 * n / tf / 1e9:6.1f} TF | bwd_dx+dz {tb:6.3f} ms {219392 * n / tb / 1e9:6.1f} TF | dw {tw:6.3f} ms {219648 * n / tw / 1e9:6.1f} TF   all: {[tuple(round(x, 3) for x in r) for r in res]}", flush=True)
+    for nch in [int(v) for v in os.environ.get("NCH", "256").split(",")]:
+        part = torch.empty(lib.nvp_dw_partial_floats(C.c_int32(d), C.c_int32(nch)), device=dev)
+        hdw = lambda: lib.nvp_mlp_bwd_dw(vp(drgb), vp(steps), vp(zt), vp(saved), vp(dy), C.byref(ps), vp(part), C.c_int32(nch), C.byref(gs), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
+        res = []
+        for rep in range(3):          # interleaved repeats: same box, same process
+            res.append((timeit(f), timeit(g), timeit(hdw)))
+        tf, tb, tw = (min(r[i] for r in res) for i in range(3))
+        print(f"{os.path.basename(path):18s} nch {nch:4d} fwd {tf:6.3f} ms {219648 * n / tf / 1e9:6.1f} TF | bwd_dx+dz {tb:6.3f} ms {219392 * n / tb / 1e9:6.1f} TF | dw {tw:6.3f} ms {219648 * n / tw / 1e9:6.1f} TF   all: {[tuple(round(x, 3) for x in r) for r in res]}", flush=True)
