@@ -51,11 +51,19 @@ struct DwArgs {
 // ---- LDS staging ------------------------------------------------------------------------
 // A 128-row x 32-pixel tile of a PTM4 stream is 1024 contiguous float4 (16 KiB): the 256 threads
 // fetch it with four fully coalesced 16-B loads each.  It is written to LDS row-major with a
-// 33-float row stride: both the 4-B scatter writes (bank = row + px) and the fragment reads
-// (lane i reads row i, 16 consecutive pixels; bank = row + px) are conflict-free.  The MFMA
-// fragment for feature row i at k-step k is pixel 16h + k on BOTH operands.
-constexpr int kRowStride = 33;
-constexpr int kTileFloats = 128 * kRowStride;          // 4224 floats = 16.5 KiB
+// 36-float row stride: rows stay 16-B aligned, so a lane reads its fragment (row i, 16 consecutive
+// pixels) with four ds_read_b128 - 8 consecutive lanes cover all 32 banks - and the 4-B transposing
+// writes (32 lanes = 32 consecutive pixels of one row) are conflict-free too.  The MFMA fragment for
+// feature row i at k-step k is pixel 16h + k on BOTH operands.
+#ifndef NVP_DW_STRIDE
+#define NVP_DW_STRIDE 36
+#endif
+constexpr int kRowStride = NVP_DW_STRIDE;
+constexpr int kTileFloats = 128 * kRowStride;          // 4608 floats = 18 KiB
+
+#ifdef NVP_ABL_DW_NOMFMA          // ablation builds only: one VALU op instead of an MFMA
+__device__ __forceinline__ f32x16 nvp_abl_fake_mfma(float a, float b, f32x16 c) { c[0] = __fmaf_rn(a, b, c[0]); return c; }
+#endif
 
 struct Stage {
     float4 a[4];
@@ -72,6 +80,11 @@ __device__ __forceinline__ void load_stage(Stage& s, const DwJob& J, int64_t t, 
     // select on the DATA in write_stage - a conditional load would become a branch with a vmcnt(0) wait
     // per element, and a select right here would wait for the prefetch immediately
     const int nvalid = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32);
+#ifdef NVP_ABL_DW_NOLOAD          // ablation builds only
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s.a[k] = make_float4(1e-3f, 2e-3f, 3e-3f, (float)t); s.b[k] = make_float4(1e-3f, 2e-3f, 3e-3f, (float)tid); s.b2[k] = s.b[k]; }
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int f = k * 256 + tid;
@@ -87,7 +100,10 @@ __device__ __forceinline__ void load_stage(Stage& s, const DwJob& J, int64_t t, 
 // `t` is the tile the stage holds (mode 2 needs its temporal steps)
 template <bool XF>
 __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb, const Stage& s, const DwJob& J,
-                                            const DwArgs& A, int64_t t, int64_t n, int tid) {
+                                            const DwArgs& A, const float* __restrict__ tab, int64_t t, int64_t n, int tid) {
+#ifdef NVP_ABL_DW_NOWRITE         // ablation builds only
+    if (t != 0x7fffffff) return;
+#endif
     const int nvalid = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32);
     float sp = 0.f;
     if (XF && J.mode == 2) sp = A.steps[min(t * 32 + (tid & 31), n - 1)];       // wave-uniform branch; px = f & 31 = tid & 31
@@ -104,7 +120,7 @@ __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __res
         } else if (XF && J.mode == 2) {          // x_0 = sin(30 (w s + c)) * h_0
             const int row = 4 * (f >> 5);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = nvp_sin(30.0f * __fmaf_rn(sp, A.sir0_wp[row + e], A.sir0_bp[row + e])) * bv[e];
+            for (int e = 0; e < 4; ++e) bv[e] = nvp_sin(30.0f * __fmaf_rn(sp, tab[row + e], tab[NVP_H + row + e])) * bv[e];
         }
         la[o] = s.a[k].x; la[o + kRowStride] = s.a[k].y; la[o + 2 * kRowStride] = s.a[k].z; la[o + 3 * kRowStride] = s.a[k].w;
         lb[o] = ok ? bv[0] : 0.f; lb[o + kRowStride] = ok ? bv[1] : 0.f;
@@ -115,8 +131,17 @@ __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __res
 
 __device__ __forceinline__ void read_frag(float (&f)[16], const float* __restrict__ tile, int row, int h) {
     const float* p = tile + row * kRowStride + 16 * h;
+    if (kRowStride % 4 == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) f[k] = p[k];
+        for (int k = 0; k < 4; ++k) {
+            const float4 t = p4[k];
+            f[4 * k] = t.x; f[4 * k + 1] = t.y; f[4 * k + 2] = t.z; f[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f[k] = p[k];
+    }
 }
 
 // KIND 0: the modulator jobs (plain operands); KIND 1: SIREN layers 1-2, whose B operand x_k is rebuilt
@@ -158,6 +183,12 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
     const DwJob J = A.job[job];
     const int wr = w >> 1, wc = w & 1;                // regular jobs: wave owns rows 64wr.., columns 64wc..
 
+    // SIREN layer 0's weight and bias (mode 2 rebuilds x_0 from them) live in LDS behind the tile buffers:
+    // a global load at the point of use would put a vmcnt(0) wait into the pipelined loop
+    float* tab = lds + 4 * kTileFloats;
+    if (XF && tid < NVP_H) { tab[tid] = A.sir0_wp[tid]; tab[NVP_H + tid] = A.sir0_bp[tid]; }
+    if (XF) __syncthreads();
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -174,7 +205,7 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
     Stage st, st2;
     if (t0 < t1) {
         load_stage<XF>(st, J, t0, tid);
-        write_stage<XF>(lds, lds + kTileFloats, st, J, A, t0, n, tid);
+        write_stage<XF>(lds, lds + kTileFloats, st, J, A, tab, t0, n, tid);
     }
 #if NVP_DW_DEPTH == 2
     if (t0 + 1 < t1) load_stage<XF>(st, J, t0 + 1, tid);
@@ -199,6 +230,9 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
 #pragma unroll
                 for (int k = 0; k < 16; ++k) bsum0 += fa[k];
             }
+#ifdef NVP_ABL_DW_NOMFMA
+#define nvp_mfma(a, b, c) nvp_abl_fake_mfma(a, b, c)
+#endif
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 acc[0][0] = nvp_mfma(fa[k], fb[0][k], acc[0][0]);
@@ -217,9 +251,9 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
         }
         if (BUFS == 1) {
             __syncthreads();                        // everyone finished reading the single buffer
-            if (more) write_stage<XF>(lds, lds + kTileFloats, st, J, A, t + 1, n, tid);
+            if (more) write_stage<XF>(lds, lds + kTileFloats, st, J, A, tab, t + 1, n, tid);
         } else {
-            if (more) write_stage<XF>(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, J, A, t + 1, n, tid);
+            if (more) write_stage<XF>(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, J, A, tab, t + 1, n, tid);
         }
 #if NVP_DW_DEPTH == 2
         st = st2;
@@ -363,7 +397,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
         else P1.job[n1++] = A.job[jx];
     }
     P0.n_jobs = n0; P1.n_jobs = n1;
-    const size_t lds_bytes = 2 * 2 * kTileFloats * sizeof(float);
+    const size_t lds_bytes = (2 * 2 * kTileFloats + 2 * NVP_H) * sizeof(float);
     const size_t lds_bytes0 = (NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats * sizeof(float);
     hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
