@@ -25,6 +25,16 @@ namespace {
 
 constexpr int kWaves = 4;
 
+// saved-activation loads of the element-wise stages (ablation hook: NVP_ABL_NOELOAD takes them from a register)
+__device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ tile_base, int T, int lane) {
+#ifdef NVP_ABL_NOELOAD
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.25f + 0.001f * (float)(lane + T);
+#else
+    load_ptm16(v, tile_base, T, lane);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Kernel A: the dX chain without the latent gradient.  Register plan (2 waves/SIMD, <= 256):
 //   dx[4], dh[4] (128) are rewritten in place into dq, dp by the element-wise stage, then
@@ -85,14 +95,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         // vmcnt retires in order: a wait for loads issued AFTER a store burst also waits for those stores
         // (an HBM write round trip).  So block T+1's loads are issued before block T's stores.
         f32x16 hv, qv;
-        load_ptm16(hv, hk, 0, lane);
-        load_ptm16(qv, qk, 0, lane);
+        load_act16(hv, hk, 0, lane);
+        load_act16(qv, qk, 0, lane);
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
             f32x16 hn, qn;
             if (T < 3) {
-                load_ptm16(hn, hk, T + 1, lane);
-                load_ptm16(qn, qk, T + 1, lane);
+                load_act16(hn, hk, T + 1, lane);
+                load_act16(qn, qk, T + 1, lane);
             }
             NVP_LOAD_FENCE();
 #pragma unroll
@@ -160,11 +170,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         const float* c0 = p.sir_b[0];
         const float* h0 = sv;
         f32x16 hv;
-        load_ptm16(hv, h0, 0, lane);
+        load_act16(hv, h0, 0, lane);
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
             f32x16 hn, dq0, dp0;
-            if (T < 3) load_ptm16(hn, h0, T + 1, lane);
+            if (T < 3) load_act16(hn, h0, T + 1, lane);
             NVP_LOAD_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -5,11 +5,9 @@ cd "$(dirname "$0")/../nvp_amd/csrc"
 OUT=../../tools/bin; mkdir -p $OUT; rm -f $OUT/libmlp_*.so
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
 build() { name=$1; shift; for f in mlp_fwd mlp_bwd mlp_dw mlp_pack; do hipcc $FL "$@" -c $f.hip -o $OUT/${f}_$name.o; done; hipcc --offload-arch=gfx950 -shared -fPIC $OUT/mlp_fwd_$name.o $OUT/mlp_bwd_$name.o $OUT/mlp_dw_$name.o $OUT/mlp_pack_$name.o -o $OUT/libmlp_$name.so; }
-S="-DNVP_DW_PIPE=0 -DNVP_ABL_DW_NOLOAD -DNVP_ABL_DW_NOWRITE"
-build a_skel $S &
-build b_skel_nobar $S -DNVP_ABL_DW_NOBARRIER &
-build c_skel_nofrag $S -DNVP_ABL_DW_NOFRAG &
-build d_skel_nofrag_nobar $S -DNVP_ABL_DW_NOFRAG -DNVP_ABL_DW_NOBARRIER &
-build e_nopipe -DNVP_DW_PIPE=0 &
+build a_prio0 -DNVP_PRIO=0 &
+build b_prio1 -DNVP_PRIO=1 &
+build c_prio2 -DNVP_PRIO=2 &
+build d_prio1_nostagger -DNVP_PRIO=1 -DNVP_STAGGER_SLEEPS=0 &
 wait
 ls $OUT/libmlp_*.so | wc -l
