@@ -41,10 +41,17 @@ __device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ 
 //   dx' = chain(dq) needs one 64-register accumulator (192 live), after which dq is dead and
 //   dh' = chain(dp) reuses the space.
 // ------------------------------------------------------------------------------------------
+// FUSE_DZ (latent <= 128 rows, i.e. one 64-register accumulator): the latent gradient
+//   dz = W2[:,128:]^T dp2 + W1[:,128:]^T dp1 + W0^T dp0
+// is accumulated by this kernel as a third chain per layer, straight from the dp registers, instead of by
+// mlp_bwd_dz_kernel re-reading the three dp streams (1.5 KB/px).  Its accumulator does not fit next to
+// dx/dh/acc, so between layers it is parked in the wave's LDS tile (free while the chains run: x2 is consumed
+// before the layer-2 chains, dq0 is written after the accumulator has been fetched back for layer 0).
+template <bool FUSE_DZ>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const float* __restrict__ packed,
-                                                                    float* __restrict__ dy,
+                                                                    float* __restrict__ dy, float* __restrict__ dzr,
                                                                     int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
@@ -155,6 +162,29 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         chain_h<2>(acc, dx, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+        if (FUSE_DZ) {
+            // dz += W_k[:, 128:]^T dp_k; the accumulator lives in LDS between layers (see above)
+            float4* park = reinterpret_cast<float4*>(xl);
+            if (k == 2) {
+#pragma unroll
+                for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            } else {
+#pragma unroll
+                for (int T = 0; T < 4; ++T)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 t = park[(T * 4 + g) * 64 + lane];
+                        acc[T][4 * g] = t.x; acc[T][4 * g + 1] = t.y; acc[T][4 * g + 2] = t.z; acc[T][4 * g + 3] = t.w;
+                    }
+            }
+            chain_hz<4>(acc, dh, packed + L.off[4 + k], lane);     // streams 6 (z2^T), 5 (z1^T)
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    park[(T * 4 + g) * 64 + lane] = make_float4(acc[T][4 * g], acc[T][4 * g + 1], acc[T][4 * g + 2], acc[T][4 * g + 3]);
+            NVP_LOAD_FENCE();
+        }
         // dh_{k-1} = W_k[:, :128]^T dp_k
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
@@ -171,10 +201,27 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         const float* h0 = sv;
         f32x16 hv;
         load_act16(hv, h0, 0, lane);
+        // The parked dz accumulator is fetched back quarter by quarter, just ahead of the dq0 rows that overwrite
+        // its LDS region (quarter T of the accumulator sits in floats [1024 T, 1024 T + 1024), rows 32 T .. 32 T + 31 of
+        // the dq0 tile in [1056 T, 1056 T + 1056)): that keeps the register peak of this stage below 256.
+        f32x16 dzacc[4];
+        auto fetch_dz = [&](int T) {
+            const float4* park = reinterpret_cast<const float4*>(xl);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = park[(T * 4 + g) * 64 + lane];
+                dzacc[T][4 * g] = t.x; dzacc[T][4 * g + 1] = t.y; dzacc[T][4 * g + 2] = t.z; dzacc[T][4 * g + 3] = t.w;
+            }
+            nvp_pin(dzacc[T]);
+        };
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            f32x16 hn, dq0, dp0;
+            f32x16 hn;
             if (T < 3) load_act16(hn, h0, T + 1, lane);
+            if (FUSE_DZ) {
+                if (T == 0) fetch_dz(0);
+                if (T < 3) fetch_dz(T + 1);
+            }
             NVP_LOAD_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -183,13 +230,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
                 float sn, cs;
                 nvp_sincos(q, sn, cs);
                 const float dxv = dx[T][r];
-                dq0[r] = 30.0f * (dxv * hv[r] * cs);          // gradient w.r.t. (w s + c)
+                dx[T][r] = 30.0f * (dxv * hv[r] * cs);        // dq0: gradient w.r.t. (w s + c)
                 const float dhv = dh[T][r] + dxv * sn;
-                dp0[r] = hv[r] > 0.f ? dhv : dhv * 0.01f;
+                dh[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;   // dp0
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xl[(32 * T + nvp_frag_row(r, h)) * kRecRowStride + j] = dq0[r];
-            store_ptm16(dyt, dp0, T, lane);
+            for (int r = 0; r < 16; ++r) xl[(32 * T + nvp_frag_row(r, h)) * kRecRowStride + j] = dx[T][r];
+            nvp_pin(dh[T]);
+            store_ptm16(dyt, dh[T], T, lane);
             NVP_LOAD_FENCE();
             if (T < 3) hv = hn;
         }
@@ -206,6 +254,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         }
         rec[kRecSir0W + lane] = wl; rec[kRecSir0W + 64 + lane] = wh;
         rec[kRecSir0B + lane] = cl; rec[kRecSir0B + 64 + lane] = ch;
+        if (FUSE_DZ) {
+            // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
+            NVP_LOAD_FENCE();
+            chain_hz<4>(dzacc, dh, packed + L.off[4], lane);       // stream 4 (z0^T)
+            const int stride = nvp_dz_stride_dev(d);
+            float* o = dzr + (tile * 32 + j) * stride;
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int base = 32 * T + 8 * g + 4 * h;
+                    if (base < stride)
+                        *reinterpret_cast<float4*>(o + base) = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
+                }
+        }
     }
 }
 
@@ -276,11 +339,19 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     if (zt != 4 && zt != 8) return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
-    hipLaunchKernelGGL(mlp_bwd_dx_kernel, grid, dim3(kWaves * 64), kWaves * kRecTileFloats * sizeof(float), (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, n, ntiles, d);
-    if (zt == 4)
-        hipLaunchKernelGGL(mlp_bwd_dz_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
-    else
-        hipLaunchKernelGGL(mlp_bwd_dz_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
+    const size_t lds = kWaves * kRecTileFloats * sizeof(float);
+#ifndef NVP_BWD_FUSE_DZ
+#define NVP_BWD_FUSE_DZ 1
+#endif
+    if (zt == 4 && NVP_BWD_FUSE_DZ) {
+        hipLaunchKernelGGL(mlp_bwd_dx_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, dz_rows, n, ntiles, d);
+    } else {
+        hipLaunchKernelGGL(mlp_bwd_dx_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, dz_rows, n, ntiles, d);
+        if (zt == 4)
+            hipLaunchKernelGGL(mlp_bwd_dz_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
+        else
+            hipLaunchKernelGGL(mlp_bwd_dz_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
+    }
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -5,9 +5,7 @@ cd "$(dirname "$0")/../nvp_amd/csrc"
 OUT=../../tools/bin; mkdir -p $OUT; rm -f $OUT/libmlp_*.so
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
 build() { name=$1; shift; for f in mlp_fwd mlp_bwd mlp_dw mlp_pack; do hipcc $FL "$@" -c $f.hip -o $OUT/${f}_$name.o; done; hipcc --offload-arch=gfx950 -shared -fPIC $OUT/mlp_fwd_$name.o $OUT/mlp_bwd_$name.o $OUT/mlp_dw_$name.o $OUT/mlp_pack_$name.o -o $OUT/libmlp_$name.so; }
-build a_prio0 -DNVP_PRIO=0 &
-build b_prio1 -DNVP_PRIO=1 &
-build c_prio2 -DNVP_PRIO=2 &
-build d_prio1_nostagger -DNVP_PRIO=1 -DNVP_STAGGER_SLEEPS=0 &
+build a_fused &
+build b_split -DNVP_BWD_FUSE_DZ=0 &
 wait
 ls $OUT/libmlp_*.so | wc -l
