@@ -167,6 +167,8 @@ struct PermArgs {
     float* dzs[3];
     int col0[3], nlev[3];
     int c0[3], c1[3];         // coordinate columns feeding (dim0, dim1) of each plane
+    int scol0, scols;         // the sparse grid's latent-gradient columns (only their max|.| is taken here)
+    unsigned* sdzmax;
 };
 
 // one thread = one (sorted position, plane); F floats per level, 128-B contiguous read per plane
@@ -208,6 +210,23 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(m));
+    // The last plane's threads also take max|dz| over the sparse grid's columns, which follow their own
+    // segment in the same row (mostly the same or the next cache line): the sparse stage then never has
+    // to read dz just for its fixed-point scale.
+    if (plane == 2) {                                  // block-uniform
+        float ms = 0.f;
+        if (p < n) {
+            const float* src = dz + (int64_t)A.order[plane][p] * dz_stride + A.scol0;     // 16-B aligned: scol0, dz_stride multiples of 4
+            const int nq = (A.scols + 3) >> 2;         // the row is zero-padded up to dz_stride
+            for (int q = 0; q < nq; ++q) {
+                const float4 t = reinterpret_cast<const float4*>(src)[q];
+                ms = fmaxf(ms, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ms = fmaxf(ms, __shfl_xor(ms, o));
+        if ((threadIdx.x & 63) == 0 && ms > 0.f) atomicMax(A.sdzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(ms));
+    }
 }
 
 __device__ __forceinline__ int row_of(float c1, float scale) { return (int)floorf(c1 * scale + 0.5f); }
@@ -397,19 +416,11 @@ __device__ __forceinline__ int nearest_idx(float c, int res) {
 constexpr int kSparseThreads = 256;
 constexpr int kSparseEntries = NVP_SPARSE_ENTRIES;   // target int64 entries per table (24 KB); grows to one x-row if wider
 
-__global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
-                                                          unsigned* __restrict__ keys, unsigned* __restrict__ dzmax, int64_t n, nvp_sparse_shape sh) {
+__global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restrict__ coords, unsigned* __restrict__ keys, int64_t n, nvp_sparse_shape sh) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float m = 0.f;
-    if (i < n) {
-        const float* c = coords + i * 3;
-        keys[i] = (unsigned)(nearest_idx(c[0], sh.t_res) * sh.x_res + nearest_idx(c[1], sh.x_res));
-        const float* g = dz + i * dz_stride + col0;
-        for (int k = 0; k < 9 * sh.n_features; ++k) m = fmaxf(m, fabsf(g[k]));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(m));
+    if (i >= n) return;
+    const float* c = coords + i * 3;
+    keys[i] = (unsigned)(nearest_idx(c[0], sh.t_res) * sh.x_res + nearest_idx(c[1], sh.x_res));
 }
 
 // srowstart[k] = first sorted position whose key is >= k, k in [0, T*X]
@@ -508,6 +519,12 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         PA.col0[p] = col; PA.nlev[p] = lv[p]->n_levels; PA.c0[p] = c0[p]; PA.c1[p] = c1[p];
         col += lv[p]->n_levels * lv[p]->n_features;
     }
+    PA.scol0 = col; PA.scols = 9 * sh->n_features; PA.sdzmax = (unsigned*)(ws + W.sdzmax);
+    if ((col & 3) != 0 || col + ((PA.scols + 3) & ~3) > dz_stride) return NVP_ERR_UNSUPPORTED;
+    {
+        hipError_t me2 = hipMemsetAsync(PA.sdzmax, 0, kMaxSlots * 4, s);
+        if (me2 != hipSuccess) return (int)me2;
+    }
     hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, coords, dz, dz_stride, PA,
                        (unsigned*)(ws + W.dzmax), n);
 
@@ -555,9 +572,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         int* sorder = (int*)(ws + W.sorder);
         int* srs = (int*)(ws + W.srowstart);
         unsigned* sdzmax = (unsigned*)(ws + W.sdzmax);
-        me = hipMemsetAsync(sdzmax, 0, kMaxSlots * 4, s);
-        if (me != hipSuccess) return (int)me;
-        hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, dz, dz_stride, col, sk_in, sdzmax, n, *sh);
+        hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk_in, n, *sh);      // max|dz|: permute_kernel
         const int nkeys = sh->t_res * sh->x_res;
         int end_bit = 1;
         while (((int64_t)1 << end_bit) < nkeys && end_bit < 32) ++end_bit;
