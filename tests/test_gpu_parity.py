@@ -383,7 +383,8 @@ def test_psnr_at_equal_steps_matches_oracle():
     import math
     from nvp_amd import harness
     from nvp_amd.modules import NVP
-    T, H, W, n, steps_total = 16, 64, 64, 8192, 30
+    T, H, W, n = 16, 64, 64, 8192
+    steps_total = int(os.environ.get("NVP_PSNR_STEPS", "30"))        # tools/psnr_track.sh runs a longer horizon
     cfg = small_cfg(F=2, T=T, X=20, Y=20)
     sd = O.init_state(cfg, seed=3)                       # reference init distributions
     model = NVP(out_features=3, encoding_config=cfg)
@@ -395,8 +396,9 @@ def test_psnr_at_equal_steps_matches_oracle():
     keys = list(sd_ref)
     opt_r = torch.optim.AdamW([sd_ref[k] for k in keys], lr=1e-2, weight_decay=0.001)
     sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=steps_total, eta_min=1e-5)
-    opt_g = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=0.001)
-    sch_g = torch.optim.lr_scheduler.CosineAnnealingLR(opt_g, T_max=steps_total, eta_min=1e-5)
+    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)      # the product's optimiser: nvp_adamw_step + cosine
+    from nvp_amd.optim import AdamW as _NvpAdamW
+    assert isinstance(opt_g, _NvpAdamW)
     gen = torch.Generator().manual_seed(0)
     flat = video.reshape(T, H * W, 3)
     diffs = []
@@ -414,6 +416,9 @@ def test_psnr_at_equal_steps_matches_oracle():
         opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
         psnr_r = 10 * math.log10(4 / float(loss_r)); psnr_g = 10 * math.log10(4 / float(loss_g))   # training.py:58
         diffs.append(abs(psnr_r - psnr_g))
+        if os.environ.get("NVP_PSNR_LOG"):
+            with open(os.environ["NVP_PSNR_LOG"], "a") as f:
+                f.write(f'{{"step": {it + 1}, "psnr_oracle": {psnr_r:.4f}, "psnr_hip": {psnr_g:.4f}}}\n')
     assert psnr_g > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
     assert max(diffs) <= 0.02, f"train-PSNR gap {max(diffs):.4f} dB"
     # evaluation PSNR on full frames (eval.py:243-256) with both final parameter sets
