@@ -40,6 +40,20 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tools", "bin", "libmlp_*.so")))
     f = lambda: lib.nvp_mlp_fwd(vp(zt), vp(steps), C.byref(ps), vp(pf), vp(rgb), vp(saved), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
     g = lambda: lib.nvp_mlp_bwd_dx(vp(drgb), vp(steps), vp(saved), C.byref(ps), vp(pb), vp(dy), vp(dz), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
     lib.nvp_dw_partial_floats.restype = C.c_int64
+    if os.environ.get("NVP_LOOP_STAGE"):          # tools/power_probe.sh: loop one stage for a few seconds
+        import time
+        nchl = 256
+        partl = torch.empty(lib.nvp_dw_partial_floats(C.c_int32(d), C.c_int32(nchl)), device=dev)
+        gradsl = [torch.empty_like(t) for t in mlp]; gsl = L.mlp_params_struct(gradsl)
+        hl = lambda: lib.nvp_mlp_bwd_dw(vp(drgb), vp(steps), vp(zt), vp(saved), vp(dy), C.byref(ps), vp(partl), C.c_int32(nchl), C.byref(gsl), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
+        fn = {"fwd": f, "bwd": g, "dw": hl}[os.environ["NVP_LOOP_STAGE"]]
+        f(); g(); torch.cuda.synchronize()
+        t0 = time.time(); it = 0
+        while time.time() - t0 < float(os.environ.get("NVP_LOOP_SECONDS", "8")):
+            for _ in range(50): fn()
+            torch.cuda.synchronize(); it += 50
+        print(f"stage {os.environ['NVP_LOOP_STAGE']}: {it} launches, {(time.time() - t0) / it * 1e3:.3f} ms each")
+        sys.exit(0)
     grads = [torch.empty_like(t) for t in mlp]
     gs = L.mlp_params_struct(grads)
     for nch in [int(v) for v in os.environ.get("NCH", "256").split(",")]:
