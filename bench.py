@@ -63,8 +63,9 @@ PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 PEAK_HBM = 8.0e12
 
 
-def cpu_baseline(n_sample: int, reps: int = 2):
-    """Oracle fwd+bwd (incl. dense grid grads, as the reference's autograd does) on the host."""
+def cpu_baseline(n_sample: int, reps: int = 1):
+    """Oracle fwd+bwd (incl. dense grid grads, as the reference's autograd does) on the host: one warm-up
+    evaluation + `reps` timed ones of a 262 144-pixel sample (~15 s each on the GPU box's 128 threads)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nvp_oracle as O
     cfg = CONFIG_NVP_S
@@ -199,6 +200,16 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9,
                     "unit": "GB/s", "frac": round(ach / PEAK_HBM, 4), "traffic": traffic.get(dom),
                     "ms_per_launch": kms[dom], "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
+        # every hot-path stage against its own roofline (SURVEY 8d asks for the isolated gather/scatter fractions too)
+        stages = {}
+        for k, ms in kms.items():
+            if k in FLOP_PX:
+                a = FLOP_PX[k] * N_PX / (ms * 1e-3)
+                stages[k] = {"ms": ms, "bound": "mfma", "achieved_tflops": round(a / 1e12, 2), "frac": round(a / PEAK_MFMA_F32, 4)}
+            elif k in BYTES_PX:
+                a = BYTES_PX[k] * N_PX / (ms * 1e-3)
+                stages[k] = {"ms": ms, "bound": "hbm", "achieved_gbs": round(a / 1e9, 1), "frac": round(a / PEAK_HBM, 4),
+                             "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None}
         hot_ms = sum(kms.values())
         line = {
             "metric": "Mpixels/sec fwd+bwd (full optimisation step), UVG-HD 1080p geometry",
@@ -213,6 +224,7 @@ def main():
                        "step_contents": "device sampler + fwd + mse + bwd + " + ("allreduce (grid grads async under the dW GEMMs) + " if world > 1 else "") + "AdamW + cosine"},
             "roofline": roof,
             "kernels_ms": kms,
+            "stages": stages,
             "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
             "final_loss": float(loss),
         }
