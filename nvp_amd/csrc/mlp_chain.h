@@ -137,6 +137,29 @@ __device__ __forceinline__ void chain_z(f32x16 (&acc)[4], const float4* __restri
     }
 }
 
+// Same k-steps for latent rows that are NOT staged in LDS (wide latents, nvp_l: the tile would not leave room
+// for two workgroups per CU): the B operand comes straight from the PTM4 tensor, one 16-B load per lane per
+// two k-steps (both lane halves read the same 512 B), prefetched one row-group ahead.  u0 must be even.
+__device__ __forceinline__ void chain_zg(f32x16 (&acc)[4], const float4* __restrict__ zg, int u0, int u1,
+                                         const float4* __restrict__ wp, int lane) {
+    const unsigned ul = (unsigned)lane;
+    const int j = lane & 31;
+    const bool hi = lane >= 32;
+    if (u0 >= u1) return;
+    float4 t = zg[(u0 >> 1) * 32 + j];
+    for (int u = u0; u < u1; u += 2) {
+        float4 tn = t;
+        if (u + 2 < u1) tn = zg[((u + 2) >> 1) * 32 + j];
+        const float4 a0 = NVP_WLOAD((wp + u * 64)[ul]);
+        float4 a1 = a0;
+        if (u + 1 < u1) a1 = NVP_WLOAD((wp + (u + 1) * 64)[ul]);
+        NVP_CHAIN_FENCE();
+        mfma4(acc, a0, hi ? t.y : t.x);
+        if (u + 1 < u1) mfma4(acc, a1, hi ? t.w : t.z);
+        t = tn;
+    }
+}
+
 __device__ __forceinline__ void lrelu4(f32x16 (&v)[4]) {
 #pragma unroll
     for (int T = 0; T < 4; ++T)

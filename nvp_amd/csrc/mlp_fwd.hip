@@ -19,6 +19,9 @@
 namespace {
 
 constexpr int kWaves = 4;
+// Latent rows kept in LDS per wave: 152 rows x 32 px x 4 B = 19 KB -> 76 KB per workgroup, two workgroups (two waves
+// per SIMD) per CU.  nvp_s (116 rows) fits entirely; nvp_l (228 rows) streams rows 152.. from the latent tensor.
+constexpr int kZLdsRows = 152;
 
 template <bool SAVE>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __restrict__ zt, const float* __restrict__ steps,
@@ -34,8 +37,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
     // this wave's latent tile -> its private LDS region (read by all three modulator layers)
     extern __shared__ __attribute__((aligned(16))) float4 zlds[];
     const int z4 = (nvp_rows4(d) / 4) * 32;                 // float4 per latent tile
-    float4* z = zlds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * z4;
-    stage_z(z, reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4, z4, lane);
+    const int zl4 = (min(nvp_rows4(d), kZLdsRows) / 4) * 32;   // ... of which staged in LDS
+    const int zs_l = min(L.zs, kZLdsRows / 2);              // k-steps served from LDS; the rest from the tensor
+    const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
+    float4* z = zlds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * zl4;
+    stage_z(z, zg, zl4, lane);
     const float4* wp = reinterpret_cast<const float4*>(packed);
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
@@ -52,7 +58,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         mfma4(hm, w[(unsigned)lane], 1.0f);
-        chain_z(hm, z, L.zs, w + 64, lane);
+        chain_z(hm, z, zs_l, w + 64, lane);
+        chain_zg(hm, zg, zs_l, L.zs, w + 64, lane);
         lrelu4(hm);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
@@ -84,7 +91,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             mfma4(acc, w[(unsigned)lane], 1.0f);
             chain_h(acc, hm, w + 64, lane);
-            chain_z(acc, z, L.zs, w + 65 * 64, lane);
+            chain_z(acc, z, zs_l, w + 65 * 64, lane);
+            chain_zg(acc, zg, zs_l, L.zs, w + 65 * 64, lane);
             lrelu4(acc);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
@@ -142,7 +150,8 @@ extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_pa
     if (n == 0) return 0;
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
-    const size_t lds = (size_t)kWaves * (nvp_rows4(d) / 4) * 32 * sizeof(float4);      // 59 KB (nvp_s), 117 KB (nvp_l)
+    const int lrows = nvp_rows4(d) < kZLdsRows ? nvp_rows4(d) : kZLdsRows;
+    const size_t lds = (size_t)kWaves * (lrows / 4) * 32 * sizeof(float4);             // 59 KB (nvp_s), 76 KB (nvp_l)
     if (lds > 160 * 1024) return NVP_ERR_UNSUPPORTED;
     if (saved)
         hipLaunchKernelGGL(mlp_fwd_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, packed_fwd, rgb, saved, n, ntiles, d);
