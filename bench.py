@@ -140,7 +140,9 @@ def main():
     parallel.broadcast_parameters(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     video = torch.randint(0, 256, (T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)   # synthetic u8 RGB, 3.7 GB
-    data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank)   # rank-offset sampler seed
+    # NVP_BENCH_UNSORTED=1: batches in the reference sampler's raw order (what a drop-in caller delivers); informational
+    data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank,   # rank-offset sampler seed
+                               sort_by_y=os.environ.get("NVP_BENCH_UNSORTED", "0") != "1")
     total = args.steps + args.warmup
     opt, sched = harness.make_optimizer(model, total_steps=max(total, 1))
     # NVP_FORCE_BUCKET=1 exercises the flat-gradient-bucket code path on a single GPU (the collective is a no-op)

@@ -7,6 +7,8 @@ for coordinates / temporal steps, exactly like the reference's autograd graph.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Sequence, Tuple
 
@@ -50,6 +52,12 @@ TIMER = None      # set to a KernelTimer() to time launches
 # Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
 # (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
 GRIDS_READY_HOOK = None
+
+# Batches that do not arrive sorted by their y coordinate (the reference's own sampler, dataio.py:104-120) are
+# put into that order inside NVPFused for the duration of the step and the RGB rows are returned in the
+# caller's order: the grid gathers get row locality (encode 1.07 -> 0.75 ms at N = 1.2 M) and the scatter skips a
+# sort.  Only worth it for training-size batches; 0 disables.
+AUTO_SORT_MIN = int(os.environ.get("NVP_AUTO_SORT_MIN", "65536"))
 
 # Optional gradient sink (data parallelism): {param.data_ptr(): preallocated tensor}.  When a
 # parameter has an entry, backward writes its gradient straight into that tensor (a view of the
@@ -263,23 +271,32 @@ class NVPFused(torch.autograd.Function):
         _check_mlp(mlp, d)
         rows = lib.nvp_latent_rows(d)
         dev = coords.device
+        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
+        order = None
+        if need_grad and not y_sorted and not temporal_interp and AUTO_SORT_MIN > 0 and n >= AUTO_SORT_MIN:
+            order = torch.argsort(coords[:, 2])
+            coords, steps, y_sorted = coords[order], steps[order], True
         zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32)
         if n:
             L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
                                        1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_fwd")
-        need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
         rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
         if need_grad:
             if temporal_interp:
                 raise NotImplementedError("temporal_interp=True is an inference-only path (reference eval.py --t_interp)")
             ctx.n, ctx.d = n, d
+            ctx.order = order
             ctx.flags = L.COORDS_SORTED_BY_Y if y_sorted else 0
             ctx.lv = (lv_xy, lv_yt, lv_xt)
             ctx.sh = sh
             if saved is None:
                 saved = torch.empty(0, device=dev)
             ctx.save_for_backward(coords, steps, zt, saved, kf_xy, kf_yt, kf_xt, emb, *mlp)
+        if order is not None:                       # rows back in the caller's order
+            out = torch.empty_like(rgb)
+            out[order] = rgb
+            return out
         return rgb
 
     @staticmethod
@@ -287,6 +304,8 @@ class NVPFused(torch.autograd.Function):
         lib = L.load()
         coords, steps, zt, saved, kf_xy, kf_yt, kf_xt, emb, *mlp = ctx.saved_tensors
         n, d = ctx.n, ctx.d
+        if ctx.order is not None:
+            drgb = drgb[ctx.order]
         if n == 0:
             z = [torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb)]
             return (None, None, *z, None, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])

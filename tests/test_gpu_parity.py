@@ -269,6 +269,33 @@ def test_nvp_forward_backward_vs_oracle(F, n):
         assert np.array_equal(got == 0, want == 0) or _relerr(got, want) < 3e-4
 
 
+def test_auto_sort_returns_rows_in_caller_order(monkeypatch):
+    """Unsorted training batches are y-sorted inside NVPFused (functional.AUTO_SORT_MIN): RGB rows must come back in
+    the caller's order and the gradients must be those of the unsorted evaluation."""
+    from nvp_amd import functional
+    monkeypatch.setattr(functional, "AUTO_SORT_MIN", 1)
+    cfg, sd, model = _nvp_pair(2)
+    gen = torch.Generator().manual_seed(123)
+    n = 3001
+    cand = torch.rand((2 * n + 64, 3), generator=gen)
+    coords = cand[_away_from_kinks(cand, sd, cfg, n)].unsqueeze(0)
+    T = cfg["3d_encoding"]["t_resolution"]
+    steps = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[torch.randint(0, T, (1, n), generator=gen)]
+    gt = torch.rand((1, n, 3), generator=gen) * 2 - 1
+    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.nvp_forward(coords, steps, sd_ref, cfg)
+    O.image_mse(ref, gt).backward()
+    out = model({"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())})["model_out"]
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= RGB_TOL
+    ((out - gt.to(dev())) ** 2).mean().backward()
+    for k in sd:
+        assert _relerr(_grad_of(model, k).cpu().numpy(), sd_ref[k].grad.numpy()) < 3e-4, k
+    # no_grad evaluation (inference) is never re-ordered
+    with torch.no_grad():
+        out2 = model({"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())})["model_out"]
+    assert torch.equal(out2, out.detach())
+
+
 def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
     """NVP_COORDS_SORTED_BY_Y only skips a sort: gradients must be bit-identical with and without the
     hint, and - integer fixed-point accumulation being order independent - across repeated runs."""
