@@ -114,6 +114,11 @@ def test_product_fails_loudly_without_a_hip_device():
         m.sparse_grid(torch.rand(5, 3))
     with pytest.raises(RuntimeError, match="HIP device"):
         m.keyframes_xy(torch.rand(5, 2))
+    from nvp_amd.optim import AdamW                      # the AdamW kernel has no CPU path either
+    p = torch.nn.Parameter(torch.zeros(8))
+    p.grad = torch.ones(8)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        AdamW([p], lr=1e-2).step()
 
 
 def test_unsupported_configs_raise():
