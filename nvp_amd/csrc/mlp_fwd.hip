@@ -144,10 +144,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
 
 }  // namespace
 
+int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
+                          float* rgb, float* saved, int64_t n, int32_t d, void* stream);        // mlp_fwd_b3.hip
+
 extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
                            float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
     if (!zt || !steps || !p || !packed_fwd || !rgb || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) return nvp_mlp_fwd_b3_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     const int lrows = nvp_rows4(d) < kZLdsRows ? nvp_rows4(d) : kZLdsRows;

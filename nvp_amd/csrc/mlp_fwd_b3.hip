@@ -1,0 +1,233 @@
+// Forward of the modulator MLP + modulated SIREN (R8-R10) on **bf16 x 3 split MFMA**: same structure as
+// mlp_fwd.hip (one wave = one 32-pixel tile, pixel on the MFMA column axis, a layer's 64 D registers are the next
+// layer's B operand, latent tile in the wave's LDS region, five saved streams), but every GEMM runs on
+// v_mfma_f32_32x32x16_bf16: both operands are written as hi + mid + lo bf16 (weights once per step by
+// pack_fwd_b3_kernel, activations on the fly from the fp32 registers) and the six products >= 2^-24 are
+// accumulated in fp32.  The result carries an error BELOW that of an fp32 fma chain of the same length
+// (profiles/r01_probe_bf16x3_split_chain.txt) at 2.5x fewer matrix-pipe cycles.  Used for latents of <= 128 rows
+// when the library is built with NVP_FWD_B3=1; everything else (element-wise stages, saved streams, RGB layout)
+// is identical to the fp32 kernel.
+#include "mlp_chain.h"
+
+namespace {
+
+constexpr int kWaves = 4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32, round to nearest even
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// 8 floats -> hi / mid / lo bf16x8 with x = hi + mid + lo to ~2^-25 |x|
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = x[2 * p], b = x[2 * p + 1];
+        const unsigned h = pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        hi[p] = h; mid[p] = m; lo[p] = pk_bf16(sa, sb);
+    }
+}
+__device__ __forceinline__ f32x16 mf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// one k-step (16 inputs) into the four output tiles; w points at the step's 12 operand quads
+__device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+    const unsigned ul = (unsigned)lane;
+    u32x4 a[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        if (T < 3) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+        }
+        NVP_CHAIN_FENCE();
+        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
+        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
+        acc[T] = mf(ah, bl, acc[T]);
+        acc[T] = mf(am, bm, acc[T]);
+        acc[T] = mf(am, bh, acc[T]);
+        acc[T] = mf(ah, bm, acc[T]);
+        acc[T] = mf(ah, bh, acc[T]);
+    }
+}
+
+// bias step: B = e_0 (1.0 at k = 0, exact in bf16), A[.][0] = hi/mid/lo of the bias
+__device__ __forceinline__ void bias_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, int lane) {
+    const unsigned ul = (unsigned)lane;
+    const u32x4 e0 = {lane < 32 ? 0x00003f80u : 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const u32x4 ah = (w + (T * 3 + 0) * 64)[ul], am = (w + (T * 3 + 1) * 64)[ul], al = (w + (T * 3 + 2) * 64)[ul];
+        acc[T] = mf(al, e0, acc[T]);
+        acc[T] = mf(am, e0, acc[T]);
+        acc[T] = mf(ah, e0, acc[T]);
+    }
+}
+
+// 8 k-steps over the previous layer's D registers
+__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3(acc, w + c * 12 * 64, bh, bm, bl, lane);
+    }
+}
+
+// 8 k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
+// step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, const u32x4* __restrict__ w, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+        const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+        const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3(acc, w + s * 12 * 64, bh, bm, bl, lane);
+    }
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float* __restrict__ zt, const float* __restrict__ steps,
+                                                                    nvp_mlp_params p, const unsigned* __restrict__ packed,
+                                                                    float* __restrict__ rgb, float* __restrict__ saved,
+                                                                    int64_t n, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
+    if (tile >= ntiles) return;                       // wave-uniform
+    nvp_stagger_start();
+    const int j = lane & 31, h = lane >> 5;
+    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3();
+    // latent tile -> this wave's LDS region, zero-padded to 128 rows (the packed weights are zero there, but
+    // 0 x garbage could be NaN)
+    extern __shared__ __attribute__((aligned(16))) float4 zlds[];
+    float4* z = zlds + wv * 1024;
+    const int z4 = (nvp_rows4(d) / 4) * 32;
+    stage_z(z, reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4, z4, lane);
+    for (int idx = z4 + lane; idx < 1024; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
+    const int64_t px = tile * 32 + j;
+    const float s = px < n ? steps[px] : 0.f;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    float* sv = SAVE ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
+
+    f32x16 hm[4], x[4], acc[4];
+
+    // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
+    {
+        const u32x4* w = wp + L.off[0] / 4;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
+        bias_b3(hm, w, lane);
+        chain_z_b3(hm, z, w + 12 * 64, lane);
+        lrelu4(hm);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
+        if (SAVE) store_ptm(sv + 0 * act, hm, lane);
+    }
+    // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
+    {
+        const float* w0 = p.sir_w[0];
+        const float* c0 = p.sir_b[0];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                const float q = 30.0f * __fmaf_rn(s, w0[row], c0[row]);
+                x[T][r] = nvp_sin(q) * hm[T][r];
+            }
+            nvp_pin(x[T]);
+            NVP_LOAD_FENCE();
+        }
+    }
+    // ---- layers 1 and 2
+#pragma unroll
+    for (int k = 1; k <= 2; ++k) {
+        {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
+            const u32x4* w = wp + L.off[k] / 4;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            bias_b3(acc, w, lane);
+            chain_h_b3(acc, hm, w + 12 * 64, lane);
+            chain_z_b3(acc, z, w + 9 * 12 * 64, lane);
+            lrelu4(acc);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
+            if (SAVE) store_ptm(sv + (int64_t)k * act, hm, lane);
+        }
+        {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
+            const u32x4* w = wp + L.off[2 + k] / 4;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            bias_b3(acc, w, lane);
+            chain_h_b3(acc, x, w + 12 * 64, lane);
+            if (SAVE) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[T][r] = nvp_sin(acc[T][r]) * hm[T][r];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) nvp_pin(x[T]);
+        }
+    }
+    // ---- last layer (3 x 128, Identity): VALU dot products + cross-half add
+    {
+        const float* w3 = p.last_w;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * T + nvp_frag_row(r, h);
+                const float v = x[T][r];
+                o0 = __fmaf_rn(w3[row], v, o0);
+                o1 = __fmaf_rn(w3[NVP_H + row], v, o1);
+                o2 = __fmaf_rn(w3[2 * NVP_H + row], v, o2);
+            }
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
+            NVP_LOAD_FENCE();
+        }
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        if (h == 0 && px < n) {
+            rgb[px * 3 + 0] = o0 + p.last_b[0];
+            rgb[px * 3 + 1] = o1 + p.last_b[1];
+            rgb[px * 3 + 2] = o2 + p.last_b[2];
+        }
+    }
+}
+
+}  // namespace
+
+// called by nvp_mlp_fwd (mlp_fwd.hip) when NVP_FWD_B3 is on and the latent has <= 128 rows
+int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
+                          float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
+    const int64_t ntiles = nvp_ntiles(n);
+    dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    const size_t lds = (size_t)kWaves * 1024 * sizeof(float4);      // 64 KB: 128 latent rows per wave
+    const unsigned* pk = reinterpret_cast<const unsigned*>(packed_fwd);
+    if (saved)
+        hipLaunchKernelGGL(mlp_fwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d);
+    else
+        hipLaunchKernelGGL(mlp_fwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}

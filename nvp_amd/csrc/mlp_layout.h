@@ -18,6 +18,10 @@
 #pragma once
 #include "nvp_common.h"
 
+#ifndef NVP_FWD_B3
+#define NVP_FWD_B3 1         // 1: the forward MLP runs on bf16 x 3 split MFMA for latents of <= 128 rows (mlp_fwd_b3.hip)
+#endif
+
 struct NvpFwdLayout {
     int zs;            // z-part steps = rows/2
     int steps[5];      // mod0, mod1, mod2, sir1, sir2
@@ -88,3 +92,31 @@ constexpr int kRecSir0B = 516;        // [128]
 constexpr int kRecFloats = 644;
 constexpr int kRecRowStride = 33;     // LDS transpose tile [128 features][32 px], conflict-free both ways
 constexpr int kRecTileFloats = 128 * kRecRowStride;
+
+// ---- bf16 x 3 split forward ("b3", mlp_fwd_b3.hip) ---------------------------------------------------------
+// Every fp32 operand is written as hi + mid + lo bf16 (8 + 8 + 8 mantissa bits) and the six products >= 2^-24
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (profiles/r01_probe_bf16x3_split_chain.txt: 1.8x the
+// fp32 MFMA skeleton, error below that of an fp32 fma chain).  One k-step covers 16 inputs: lane (i, h) supplies
+// A[out 32T'+i][k = 8h + q], q = 0..7, as one 16-B register quad per part.  Packed stream, in u32x4 units:
+//        stream[((step*4 + T')*3 + part)*64 + lane]          part 0 hi, 1 mid, 2 lo
+// Steps of a layer: bias step (A[.][k=0] = b, B = e_0), then 8 steps per 128 chained inputs with
+//        in(c, h, q) = 32 (c>>1) + 8 (2 (c&1) + (q>>2)) + 4 h + (q&3)        (= the D registers 8(c&1)..+7 of tile c>>1)
+// then, for the modulator layers, 8 latent steps with in(s, h, q) = 16 s + 8 h + q (zero beyond D).
+struct NvpFwdLayoutB3 {
+    int steps[5];      // mod0, mod1, mod2, sir1, sir2
+    int64_t off[6];    // u32 offsets, off[5] = total
+};
+constexpr int kB3StepU32 = 4 * 3 * 64 * 4;       // u32 per k-step (12 KiB)
+
+__host__ __device__ inline bool nvp_fwd_b3_ok(int d) { return ((d + 3) & ~3) <= 128; }
+
+__host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3() {
+    NvpFwdLayoutB3 L;
+    L.steps[0] = 1 + 8; L.steps[1] = 1 + 8 + 8; L.steps[2] = 1 + 8 + 8; L.steps[3] = 1 + 8; L.steps[4] = 1 + 8;
+    int64_t o = 0;
+    for (int i = 0; i < 5; ++i) { L.off[i] = o; o += (int64_t)L.steps[i] * kB3StepU32; }
+    L.off[5] = o;
+    return L;
+}
+
+__host__ __device__ inline int nvp_b3_chain_in(int c, int h, int q) { return 32 * (c >> 1) + 8 * (2 * (c & 1) + (q >> 2)) + 4 * h + (q & 3); }

@@ -41,6 +41,62 @@ __global__ __launch_bounds__(256) void pack_fwd_kernel(nvp_mlp_params p, float* 
     out[idx] = v;
 }
 
+__device__ __forceinline__ unsigned nvp_bf16_rne(float f) {           // bf16 bits of f, round to nearest even (finite inputs)
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// bf16 x 3 forward stream (mlp_layout.h "b3"): one thread per packed u32 = two consecutive k of one part
+__global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
+    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3();
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L.off[5]) return;
+    int seg = 0;
+    while (idx >= L.off[seg + 1]) ++seg;
+    const int64_t loc = idx - L.off[seg];
+    const int pr = (int)(loc & 3);                 // which pair of the lane's eight k
+    const int lane = (int)((loc >> 2) & 63);
+    const int part = (int)((loc >> 8) % 3);
+    const int tp = (int)(((loc >> 8) / 3) & 3);
+    const int step = (int)((loc >> 8) / 12);
+    const int i = lane & 31, h = lane >> 5;
+    const int out_row = 32 * tp + i;
+    const float* W; const float* b; int ld; bool has_h, has_z;
+    switch (seg) {
+        case 0: W = p.mod_w[0]; b = p.mod_b[0]; ld = d; has_h = false; has_z = true; break;
+        case 1: W = p.mod_w[1]; b = p.mod_b[1]; ld = NVP_H + d; has_h = true; has_z = true; break;
+        case 2: W = p.mod_w[2]; b = p.mod_b[2]; ld = NVP_H + d; has_h = true; has_z = true; break;
+        case 3: W = p.sir_w[1]; b = p.sir_b[1]; ld = NVP_H; has_h = true; has_z = false; break;
+        default: W = p.sir_w[2]; b = p.sir_b[2]; ld = NVP_H; has_h = true; has_z = false; break;
+    }
+    unsigned packed = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = 2 * pr + e;
+        float v = 0.f;
+        if (step == 0) {
+            if (h == 0 && q == 0) v = b[out_row];
+        } else {
+            const int s = step - 1;
+            if (has_h && s < 8) {
+                v = W[(int64_t)out_row * ld + nvp_b3_chain_in(s, h, q)];
+            } else if (has_z) {
+                const int in = 16 * (has_h ? s - 8 : s) + 8 * h + q;
+                if (in < d) v = W[(int64_t)out_row * ld + (has_h ? NVP_H : 0) + in];
+            }
+        }
+        // hi / mid / lo with the same rounding the kernel applies to activations
+        const unsigned hi = nvp_bf16_rne(v);
+        const float r1 = v - __uint_as_float(hi << 16);
+        const unsigned mid = nvp_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float(mid << 16);
+        const unsigned lo = nvp_bf16_rne(r2);
+        const unsigned bits = part == 0 ? hi : (part == 1 ? mid : lo);
+        packed |= (bits & 0xffffu) << (16 * e);
+    }
+    out[idx] = packed;
+}
+
 __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* __restrict__ out, int d) {
     const NvpBwdLayout L = nvp_bwd_layout(d);
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -73,7 +129,7 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* 
 
 extern "C" {
 
-int64_t nvp_packed_fwd_floats(int32_t d) { return nvp_fwd_layout(d).off[5]; }
+int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3().off[5] : nvp_fwd_layout(d).off[5]; }
 int64_t nvp_packed_bwd_floats(int32_t d) { return nvp_bwd_layout(d).off[7]; }
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
@@ -85,6 +141,12 @@ const char* nvp_version(void) { return "nvp_hip 0.1 (gfx950)"; }
 
 int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
+    if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
+        const int64_t nb = nvp_fwd_layout_b3().off[5];
+        hipLaunchKernelGGL(pack_fwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
+        NVP_LAUNCH_CHECK();
+        return 0;
+    }
     int64_t n = nvp_fwd_layout(d).off[5];
     hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, packed, d);
     NVP_LAUNCH_CHECK();

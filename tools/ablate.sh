@@ -4,11 +4,8 @@ set -euo pipefail
 cd "$(dirname "$0")/../nvp_amd/csrc"
 OUT=../../tools/bin; mkdir -p $OUT; rm -f $OUT/libmlp_*.so
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed"
-build() { name=$1; shift; for f in mlp_fwd mlp_bwd mlp_dw mlp_pack; do hipcc $FL "$@" -c $f.hip -o $OUT/${f}_$name.o; done; hipcc --offload-arch=gfx950 -shared -fPIC $OUT/mlp_fwd_$name.o $OUT/mlp_bwd_$name.o $OUT/mlp_dw_$name.o $OUT/mlp_pack_$name.o -o $OUT/libmlp_$name.so; }
-build a_base &
-build b_spread1 -DNVP_STAGGER_SPREAD=1 &
-build c_spread2 -DNVP_STAGGER_SPREAD=2 &
-build d_sleeps8 -DNVP_STAGGER_SLEEPS=8 &
-build e_sleeps16 -DNVP_STAGGER_SLEEPS=16 &
+build() { name=$1; shift; objs=""; for f in mlp_fwd mlp_fwd_b3 mlp_bwd mlp_dw mlp_pack; do hipcc $FL "$@" -c $f.hip -o $OUT/${f}_$name.o; objs="$objs $OUT/${f}_$name.o"; done; hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT/libmlp_$name.so; }
+build a_fp32 &
+build b_b3 -DNVP_FWD_B3=1 &
 wait
 ls $OUT/libmlp_*.so | wc -l
