@@ -1,0 +1,87 @@
+// bf16 x 3 split-MFMA helpers shared by mlp_fwd_b3.hip and mlp_bwd_b3.hip (see mlp_layout.h, "b3").
+#pragma once
+#include "mlp_chain.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32, round to nearest even
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// 8 floats -> hi / mid / lo bf16x8 with x = hi + mid + lo to ~2^-25 |x|
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = x[2 * p], b = x[2 * p + 1];
+        const unsigned h = pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        hi[p] = h; mid[p] = m; lo[p] = pk_bf16(sa, sb);
+    }
+}
+__device__ __forceinline__ f32x16 mf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// one k-step (16 inputs) into the four output tiles; w points at the step's 12 operand quads.  PF: prefetch the next
+// tile's three quads while the current tile's six MFMAs issue (24 instead of 12 operand registers).
+template <bool PF = true>
+__device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+    const unsigned ul = (unsigned)lane;
+    u32x4 a[2][3];
+    if (PF) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        if (PF) {
+            if (T < 3) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[T & 1][q] = (w + (T * 3 + q) * 64)[ul];
+        }
+        NVP_CHAIN_FENCE();
+        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
+        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
+        acc[T] = mf(ah, bl, acc[T]);
+        acc[T] = mf(am, bm, acc[T]);
+        acc[T] = mf(am, bh, acc[T]);
+        acc[T] = mf(ah, bm, acc[T]);
+        acc[T] = mf(ah, bh, acc[T]);
+    }
+}
+
+// bias step: B = e_0 (1.0 at k = 0, exact in bf16), A[.][0] = hi/mid/lo of the bias
+__device__ __forceinline__ void bias_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, int lane) {
+    const unsigned ul = (unsigned)lane;
+    const u32x4 e0 = {lane < 32 ? 0x00003f80u : 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const u32x4 ah = (w + (T * 3 + 0) * 64)[ul], am = (w + (T * 3 + 1) * 64)[ul], al = (w + (T * 3 + 2) * 64)[ul];
+        acc[T] = mf(al, e0, acc[T]);
+        acc[T] = mf(am, e0, acc[T]);
+        acc[T] = mf(ah, e0, acc[T]);
+    }
+}
+
+// 8 k-steps over the previous layer's D registers
+template <bool PF = true>
+__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3<PF>(acc, w + c * 12 * 64, bh, bm, bl, lane);
+    }
+}
+

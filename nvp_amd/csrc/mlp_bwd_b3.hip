@@ -1,56 +1,24 @@
-// Backward of the modulator MLP + modulated SIREN w.r.t. activations (the "dX chain" of
-// R12): from dL/drgb produce the latent gradient, the five per-pixel dY streams the
-// weight-gradient GEMMs (mlp_dw.hip) contract over the pixel axis, and - already reduced over
-// the tile's 32 pixels - the gradients of the two tiny layers (last layer, SIREN layer 0).
-//
-// Same structure as mlp_fwd.hip: one wavefront = one 32-pixel tile, every transposed GEMM
-//   dX[in][pixel] = sum_out W[out][in] * dY[out][pixel]
-// runs on v_mfma_f32_32x32x2_f32 with A = packed W^T stream and B = the dY registers that
-// the previous stage just produced; nothing is staged through LDS.  Two kernels, both at two
-// waves per SIMD so one wave's element-wise / memory phases hide behind the other's MFMAs:
-// the chain kernel (dq, dp, one accumulator: <= 256 registers) and the latent-gradient
-// kernel, which re-reads the three dp streams it needs (an extra 1.5 KB/px of warm reads).
-//
-// Chain (forward names: p_k modulator pre-activation, h_k = lrelu(p_k), q_k SIREN
-// pre-sine, x_k = sin(q_k) h_k, q_0 = 30 (w s + c)):
-//   dx2 = V3^T drgb
-//   dq_k = dx_k h_k cos(q_k);  dh_k (+)= dx_k sin(q_k);  dp_k = dh_k lrelu'(p_k)
-//   dx_{k-1} = V_k^T dq_k;     dh_{k-1} = W_k[:, :128]^T dp_k;   dz += W_k[:, 128:]^T dp_k
-// Bound: fp32 MFMA nominally (219 392 FLOP/px, nvp_s), in practice HBM WRITE bandwidth: the six
-// dY streams are 3 KB/px out on top of 2.5 KB/px in.  The modulated sine outputs x_k are therefore NOT
-// written: the dW kernel rebuilds x_k = sin(q_k) h_k from the forward pass's saved streams.
-#include "mlp_chain.h"
+// Backward dX chain + latent gradient + per-tile records (see mlp_bwd.hip, whose structure this kernel shares line
+// for line) with every transposed GEMM on **bf16 x 3 split MFMA** (mlp_b3.h): dq / dp are split into hi + mid + lo
+// bf16 on the fly, the transposed weights come pre-split from pack_bwd_b3_kernel, six products per k-step are
+// accumulated in fp32.  Used for latents of <= 128 rows when the library is built with NVP_BWD_B3=1.
+#include "mlp_b3.h"
+
+#ifndef NVP_BWD_B3_PF
+#define NVP_BWD_B3_PF true       // operand prefetch inside a k-step (costs a few more spilled registers, measured 2.76 vs 2.83 ms)
+#endif
 
 namespace {
 
 constexpr int kWaves = 4;
 
-// saved-activation loads of the element-wise stages (ablation hook: NVP_ABL_NOELOAD takes them from a register)
 __device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ tile_base, int T, int lane) {
-#ifdef NVP_ABL_NOELOAD
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = 0.25f + 0.001f * (float)(lane + T);
-#else
     load_ptm16(v, tile_base, T, lane);
-#endif
 }
 
-// ------------------------------------------------------------------------------------------
-// Kernel A: the dX chain without the latent gradient.  Register plan (2 waves/SIMD, <= 256):
-//   dx[4], dh[4] (128) are rewritten in place into dq, dp by the element-wise stage, then
-//   dx' = chain(dq) needs one 64-register accumulator (192 live), after which dq is dead and
-//   dh' = chain(dp) reuses the space.
-// ------------------------------------------------------------------------------------------
-// FUSE_DZ (latent <= 128 rows, i.e. one 64-register accumulator): the latent gradient
-//   dz = W2[:,128:]^T dp2 + W1[:,128:]^T dp1 + W0^T dp0
-// is accumulated by this kernel as a third chain per layer, straight from the dp registers, instead of by
-// mlp_bwd_dz_kernel re-reading the three dp streams (1.5 KB/px).  Its accumulator does not fit next to
-// dx/dh/acc, so between layers it is parked in the wave's LDS tile (free while the chains run: x2 is consumed
-// before the layer-2 chains, dq0 is written after the accumulator has been fetched back for layer 0).
-template <bool FUSE_DZ>
-__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
-                                                                    const float* __restrict__ packed,
+                                                                    const unsigned* __restrict__ packed,
                                                                     float* __restrict__ dy, float* __restrict__ dzr,
                                                                     int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
@@ -58,14 +26,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
     if (tile >= ntiles) return;                       // wave-uniform
     nvp_stagger_start();
     const int j = lane & 31, h = lane >> 5;
-    const NvpBwdLayout L = nvp_bwd_layout(d);
     const int64_t px = tile * 32 + j;
     const bool valid = px < n;
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
     const int64_t tb = tile * (int64_t)NVP_H * 32;
     const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
     float* dyt = dy + tb;                  // dp0,dp1,dp2,(records),dq1,dq2
-    const float4* wp = reinterpret_cast<const float4*>(packed);
+    const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
 
     // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
     // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
@@ -159,10 +126,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         f32x16 acc[4];
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h<2>(acc, dx, wp + L.off[2 - k] / 4, lane);          // streams 0 (sir2^T), 1 (sir1^T)
+        chain_h_b3<NVP_BWD_B3_PF>(acc, dx, wp + nvp_bwd_b3_off(2 - k) / 4, lane);   // streams 0 (sir2^T), 1 (sir1^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
-        if (FUSE_DZ) {
+        {
             // dz += W_k[:, 128:]^T dp_k; the accumulator lives in LDS between layers (see above)
             float4* park = reinterpret_cast<float4*>(xl);
             if (k == 2) {
@@ -177,7 +144,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
                         acc[T][4 * g] = t.x; acc[T][4 * g + 1] = t.y; acc[T][4 * g + 2] = t.z; acc[T][4 * g + 3] = t.w;
                     }
             }
-            chain_hz<4>(acc, dh, packed + L.off[4 + k], lane);     // streams 6 (z2^T), 5 (z1^T)
+            chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 + k) / 4, lane);   // streams 6 (z2^T), 5 (z1^T)
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -188,7 +155,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         // dh_{k-1} = W_k[:, :128]^T dp_k
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h<2>(acc, dh, wp + L.off[4 - k] / 4, lane);          // streams 2 (mod2h^T), 3 (mod1h^T)
+        chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 - k) / 4, lane);   // streams 2 (mod2h^T), 3 (mod1h^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
     }
@@ -218,7 +185,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         for (int T = 0; T < 4; ++T) {
             f32x16 hn;
             if (T < 3) load_act16(hn, h0, T + 1, lane);
-            if (FUSE_DZ) {
+            {
                 if (T == 0) fetch_dz(0);
                 if (T < 3) fetch_dz(T + 1);
             }
@@ -254,10 +221,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
         }
         rec[kRecSir0W + lane] = wl; rec[kRecSir0W + 64 + lane] = wh;
         rec[kRecSir0B + lane] = cl; rec[kRecSir0B + 64 + lane] = ch;
-        if (FUSE_DZ) {
+        {
             // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
             NVP_LOAD_FENCE();
-            chain_hz<4>(dzacc, dh, packed + L.off[4], lane);       // stream 4 (z0^T)
+            chain_h_b3<NVP_BWD_B3_PF>(dzacc, dh, wp + nvp_bwd_b3_off(4) / 4, lane);     // stream 4 (z0^T)
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
 #pragma unroll
@@ -272,90 +239,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dx_kernel(const float*
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Kernel Z: latent gradient  dz = W0^T dp0 + W1[:,128:]^T dp1 + W2[:,128:]^T dp2, reading the
-// three dp streams the chain kernel just wrote (L2/MALL-warm).  Output ROW-MAJOR
-// [pixel][stride] (stride = D rounded up to 4): a lane owns 4 consecutive features per
-// register group -> one 16-B store; the scatter stage gathers a pixel's features as
-// contiguous 128-B runs.
-// ------------------------------------------------------------------------------------------
-template <int ZT>
-__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_kernel(const float* __restrict__ dy, const float* __restrict__ packed,
-                                                                    float* __restrict__ dzr, int64_t ntiles, int d) {
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
-    if (tile >= ntiles) return;
-    nvp_stagger_start();
-    const int j = lane & 31, h = lane >> 5;
-    const NvpBwdLayout L = nvp_bwd_layout(d);
-    const int64_t act = ntiles * (int64_t)NVP_H * 32;
-    const float* dyt = dy + tile * (int64_t)NVP_H * 32;
-
-    f32x16 dz[ZT];
-#pragma unroll
-    for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
-
-    f32x16 b[4];
-#pragma unroll
-    for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + 2 * act, T, lane);
-#pragma unroll
-    for (int k = 2; k >= 0; --k) {
-        f32x16 nb[4];
-        if (ZT == 4 && k > 0) {             // prefetch the next dp stream while this one is consumed
-#pragma unroll
-            for (int T = 0; T < 4; ++T) load_ptm16(nb[T], dyt + (int64_t)(k - 1) * act, T, lane);
-        }
-        NVP_LOAD_FENCE();
-        chain_hz<ZT>(dz, b, packed + L.off[4 + k], lane);       // streams 6 (z2^T), 5 (z1^T), 4 (z0^T)
-        if (k > 0) {
-            if (ZT == 4) {
-#pragma unroll
-                for (int T = 0; T < 4; ++T) b[T] = nb[T];
-            } else {
-#pragma unroll
-                for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + (int64_t)(k - 1) * act, T, lane);
-            }
-        }
-    }
-    const int stride = nvp_dz_stride_dev(d);
-    float* o = dzr + (tile * 32 + j) * stride;
-#pragma unroll
-    for (int T = 0; T < ZT; ++T)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int base = 32 * T + 8 * g + 4 * h;
-            if (base < stride)
-                *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
-        }
-}
-
 }  // namespace
 
+// called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on and the latent has <= 128 rows
 int nvp_mlp_bwd_b3_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                          const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream);   // mlp_bwd_b3.hip
-
-extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                              const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
-    if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
-    if (n == 0) return 0;
-    if (NVP_BWD_B3 && nvp_fwd_b3_ok(d)) return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
+                          const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
-    const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
-    if (zt != 4 && zt != 8) return NVP_ERR_UNSUPPORTED;       // latent wider than 256 rows (n_features_per_level = 8)
     const size_t lds = kWaves * kRecTileFloats * sizeof(float);
-#ifndef NVP_BWD_FUSE_DZ
-#define NVP_BWD_FUSE_DZ 1
-#endif
-    if (zt == 4 && NVP_BWD_FUSE_DZ) {
-        hipLaunchKernelGGL(mlp_bwd_dx_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, dz_rows, n, ntiles, d);
-    } else {
-        hipLaunchKernelGGL(mlp_bwd_dx_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, packed_bwd, dy, dz_rows, n, ntiles, d);
-        if (zt == 4)
-            hipLaunchKernelGGL(mlp_bwd_dz_kernel<4>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
-        else
-            hipLaunchKernelGGL(mlp_bwd_dz_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, packed_bwd, dz_rows, ntiles, d);
-    }
+    hipLaunchKernelGGL(mlp_bwd_b3_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p,
+                       reinterpret_cast<const unsigned*>(packed_bwd), dy, dz_rows, n, ntiles, d);
     NVP_LAUNCH_CHECK();
     return 0;
 }

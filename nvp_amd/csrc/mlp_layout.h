@@ -18,6 +18,9 @@
 #pragma once
 #include "nvp_common.h"
 
+#ifndef NVP_BWD_B3
+#define NVP_BWD_B3 1         // 1: the backward chain (dX + latent gradient) too (mlp_bwd_b3.hip)
+#endif
 #ifndef NVP_FWD_B3
 #define NVP_FWD_B3 1         // 1: the forward MLP runs on bf16 x 3 split MFMA for latents of <= 128 rows (mlp_fwd_b3.hip)
 #endif
@@ -120,3 +123,7 @@ __host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3() {
 }
 
 __host__ __device__ inline int nvp_b3_chain_in(int c, int h, int q) { return 32 * (c >> 1) + 8 * (2 * (c & 1) + (q >> 2)) + 4 * h + (q & 3); }
+
+// Backward b3 streams (A = W^T: row i = INPUT index 32T' + i, k = OUTPUT index nvp_b3_chain_in(c, h, q)), 8 steps each,
+// no bias step: 0 sir2^T, 1 sir1^T, 2 mod2h^T, 3 mod1h^T, 4 z0^T, 5 z1^T, 6 z2^T (latent rows beyond D are zero).
+__host__ __device__ inline int64_t nvp_bwd_b3_off(int stream) { return (int64_t)stream * 8 * kB3StepU32; }

@@ -97,6 +97,44 @@ __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsi
     out[idx] = packed;
 }
 
+// bf16 x 3 backward streams (mlp_layout.h): one thread per packed u32
+__global__ __launch_bounds__(256) void pack_bwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nvp_bwd_b3_off(7)) return;
+    const int seg = (int)(idx / nvp_bwd_b3_off(1));
+    const int64_t loc = idx - nvp_bwd_b3_off(seg);
+    const int pr = (int)(loc & 3);
+    const int lane = (int)((loc >> 2) & 63);
+    const int part = (int)((loc >> 8) % 3);
+    const int tp = (int)(((loc >> 8) / 3) & 3);
+    const int step = (int)((loc >> 8) / 12);
+    const int i = lane & 31, h = lane >> 5;
+    const int in = 32 * tp + i;                    // A row = input index
+    unsigned packed = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int o = nvp_b3_chain_in(step, h, 2 * pr + e);        // k = output index
+        float v = 0.f;
+        switch (seg) {
+            case 0: v = p.sir_w[2][(int64_t)o * NVP_H + in]; break;
+            case 1: v = p.sir_w[1][(int64_t)o * NVP_H + in]; break;
+            case 2: v = p.mod_w[2][(int64_t)o * (NVP_H + d) + in]; break;
+            case 3: v = p.mod_w[1][(int64_t)o * (NVP_H + d) + in]; break;
+            case 4: if (in < d) v = p.mod_w[0][(int64_t)o * d + in]; break;
+            case 5: if (in < d) v = p.mod_w[1][(int64_t)o * (NVP_H + d) + NVP_H + in]; break;
+            default: if (in < d) v = p.mod_w[2][(int64_t)o * (NVP_H + d) + NVP_H + in]; break;
+        }
+        const unsigned hi = nvp_bf16_rne(v);
+        const float r1 = v - __uint_as_float(hi << 16);
+        const unsigned mid = nvp_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float(mid << 16);
+        const unsigned lo = nvp_bf16_rne(r2);
+        const unsigned bits = part == 0 ? hi : (part == 1 ? mid : lo);
+        packed |= (bits & 0xffffu) << (16 * e);
+    }
+    out[idx] = packed;
+}
+
 __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* __restrict__ out, int d) {
     const NvpBwdLayout L = nvp_bwd_layout(d);
     int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -130,7 +168,7 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* 
 extern "C" {
 
 int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3().off[5] : nvp_fwd_layout(d).off[5]; }
-int64_t nvp_packed_bwd_floats(int32_t d) { return nvp_bwd_layout(d).off[7]; }
+int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_bwd_b3_off(7) : nvp_bwd_layout(d).off[7]; }
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
     return nvp_param_layout(d).total * (int64_t)n_chunks;       // one full gradient record per pixel chunk
@@ -155,6 +193,12 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
 
 int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
+    if (NVP_BWD_B3 && nvp_fwd_b3_ok(d)) {
+        const int64_t nb = nvp_bwd_b3_off(7);
+        hipLaunchKernelGGL(pack_bwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
+        NVP_LAUNCH_CHECK();
+        return 0;
+    }
     int64_t n = nvp_bwd_layout(d).off[7];
     hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, packed, d);
     NVP_LAUNCH_CHECK();
