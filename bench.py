@@ -218,6 +218,8 @@ def main():
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the forward / backward-chain GEMMs issue each fp32 product as six "
+                          "bf16 MFMA products of hi+mid+lo operand splits (error below an fp32 fma chain, DESIGN.md 4.1a); dW GEMMs: fp32 MFMA",
             "config": {"workload": ("configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s, " if args.config == "s" else
                                     "configs[2] geometry: 1920x1080x300 synthetic u8 RGB video, config_nvp_l, ") +
                                    f"{N_PX} (t,x,y) samples per GPU per step, random-init parameters",
