@@ -44,8 +44,19 @@ __device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restric
                 for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
             }
         } else {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a[T & 1][q] = (w + (T * 3 + q) * 64)[ul];
+            // register-lean order: lo first (one use), then mid, then hi; at most two operand quads are live
+            const u32x4 al = (w + (T * 3 + 2) * 64)[ul];
+            const u32x4 am = (w + (T * 3 + 1) * 64)[ul];
+            NVP_CHAIN_FENCE();
+            acc[T] = mf(al, bh, acc[T]);
+            acc[T] = mf(am, bm, acc[T]);
+            const u32x4 ah = (w + (T * 3 + 0) * 64)[ul];
+            acc[T] = mf(am, bh, acc[T]);
+            NVP_CHAIN_FENCE();
+            acc[T] = mf(ah, bl, acc[T]);
+            acc[T] = mf(ah, bm, acc[T]);
+            acc[T] = mf(ah, bh, acc[T]);
+            continue;
         }
         NVP_CHAIN_FENCE();
         const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];

@@ -152,7 +152,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
                     park[(T * 4 + g) * 64 + lane] = make_float4(acc[T][4 * g], acc[T][4 * g + 1], acc[T][4 * g + 2], acc[T][4 * g + 3]);
             NVP_LOAD_FENCE();
         }
-        // dh_{k-1} = W_k[:, :128]^T dp_k
+        // dh_{k-1} = W_k[:, :128]^T dp_k.  The pins make dp opaque again: otherwise hipcc keeps the 96 registers of
+        // hi/mid/lo parts it computed for the dz chain alive for this one and spills them (1.8 GB of scratch traffic
+        // per step); re-splitting costs 352 VALU operations.
+#pragma unroll
+        for (int T = 0; T < 4; ++T) nvp_pin(dh[T]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
         chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 - k) / 4, lane);   // streams 2 (mod2h^T), 3 (mod1h^T)
