@@ -144,3 +144,21 @@ def test_branch_free_sincos_constants_are_accurate():
     sn = np.where(q & 2, -s0, s0); cs = np.where((q + 1) & 2, -c0, c0)
     assert np.abs(sn - np.sin(x.astype(np.float64))).max() < 2e-7
     assert np.abs(cs - np.cos(x.astype(np.float64))).max() < 2e-7
+
+
+def test_sin_only_polynomial_is_accurate():
+    """Host emulation of nvp_sin (forward pass / dW staging): reduction by pi + one degree-9 odd polynomial."""
+    f = np.float32
+
+    def fma(a, b, c):
+        return f(np.float64(a) * np.float64(b) + np.float64(c))
+
+    x = ((np.random.default_rng(1).random(400000) * 2 - 1) * 1000).astype(f)
+    n = np.rint(x * f(0.318309886)).astype(f)
+    r = fma(n, f(-3.14159274), x)
+    r = fma(n, f(8.74227766e-08), r)
+    r2 = (r * r).astype(f)
+    p = fma(r2, f(2.6000545605e-06), f(-1.9806615092e-04)); p = fma(p, r2, f(8.3330172897e-03)); p = fma(p, r2, f(-1.6666657096e-01))
+    sn = fma((p * r2).astype(f), r, r)
+    sn = np.where(n.astype(np.int64) & 1, -sn, sn)
+    assert np.abs(sn - np.sin(x.astype(np.float64))).max() < 2e-7
