@@ -138,7 +138,10 @@ int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t 
 /* ---- R8-R10: SirenWrapper.forward = Modulator + modulated SirenNet
  * (reference modulation.py:138-145, 112-121, 83-92).
  * pack: re-lays the 14 tensors out as MFMA A-operand streams (call after every
- *       optimizer step; ~0.5 MB).
+ *       optimizer step; 0.4-0.8 MB).  The packed buffers are opaque: their size is
+ *       nvp_packed_{fwd,bwd}_floats(latent_dim) and their format is whatever the fwd /
+ *       bwd_dx kernels of this build consume (fp32 k-steps, or hi/mid/lo bf16 operand
+ *       quads for the bf16x3 split-MFMA kernels used when the latent has <= 128 rows).
  * fwd : zt PTM latent, steps [N] -> rgb [N,3] row-major; `saved` receives the five
  *       activations backward needs (h0,h1,h2 post-LeakyReLU, q1,q2 pre-sine), each PTM
  *       [ntiles][128][32]; pass NULL for inference (nothing is stored). */
