@@ -132,8 +132,9 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
         functional.GRAD_SINK = None
         functional.GRIDS_READY_HOOK = None
     if bucket is not None and isinstance(opt, AdamW):
-        bucket.all_reduce(scale=False)              # SUM only; the 1/world factor is applied inside the AdamW kernel
-        opt.step(grad_scale=1.0 / bucket.world_size())
+        # SUM all-reduce in pieces (the grid pieces are already in flight); AdamW updates each piece as its collective
+        # completes, 1/world applied inside the kernel
+        opt.step(grad_scale=1.0 / bucket.world_size(), schedule=bucket.step_schedule())
     else:
         if bucket is not None:
             bucket.all_reduce_mean()                # copies back only if some grad did not land in the bucket

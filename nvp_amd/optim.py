@@ -23,16 +23,20 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, schedule=None):
         """One AdamW update.  `grad_scale` multiplies every gradient inside the kernel (data parallel: 1/world
-        after a SUM all-reduce of the flat gradient, which saves a separate scaling pass over 543 MB)."""
+        after a SUM all-reduce of the flat gradient, which saves a separate scaling pass over 543 MB).
+        `schedule` (parallel.GradBucket.step_schedule()): [(wait, [(param, a, b), ...]), ...] - for each entry
+        wait() is called (the current stream then waits for that piece of the gradient all-reduce) and elements
+        [a, b) of those parameters are updated, so the update of one piece overlaps the collective of the next.
+        Parameters (or parts) the schedule does not mention are updated last."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
+        info = {}                                   # id(param) -> (param, group, step, covered ranges)
         for group in self.param_groups:
-            by_step = {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -44,12 +48,42 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                seg = _lib.AdamwSeg(_lib.ptr(p), _lib.ptr(p.grad), _lib.ptr(st["exp_avg"]), _lib.ptr(st["exp_avg_sq"]), p.numel())
-                by_step.setdefault(int(st["step"]), []).append(seg)
-            b1, b2 = group["betas"]
-            for step, segs in by_step.items():
+                for t in (p, p.grad, st["exp_avg"], st["exp_avg_sq"]):
+                    _lib.ptr(t)                     # loud errors for CPU / non-contiguous tensors
+                info[id(p)] = (p, group, int(st["step"]), [])
+
+        def launch(items):
+            """items: [(param, a, b)] -> one kernel launch per (group, step) combination"""
+            buckets = {}
+            for p, a, b in items:
+                ent = info.get(id(p))
+                if ent is None or a >= b:
+                    continue
+                _, group, step, cov = ent
+                cov.append((a, b))
+                st = self.state[p]
+                seg = _lib.AdamwSeg(p.data_ptr() + 4 * a, p.grad.data_ptr() + 4 * a, st["exp_avg"].data_ptr() + 4 * a,
+                                    st["exp_avg_sq"].data_ptr() + 4 * a, b - a)
+                buckets.setdefault((id(group), step), (group, step, []))[2].append(seg)
+            for group, step, segs in buckets.values():
+                b1, b2 = group["betas"]
                 arr = (_lib.AdamwSeg * len(segs))(*segs)
                 _lib.check(lib.nvp_adamw_step(arr, len(segs), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                               float(group["weight_decay"]), step, float(grad_scale), _lib.stream_ptr()),
                            "nvp_adamw_step")
+
+        for wait, items in (schedule or []):
+            wait()
+            launch(items)
+        # whatever the schedule did not cover (everything, without a schedule)
+        rest = []
+        for p, group, step, cov in info.values():
+            pos = 0
+            for a, b in sorted(cov):
+                if a > pos:
+                    rest.append((p, pos, a))
+                pos = max(pos, b)
+            if pos < p.numel():
+                rest.append((p, pos, p.numel()))
+        launch(rest)
         return loss

@@ -44,7 +44,8 @@ def unique_parameters(module: torch.nn.Module) -> List[torch.nn.Parameter]:
 class GradBucket:
     """All gradients of a module as views into one flat fp32 buffer + the per-step all-reduce."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], early: Optional[Iterable[torch.nn.Parameter]] = None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], early: Optional[Iterable[torch.nn.Parameter]] = None,
+                 chunk_elems: int = 32 * 1024 * 1024):
         """`early`: parameters whose gradients are complete before the rest of backward has run (NVP's four
         grids: 99.9 % of the bytes).  If they occupy one contiguous range of the flat buffer, their all-reduce
         can be started early and asynchronously (`start_early`) and overlaps the remaining backward kernels."""
@@ -64,7 +65,13 @@ class GradBucket:
             off += p.numel()
         self.attach()
         self._early_range = None
-        self._early_work = None
+        self._early_work = None          # list of (lo, hi, work) once start_early() has run
+        self.chunk_elems = int(chunk_elems)          # the early range is reduced in pieces of <= this many elements (128 MB)
+        self._offsets = []
+        o = 0
+        for p in self.params:
+            self._offsets.append(o)
+            o += p.numel()
         if early is not None:
             ids = {id(p) for p in early}
             offs, o = [], 0
@@ -77,14 +84,63 @@ class GradBucket:
                 if sum(b - a for a, b in offs) == hi - lo:            # contiguous: nothing else in between
                     self._early_range = (lo, hi)
 
+    def early_chunks(self) -> list:
+        """[(lo, hi)] pieces of the early range, each <= chunk_elems elements."""
+        if self._early_range is None:
+            return []
+        lo, hi = self._early_range
+        step = max(1, self.chunk_elems)
+        return [(a, min(a + step, hi)) for a in range(lo, hi, step)]
+
     def start_early(self) -> None:
-        """Asynchronous all-reduce of the early range (call once its gradients are enqueued on the current
-        stream; torch.distributed orders the collective after that work).  No-op without a process group."""
+        """Asynchronous all-reduces of the early range, piece by piece (call once its gradients are enqueued on the
+        current stream; torch.distributed orders the collectives after that work).  Pieces let the optimizer update
+        the parameters of piece i while piece i+1 is still on the wire (`step_schedule`).  No-op without a group."""
         if self._early_range is None or self._early_work is not None:
             return
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            lo, hi = self._early_range
-            self._early_work = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            self._early_work = [(a, b, dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
+                                for a, b in self.early_chunks()]
+
+    def _join_early(self) -> None:
+        if self._early_work is not None:
+            for _, _, w in self._early_work:
+                w.wait()
+            self._early_work = None
+
+    def params_in(self, lo: int, hi: int) -> list:
+        """[(param, a, b)]: the sub-ranges [a, b) (in elements of each parameter) that flat range [lo, hi) covers."""
+        out = []
+        for p, o in zip(self.params, self._offsets):
+            a, b = max(lo, o), min(hi, o + p.numel())
+            if a < b:
+                out.append((p, a - o, b - o))
+        return out
+
+    def step_schedule(self) -> Optional[list]:
+        """For an optimizer that can update sub-ranges (nvp_amd.optim.AdamW.step(schedule=...)): reduce what is not
+        in flight yet, and return [(wait, [(param, a, b), ...]), ...] in completion order - wait() makes the
+        current stream wait for that piece's collective.  Gradients stay SUMS (the caller passes 1/world as
+        grad_scale).  Returns None for a single process (nothing to wait for)."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        if not self.consistent():
+            self.all_reduce(scale=False)            # repair path: everything reduced synchronously
+            return None
+        sched = []
+        if self._early_work is None:
+            w = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+            return [(w.wait, self.params_in(0, self.numel))]
+        lo, hi = self._early_range
+        rest = []
+        if lo > 0:
+            rest.append((0, lo, dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM, async_op=True)))
+        if hi < self.numel:
+            rest.append((hi, self.numel, dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM, async_op=True)))
+        for a, b, w in self._early_work + rest:      # collectives complete in issue order
+            sched.append((w.wait, self.params_in(a, b)))
+        self._early_work = None
+        return sched
 
     def attach(self) -> None:
         """(Re)bind .grad to the bucket views (after zero_grad(set_to_none=True) or a rebuild)."""
@@ -123,9 +179,7 @@ class GradBucket:
             # a grad tensor was replaced (e.g. zero_grad(set_to_none=True)): copy back into the bucket.
             # An early all-reduce that already ran on stale bucket memory is joined and discarded: the
             # copy below restores the local gradients and the full all-reduce redoes the sum.
-            if self._early_work is not None:
-                self._early_work.wait()
-                self._early_work = None
+            self._join_early()
             for p, v in zip(self.params, self.views):
                 if p.grad is None:
                     v.zero_()
@@ -140,8 +194,7 @@ class GradBucket:
                     dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM)
                 if hi < self.numel:
                     dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM)
-                self._early_work.wait()
-                self._early_work = None
+                self._join_early()
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)       # one collective over the whole gradient
             if scale:

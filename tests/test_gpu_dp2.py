@@ -97,8 +97,8 @@ def _worker(rank, world, port, q):
     model = _model(cfg)
     parallel.broadcast_parameters(model)
     early = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings]
-    bucket = parallel.GradBucket(parallel.unique_parameters(model), early=early)
-    assert bucket._early_range is not None
+    bucket = parallel.GradBucket(parallel.unique_parameters(model), early=early, chunk_elems=3_000_000)   # pieces split tensors
+    assert bucket._early_range is not None and len(bucket.early_chunks()) >= 8
     mine = [halves[rank] for halves in _batches(T, H, W)]
     grads = _grads(model, mine[0], bucket)          # gradient-level check first (no AdamW in between)
     params = _run(model, mine, bucket)

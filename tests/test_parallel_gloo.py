@@ -86,6 +86,26 @@ def _worker(rank, world, port, q):
     for k, p in enumerate(params):
         want_k = sum((r + 1) * (k + 2) for r in range(world)) / world
         assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), k
+    # chunked early reduce + step schedule: pieces cross parameter boundaries, every element is scheduled exactly once,
+    # and after all waits the buffer holds the SUM (the optimizer applies 1/world)
+    b3 = parallel.GradBucket(params, early=early, chunk_elems=1000)
+    assert len(b3.early_chunks()) > 4 and b3.early_chunks()[0][0] == 0 and b3.early_chunks()[-1][1] == b3._early_range[1]
+    for k, p in enumerate(params):
+        p.grad.fill_(float((rank + 1) * (k + 3)))
+    b3.start_early()
+    sched = b3.step_schedule()
+    seen = {id(p): torch.zeros(p.numel(), dtype=torch.int32) for p in params}
+    for wait, items in sched:
+        wait()
+        for p, a, b_ in items:
+            assert 0 <= a < b_ <= p.numel()
+            seen[id(p)][a:b_] += 1
+            off = b3._offsets[[id(q) for q in params].index(id(p))]
+            k = [id(q) for q in params].index(id(p))
+            want_sum = float(sum((r + 1) * (k + 3) for r in range(world)))
+            assert bool((b3.flat[off + a:off + b_] == want_sum).all()), "piece scheduled before its reduce completed"
+    assert all(bool((v == 1).all()) for v in seen.values()), "every element must be scheduled exactly once"
+    assert b3._early_work is None and b3.step_schedule() is not None      # a second call reduces everything again (one piece)
     bucket.attach()
 
     # identical AdamW steps from identical averaged grads keep the replicas bit-identical
