@@ -5,7 +5,7 @@
 #include "mlp_b3.h"
 
 #ifndef NVP_BWD_B3_PF
-#define NVP_BWD_B3_PF true       // operand prefetch inside a k-step (costs a few more spilled registers, measured 2.76 vs 2.83 ms)
+#define NVP_BWD_B3_PF true       // operand prefetch inside a k-step: three more live quads, measured 2.51 vs 2.71 ms
 #endif
 
 namespace {
