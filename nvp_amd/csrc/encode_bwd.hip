@@ -171,61 +171,77 @@ struct PermArgs {
     unsigned* sdzmax;
 };
 
-// one thread = one (sorted position, plane); F floats per level, 128-B contiguous read per plane
+// A workgroup rewrites kPermPix<F> consecutive sorted positions of one plane.  A pixel's segment of this plane in the
+// row-major latent gradient (16 F floats = 128 B for F = 2) is read by NV = 4 F consecutive lanes as ONE coalesced
+// run (a thread-per-pixel loop strides 464 B between lanes and re-fetches every line several times: 1.6 GB of
+// fetch for 0.5 GB of data), transposed through LDS (row stride 16 F + 1: conflict-free both ways), and written
+// level-major with consecutive threads on consecutive pixels (2 KB runs per level).  The same pass takes max|dz|
+// for the plane and, from the last plane's workgroups, over the sparse grid's columns.
+template <int F> struct PermCfg {
+    static constexpr int NV = 16 * F / 4;              // float4 per pixel segment = lanes per pixel
+    static constexpr int PIX = F <= 2 ? 256 : (F == 4 ? 128 : 64);      // pixels per workgroup: LDS tile <= 34 KB
+    static constexpr int STRIDE = 16 * F + 1;
+};
+
 template <int F>
 __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride,
                                                       PermArgs A, unsigned* __restrict__ dzmax, int64_t n) {
+    constexpr int NV = PermCfg<F>::NV, PIX = PermCfg<F>::PIX, STRIDE = PermCfg<F>::STRIDE;
+    constexpr int PPP = 256 / NV;                      // pixels per pass
+    extern __shared__ float tile[];                    // [PIX][STRIDE]
     const int plane = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    float m = 0.f;
-    if (p < n) {
-        const int id = A.order[plane][p];
-        const float* c = coords + (int64_t)id * 3;
-        A.cs[plane][p] = make_float2(c[A.c0[plane]], c[A.c1[plane]]);
-        const float* src = dz + (int64_t)id * dz_stride + A.col0[plane];
-        float* dst = A.dzs[plane];
-        const int nl = A.nlev[plane];
-        // the pixel's row segment of this plane (nl*F <= 16*F floats, 16-B aligned: col0 and dz_stride are
-        // multiples of 4) is fetched with independent 16-B loads first, then streamed out level-major
-        constexpr int NV = 16 * F / 4;
-        float4 seg[NV];
-        const int qmax = (nl * F - 1) >> 2;              // clamp instead of predicating: no branches, no early waits
+    const int64_t p0 = (int64_t)blockIdx.x * PIX;
+    const int t = threadIdx.x;
+    const int nl = A.nlev[plane];
+    const int qmax = (nl * F - 1) >> 2;
+    const int* order = A.order[plane];
+    const int q = t % NV, pp = t / NV;
+    float ms = 0.f;
+    // ---- phase 1: coalesced segment reads -> LDS
 #pragma unroll
-        for (int q = 0; q < NV; ++q) seg[q] = reinterpret_cast<const float4*>(src)[min(q, qmax)];
-#pragma unroll
-        for (int l = 0; l < 16; ++l) {
-            if (l >= nl) break;
-            float v[F];
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const int e = l * F + f;
-                const float4 t = seg[e >> 2];
-                v[f] = (e & 3) == 0 ? t.x : ((e & 3) == 1 ? t.y : ((e & 3) == 2 ? t.z : t.w));
-                m = fmaxf(m, fabsf(v[f]));
+    for (int i = 0; i < PIX / PPP; ++i) {
+        const int pix = i * PPP + pp;
+        const int64_t p = p0 + pix;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < n) {
+            const int id = order[p];
+            if (q <= qmax) v = reinterpret_cast<const float4*>(dz + (int64_t)id * dz_stride + A.col0[plane])[q];
+            if (plane == 2 && 4 * q < A.scols) {       // the sparse columns follow this plane's segment in the same row
+                const float4 sv = reinterpret_cast<const float4*>(dz + (int64_t)id * dz_stride + A.scol0)[q];
+                ms = fmaxf(ms, fmaxf(fmaxf(fabsf(sv.x), fabsf(sv.y)), fmaxf(fabsf(sv.z), fabsf(sv.w))));
             }
+        }
+        float* d = tile + pix * STRIDE + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // ---- phase 2: thread = pixel, level-major stores
+    float m = 0.f;
+    for (int pix = t; pix < PIX; pix += 256) {
+        const int64_t p = p0 + pix;
+        if (p < n) {
+            const int id = order[p];
+            const float* c = coords + (int64_t)id * 3;
+            A.cs[plane][p] = make_float2(c[A.c0[plane]], c[A.c1[plane]]);
+            float* dst = A.dzs[plane];
+            const float* srow = tile + pix * STRIDE;
 #pragma unroll
-            for (int f = 0; f < F; ++f) dst[((int64_t)l * n + p) * F + f] = v[f];
+            for (int l = 0; l < 16; ++l) {
+                if (l >= nl) break;
+                float v[F];
+#pragma unroll
+                for (int f = 0; f < F; ++f) { v[f] = srow[l * F + f]; m = fmaxf(m, fabsf(v[f])); }
+#pragma unroll
+                for (int f = 0; f < F; ++f) dst[((int64_t)l * n + p) * F + f] = v[f];
+            }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(dzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(m));
-    // The last plane's threads also take max|dz| over the sparse grid's columns, which follow their own
-    // segment in the same row (mostly the same or the next cache line): the sparse stage then never has
-    // to read dz just for its fixed-point scale.
-    if (plane == 2) {                                  // block-uniform
-        float ms = 0.f;
-        if (p < n) {
-            const float* src = dz + (int64_t)A.order[plane][p] * dz_stride + A.scol0;     // 16-B aligned: scol0, dz_stride multiples of 4
-            const int nq = (A.scols + 3) >> 2;         // the row is zero-padded up to dz_stride
-            for (int q = 0; q < nq; ++q) {
-                const float4 t = reinterpret_cast<const float4*>(src)[q];
-                ms = fmaxf(ms, fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))));
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ms = fmaxf(ms, __shfl_xor(ms, o));
-        if ((threadIdx.x & 63) == 0 && ms > 0.f) atomicMax(A.sdzmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kMaxSlots - 1)), __float_as_uint(ms));
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); ms = fmaxf(ms, __shfl_xor(ms, o)); }
+    if ((t & 63) == 0) {
+        const int slot = (blockIdx.x * 4 + (t >> 6)) & (kMaxSlots - 1);
+        if (m > 0.f) atomicMax(dzmax + slot, __float_as_uint(m));
+        if (plane == 2 && ms > 0.f) atomicMax(A.sdzmax + slot, __float_as_uint(ms));
     }
 }
 
@@ -525,8 +541,9 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         hipError_t me2 = hipMemsetAsync(PA.sdzmax, 0, kMaxSlots * 4, s);
         if (me2 != hipSuccess) return (int)me2;
     }
-    hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, s, coords, dz, dz_stride, PA,
-                       (unsigned*)(ws + W.dzmax), n);
+    if (PA.scols > 16 * F) return NVP_ERR_UNSUPPORTED;         // the sparse columns are scanned by the plane's own lanes
+    hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + PermCfg<F>::PIX - 1) / PermCfg<F>::PIX), 3), dim3(256),
+                       (size_t)PermCfg<F>::PIX * PermCfg<F>::STRIDE * sizeof(float), s, coords, dz, dz_stride, PA, (unsigned*)(ws + W.dzmax), n);
 
     RowArgs RA;
     int rs_max = 0;
