@@ -285,6 +285,45 @@ def gen_quant(seed):
                         n_levels=np.array(5))
 
 
+def gen_export(seed):
+    """compression.py's compress_keyframes / compress_sparse_grid write u8 images with cv2.imwrite.
+    Their two `def`s are extracted with `ast` (the script itself cannot be imported: argparse, cv2, configargparse)
+    and executed here with a stand-in `cv2.imwrite` that records (path, array) instead of encoding a PNG; the
+    decode side of eval_compression.py (img / 255 * (max - min) + min, per dim and level) is applied to the recorded
+    images to capture the round-trip values."""
+    import ast
+    import math
+    import types
+    src = open(os.path.join(REF, "experiment_scripts", "compression.py")).read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("compress_keyframes", "compress_sparse_grid")]
+    assert len(fns) == 2
+    written = []
+    cv2 = types.SimpleNamespace(imwrite=lambda path, arr: written.append((path, np.array(arr))))
+    fake_os = types.SimpleNamespace(path=os.path, makedirs=lambda *a, **k: None)
+    env = {"torch": torch, "np": np, "math": math, "cv2": cv2, "os": fake_os, "unit_multiplier": 2.0 ** 8 - 1.0}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "compression.py", "exec"), env)
+    gen = torch.Generator().manual_seed(seed)
+    cfg = {"n_levels": 5, "n_features_per_level": 2, "per_level_scale": 1.35, "base_resolution": 16}
+    n = O.dense_grid_n_params(cfg)
+    kf = torch.randn(n, generator=gen) * 0.1
+    sg = torch.randn((5, 6, 7, 2), generator=gen) * 0.05
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env["compress_keyframes"](kf.clone(), cfg, "kf")
+        n_kf = len(written)
+        env["compress_sparse_grid"](sg.clone(), {"n_features_per_level": 2}, "sg")
+    blob = {"kf": kf.numpy(), "sg": sg.numpy(), "n_levels": np.array(5)}
+    for path, arr in written[:n_kf]:                       # kf/dim{d}/{level:02d}.png
+        d, lvl = int(path.split("dim")[1].split("/")[0]), int(os.path.basename(path)[:2])
+        blob[f"kf_d{d}_l{lvl}"] = arr
+    for path, arr in written[n_kf:]:                       # sg/dim{d}/{frame:05d}.png
+        d, fr = int(path.split("dim")[1].split("/")[0]), int(os.path.basename(path)[:5])
+        blob[f"sg_d{d}_f{fr}"] = arr
+    np.savez_compressed(os.path.join(OUT, "export.npz"), **blob)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)          # deterministic reductions while generating
@@ -296,6 +335,7 @@ def main():
     gen_e2e(seed=31)
     gen_init(seed=123)
     gen_quant(seed=41)
+    gen_export(seed=51)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"golden fixtures written to {OUT} ({tot / 1024:.0f} KiB); oracle == reference on all cases")
 

@@ -180,3 +180,48 @@ def test_grad_sink_returns_fresh_alias():
         functional.GRAD_SINK = None
     assert g is not buf and g.data_ptr() == buf.data_ptr()
     assert functional._grad_buffer(p).data_ptr() != buf.data_ptr()      # no sink -> private buffer
+
+
+def test_codec_export_matches_reference_compression_script(tmp_path):
+    """the 8-bit planes of nvp_amd.export against images captured from the reference's
+    compress_keyframes / compress_sparse_grid (oracle/make_golden.py::gen_export), the decode formula of
+    eval_compression.py, and a PNG write/read round trip through the on-disk tree."""
+    from nvp_amd import export
+    g = np.load(os.path.join(GOLDEN, "export.npz"))
+    cfg = {"n_levels": int(g["n_levels"]), "n_features_per_level": 2, "per_level_scale": 1.35, "base_resolution": 16}
+    images, mins, maxs = export.keyframe_planes(torch.from_numpy(g["kf"]), cfg)
+    for d in range(2):
+        for l in range(cfg["n_levels"]):
+            assert np.array_equal(images[d][l], g[f"kf_d{d}_l{l}"][:, :, 0]), (d, l)
+    frames, smin, smax = export.sparse_planes(torch.from_numpy(g["sg"]))
+    for d in range(2):
+        for t in range(g["sg"].shape[0]):
+            assert np.array_equal(frames[d][t], g[f"sg_d{d}_f{t}"][:, :, 0]), (d, t)
+    # decode: within half a quantisation step of the original, level by level
+    back = export.keyframes_from_planes(images, mins, maxs)
+    res, off = export.level_geometry(cfg)
+    kf = torch.from_numpy(g["kf"]).reshape(-1, 2)
+    for d in range(2):
+        for l in range(cfg["n_levels"]):
+            step = (maxs[d][l] - mins[d][l]) / 255.0
+            err = (back.reshape(-1, 2)[off[l]:off[l + 1], d] - kf[off[l]:off[l + 1], d]).abs().max()
+            assert float(err) <= 0.5 * step * 1.001 + 1e-7
+    sback = export.sparse_from_planes(frames, smin, smax)
+    assert sback.shape == g["sg"].shape
+    assert float((sback - torch.from_numpy(g["sg"])).abs().max()) <= 0.5 * max(smax[d] - smin[d] for d in range(2)) / 255.0 * 1.001 + 1e-7
+    # PNG round trip
+    p = str(tmp_path / "x.png")
+    export.write_png(p, images[1][3])
+    assert np.array_equal(export.read_png(p), images[1][3])
+    # whole-model tree: export, import, parameters equal the de-quantised values
+    cfg_m = small_cfg(F=2, T=4, X=5, Y=6, n_levels=4)
+    m = modules.NVP(out_features=3, encoding_config=cfg_m)
+    with torch.no_grad():
+        for prm in (m.keyframes_xy.params, m.keyframes_xt.params, m.keyframes_yt.params, m.sparse_grid.embeddings):
+            prm.copy_(torch.randn(prm.shape) * 0.1)
+    want_xy = export.keyframes_from_planes(*export.keyframe_planes(m.keyframes_xy.params, cfg_m["2d_encoding_xy"]))
+    want_sg = export.sparse_from_planes(*export.sparse_planes(m.sparse_grid.embeddings))
+    stats = export.export_model(m, cfg_m, str(tmp_path / "tree"))
+    assert stats["files"] == 3 * 2 * 4 + 2 * 4
+    export.import_model(m, cfg_m, str(tmp_path / "tree"))
+    assert torch.equal(m.keyframes_xy.params.detach(), want_xy) and torch.equal(m.sparse_grid.embeddings.detach(), want_sg)
