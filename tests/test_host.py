@@ -225,3 +225,27 @@ def test_codec_export_matches_reference_compression_script(tmp_path):
     assert stats["files"] == 3 * 2 * 4 + 2 * 4
     export.import_model(m, cfg_m, str(tmp_path / "tree"))
     assert torch.equal(m.keyframes_xy.params.detach(), want_xy) and torch.equal(m.sparse_grid.embeddings.detach(), want_sg)
+
+
+def test_compat_install_shadows_the_reference_import_names():
+    """after compat.install(), `import modules` / `import tinycudann` / `from sparsegrid import
+    SparseGrid` / `import modulation` (what the reference's scripts and its modules.py do) resolve to nvp_amd."""
+    import importlib
+    import sys
+    from nvp_amd import compat
+    saved = {k: sys.modules.get(k) for k in ("modules", "modulation", "sparsegrid", "tinycudann")}
+    try:
+        compat.install()
+        assert importlib.import_module("modules").NVP is modules.NVP
+        assert importlib.import_module("sparsegrid").SparseGrid is sparsegrid.SparseGrid
+        assert importlib.import_module("modulation").SirenWrapper is modulation.SirenWrapper
+        assert hasattr(importlib.import_module("tinycudann"), "Encoding")
+        # the reference's constructor call (train_video.py:46): extra kwargs are swallowed
+        m = importlib.import_module("modules").NVP(type="nvp", in_features=2, out_features=3, encoding_config=small_cfg())
+        assert hasattr(m, "keyframes_xy") and hasattr(m, "sparse_grid") and hasattr(m, "wrapper")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
