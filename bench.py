@@ -154,7 +154,7 @@ def main():
     if os.environ.get("NVP_DP_OVERLAP", "1") != "0":
         early = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings]
     bucket = (parallel.GradBucket(parallel.unique_parameters(model), early=early)
-              if (world > 1 or os.environ.get("NVP_FORCE_BUCKET")) else None)
+              if (world > 1 or os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1") else None)
 
     def one_step():
         mi, gt = data.sample()
@@ -164,7 +164,7 @@ def main():
         one_step()
 
     def barrier():
-        if world > 1:
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -243,7 +243,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

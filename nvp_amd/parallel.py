@@ -18,12 +18,22 @@ import torch
 import torch.distributed as dist
 
 
+def _force() -> bool:
+    """NVP_DP_FORCE_COLLECTIVES=1: run the collective code paths even with ONE rank (a single-GPU box can then exercise
+    the real RCCL calls - init, barrier, chunked asynchronous all-reduces on slices of the flat buffer, waits)."""
+    return os.environ.get("NVP_DP_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _multi() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force())
+
+
 def init_distributed(backend: Optional[str] = None) -> tuple:
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -98,7 +108,7 @@ class GradBucket:
         the parameters of piece i while piece i+1 is still on the wire (`step_schedule`).  No-op without a group."""
         if self._early_range is None or self._early_work is not None:
             return
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _multi():
             self._early_work = [(a, b, dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
                                 for a, b in self.early_chunks()]
 
@@ -122,7 +132,7 @@ class GradBucket:
         in flight yet, and return [(wait, [(param, a, b), ...]), ...] in completion order - wait() makes the
         current stream wait for that piece's collective.  Gradients stay SUMS (the caller passes 1/world as
         grad_scale).  Returns None for a single process (nothing to wait for)."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not _multi():
             return None
         if not self.consistent():
             self.all_reduce(scale=False)            # repair path: everything reduced synchronously
@@ -186,7 +196,7 @@ class GradBucket:
                 elif p.grad.data_ptr() != v.data_ptr():
                     v.copy_(p.grad)
             self.attach()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _multi():
             if self._early_work is not None:
                 # the big range is already in flight (overlapping the dW GEMMs): reduce the rest, then join
                 lo, hi = self._early_range
@@ -203,6 +213,6 @@ class GradBucket:
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     """Make every rank start from rank `src`'s parameters (replicated-parameter DP)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _multi():
         for p in unique_parameters(module):
             dist.broadcast(p.data, src=src)
