@@ -6,6 +6,7 @@
 //                    hi/mid/lo bf16 on the fly, weight parts from registers                          (matrix-pipe ceiling)
 //   2  bf16x3 glob   same, the 3 weight parts streamed per wave from an L2-resident packed tensor (96 KB per chain)
 //   3  bf16x3 lds    same, weight parts read from LDS (one layer staged once per 8-wave workgroup)    (LDS read cost)
+//   4 / 5            as 1, but each product is issued for 2 / 4 output tiles in turn, so back-to-back MFMAs never share an accumulator
 // Reports fp32-equivalent TFLOP/s (2*128*128*32 FLOP per chain per wave) and, for one tile, the error of the
 // 6-product split against float64 next to the error of an fp32 fma chain.
 #include <hip/hip_runtime.h>
@@ -70,6 +71,31 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 256, MODE == 3 ? 1 : 2) void chai
                 for (int q = 0; q < 8; ++q) x[q] = act[s >> 1][8 * (s & 1) + q];
                 u32x4 bh, bm, bl;
                 split8(x, bh, bm, bl);
+                if (MODE == 4 || MODE == 5) {
+                    const int W = MODE == 4 ? 2 : 4;           // tiles interleaved per product
+#pragma unroll
+                    for (int T0 = 0; T0 < 4; T0 += W) {
+                        u32x4 ah[4], am[4], al[4];
+#pragma unroll
+                        for (int t = 0; t < W; ++t) {
+                            const unsigned k = 0x3c003c00u + (unsigned)(s * 4 + T0 + t);
+                            ah[t] = (u32x4)(k); am[t] = (u32x4)(k ^ 0x00400040u); al[t] = (u32x4)(k ^ 0x01000100u);
+                        }
+#pragma unroll
+                        for (int t = 0; t < W; ++t) acc[T0 + t] = mf(al[t], bh, acc[T0 + t]);
+#pragma unroll
+                        for (int t = 0; t < W; ++t) acc[T0 + t] = mf(ah[t], bl, acc[T0 + t]);
+#pragma unroll
+                        for (int t = 0; t < W; ++t) acc[T0 + t] = mf(am[t], bm, acc[T0 + t]);
+#pragma unroll
+                        for (int t = 0; t < W; ++t) acc[T0 + t] = mf(am[t], bh, acc[T0 + t]);
+#pragma unroll
+                        for (int t = 0; t < W; ++t) acc[T0 + t] = mf(ah[t], bm, acc[T0 + t]);
+#pragma unroll
+                        for (int t = 0; t < W; ++t) acc[T0 + t] = mf(ah[t], bh, acc[T0 + t]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int T = 0; T < 4; ++T) {
                     u32x4 ah, am, al;
@@ -137,6 +163,8 @@ int main() {
             if (mode == 0) hipLaunchKernelGGL(chain_probe<0>, dim3(waves_blocks), dim3(256), 0, 0, wpk, out, nchain);
             if (mode == 1) hipLaunchKernelGGL(chain_probe<1>, dim3(waves_blocks), dim3(256), 0, 0, wpk, out, nchain);
             if (mode == 2) hipLaunchKernelGGL(chain_probe<2>, dim3(waves_blocks), dim3(256), 0, 0, wpk, out, nchain);
+            if (mode == 4) hipLaunchKernelGGL(chain_probe<4>, dim3(waves_blocks), dim3(256), 0, 0, wpk, out, nchain);
+            if (mode == 5) hipLaunchKernelGGL(chain_probe<5>, dim3(waves_blocks), dim3(256), 0, 0, wpk, out, nchain);
             if (mode == 3) hipLaunchKernelGGL(chain_probe<3>, dim3(waves_blocks / 2), dim3(512), 8 * 4 * 3 * 64 * 16, 0, wpk, out, nchain);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
@@ -145,7 +173,7 @@ int main() {
         printf("mode %d: %.3f ms  %.1f TFLOP/s fp32-equivalent  (%.0f cycles/chain/SIMD at 2.4 GHz incl. 2 waves)\n", mode, best,
                flop * waves / (best * 1e-3) / 1e12, best * 1e-3 * 2.4e9 / (nchain * (waves / 1024.0)));
     };
-    for (int m = 0; m < 4; ++m) run(m);
+    for (int m = 0; m < 6; ++m) run(m);
 
     // accuracy of the 6-product split
     std::vector<float> A(32 * 128), B(128 * 32); srand(1);
