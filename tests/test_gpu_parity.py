@@ -506,3 +506,32 @@ def test_adamw_kernel_matches_torch_adamw():
         bad = AdamW([torch.nn.Parameter(torch.zeros(4))], lr=1e-2)
         bad.param_groups[0]["params"][0].grad = torch.zeros(4)
         bad.step()
+
+
+def test_device_sampler_matches_reference_sampler_formulas():
+    """Row H / N1: nvp_sample_gather against the oracle's restatement of dataio.py:93-120 for the same (ti, pi) draws -
+    coordinates, temporal steps and gt bytes bit-exact - and DeviceVideo's contract (draw order, y-sorted delivery)."""
+    import ctypes as C
+    from nvp_amd import _lib as L, harness
+    T, H, W, n = 7, 33, 41, 5000
+    gen = torch.Generator().manual_seed(3)
+    video = torch.randint(0, 256, (T, H, W, 3), generator=gen, dtype=torch.uint8)
+    ti, pi, coords_ref, steps_ref = O.sample_batch(T, H, W, n, gen)
+    gt_ref = video.reshape(T, H * W, 3)[ti, pi]
+    vd = video.to(dev())
+    data = harness.DeviceVideo(vd, n_samples=n, seed=0, sort_by_y=False)
+    coords = torch.empty((n, 3), device=dev()); steps = torch.empty((n,), device=dev()); gt = torch.empty((n, 3), device=dev(), dtype=torch.uint8)
+    lib = L.load()
+    ti_d, pi_d = ti.to(dev()), pi.to(dev())            # keep the device copies alive across the launch
+    L.check(lib.nvp_sample_gather(L.ptr(vd, torch.uint8), L.ptr(ti_d, torch.int64), L.ptr(pi_d, torch.int64),
+                                  L.ptr(data.tcoord_tab), L.ptr(data.tstep_tab), L.ptr(coords), L.ptr(steps), L.ptr(gt, torch.uint8),
+                                  n, T, H, W, L.stream_ptr()), "nvp_sample_gather")
+    assert torch.equal(coords.cpu(), coords_ref) and torch.equal(steps.cpu(), steps_ref) and torch.equal(gt.cpu(), gt_ref)
+    # DeviceVideo: shapes, value ranges, and the y-sorted delivery is a permutation in ascending image-column order
+    mi, g = harness.DeviceVideo(vd, n_samples=n, seed=5, sort_by_y=True).sample()
+    c = mi["all_coords"][0]
+    assert mi["all_coords"].shape == (1, n, 3) and mi["temporal_steps"].shape == (1, n) and g["img"].shape == (1, n, 3) and mi["sorted_by_y"]
+    assert bool((c[1:, 2] >= c[:-1, 2]).all()) and float(c.min()) >= 0 and float(c.max()) <= 1
+    mi2, g2 = harness.DeviceVideo(vd, n_samples=n, seed=5, sort_by_y=False).sample()      # same draws, raw order
+    key = lambda cc, ss: torch.sort(cc[:, 0] * 1e6 + cc[:, 1] * 1e3 + cc[:, 2] + ss * 1e-3).values
+    assert torch.allclose(key(c, mi["temporal_steps"][0]), key(mi2["all_coords"][0], mi2["temporal_steps"][0]))
