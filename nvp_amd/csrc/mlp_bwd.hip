@@ -338,7 +338,7 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
                               const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
     if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
-    if (NVP_BWD_B3 && nvp_fwd_b3_ok(d)) return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
+    if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));

@@ -5,21 +5,39 @@
 // pack_fwd_b3_kernel, activations on the fly from the fp32 registers) and the six products >= 2^-24 are
 // accumulated in fp32.  The result carries an error BELOW that of an fp32 fma chain of the same length
 // (profiles/r01_probe_bf16x3_split_chain.txt) at 2.5x fewer matrix-pipe cycles.  Used for latents of <= 128 rows
-// when the library is built with NVP_FWD_B3=1; everything else (element-wise stages, saved streams, RGB layout)
+// when the library is built with NVP_FWD_B3=1 (up to 256 rows; beyond 144 rows the rest is read from the tensor); everything else (element-wise stages, saved streams, RGB layout)
 // is identical to the fp32 kernel.
 #include "mlp_b3.h"
 
 namespace {
 
 constexpr int kWaves = 4;
-// 8 k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
+// `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
 // step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
-__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, const u32x4* __restrict__ w, int lane) {
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const u32x4* __restrict__ w, int lane) {
     const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) {
         const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
         const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+        const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3(acc, w + s * 12 * 64, bh, bm, bl, lane);
+    }
+}
+
+// k-steps [s0, s1) straight from the latent tensor (wide latents: rows the LDS tile does not hold); row-groups at or
+// beyond rg_end (the tensor's rows / 4) read as zero - the tile of the LAST pixels is followed by nothing
+__device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end,
+                                            const u32x4* __restrict__ w, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int s = s0; s < s1; ++s) {
+        const int rg = 4 * s + 2 * h;
+        const float4 t0 = rg < rg_end ? zg[rg * 32 + j] : zero;
+        const float4 t1 = rg + 1 < rg_end ? zg[(rg + 1) * 32 + j] : zero;
         const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
         u32x4 bh, bm, bl;
         split8(x, bh, bm, bl);
@@ -38,16 +56,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     if (tile >= ntiles) return;                       // wave-uniform
     nvp_stagger_start();
     const int j = lane & 31, h = lane >> 5;
-    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3();
-    // latent tile -> this wave's LDS region, zero-padded to 128 rows (the packed weights are zero there, but
-    // 0 x garbage could be NaN)
+    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
+    // latent tile -> this wave's LDS region: the first zs_l k-steps' rows, zero-padded to whole k-steps (the packed
+    // weights are zero there, but 0 x garbage could be NaN); wide latents (nvp_l) read the remaining rows from the tensor
     extern __shared__ __attribute__((aligned(16))) float4 zlds[];
-    float4* z = zlds + wv * 1024;
+    const int zs_l = min(L.zs, kB3ZLdsSteps);
+    const int zl4 = zs_l * 4 * 32;                           // float4 per wave in LDS
+    float4* z = zlds + wv * zl4;
     const int z4 = (nvp_rows4(d) / 4) * 32;
-    stage_z(z, reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4, z4, lane);
-    for (int idx = z4 + lane; idx < 1024; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
+    stage_z(z, zg, min(z4, zl4), lane);
+    for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int rg_end = nvp_rows4(d) / 4;
     const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
@@ -62,7 +84,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         bias_b3(hm, w, lane);
-        chain_z_b3(hm, z, w + 12 * 64, lane);
+        chain_z_b3(hm, z, zs_l, w + 12 * 64, lane);
+        chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, w + 12 * 64, lane);
         lrelu4(hm);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
@@ -93,7 +116,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             bias_b3(acc, w, lane);
             chain_h_b3(acc, hm, w + 12 * 64, lane);
-            chain_z_b3(acc, z, w + 9 * 12 * 64, lane);
+            chain_z_b3(acc, z, zs_l, w + 9 * 12 * 64, lane);
+            chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, w + 9 * 12 * 64, lane);
             lrelu4(acc);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
@@ -149,7 +173,8 @@ int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_par
                           float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
-    const size_t lds = (size_t)kWaves * 1024 * sizeof(float4);      // 64 KB: 128 latent rows per wave
+    const int zs = nvp_fwd_layout_b3(d).zs;
+    const size_t lds = (size_t)kWaves * (zs < kB3ZLdsSteps ? zs : kB3ZLdsSteps) * 4 * 32 * sizeof(float4);      // 64 KB (nvp_s), 72 KB (nvp_l)
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_fwd);
     if (saved)
         hipLaunchKernelGGL(mlp_fwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d);

@@ -104,18 +104,22 @@ constexpr int kRecTileFloats = 128 * kRecRowStride;
 //        stream[((step*4 + T')*3 + part)*64 + lane]          part 0 hi, 1 mid, 2 lo
 // Steps of a layer: bias step (A[.][k=0] = b, B = e_0), then 8 steps per 128 chained inputs with
 //        in(c, h, q) = 32 (c>>1) + 8 (2 (c&1) + (q>>2)) + 4 h + (q&3)        (= the D registers 8(c&1)..+7 of tile c>>1)
-// then, for the modulator layers, 8 latent steps with in(s, h, q) = 16 s + 8 h + q (zero beyond D).
+// then, for the modulator layers, ceil(rows/16) latent steps with in(s, h, q) = 16 s + 8 h + q (zero beyond D).
 struct NvpFwdLayoutB3 {
+    int zs;            // latent k-steps = ceil(rows / 16)
     int steps[5];      // mod0, mod1, mod2, sir1, sir2
     int64_t off[6];    // u32 offsets, off[5] = total
 };
 constexpr int kB3StepU32 = 4 * 3 * 64 * 4;       // u32 per k-step (12 KiB)
+constexpr int kB3ZLdsSteps = 9;                  // latent k-steps kept in LDS per wave (144 rows = 18 KiB); the rest is read from the tensor
 
-__host__ __device__ inline bool nvp_fwd_b3_ok(int d) { return ((d + 3) & ~3) <= 128; }
+__host__ __device__ inline bool nvp_fwd_b3_ok(int d) { return ((d + 3) & ~3) <= 256; }     // forward: latent up to 256 rows
+__host__ __device__ inline bool nvp_bwd_b3_ok(int d) { return ((d + 3) & ~3) <= 128; }     // backward chain: one 64-register latent accumulator
 
-__host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3() {
+__host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3(int d) {
     NvpFwdLayoutB3 L;
-    L.steps[0] = 1 + 8; L.steps[1] = 1 + 8 + 8; L.steps[2] = 1 + 8 + 8; L.steps[3] = 1 + 8; L.steps[4] = 1 + 8;
+    L.zs = (((d + 3) & ~3) + 15) / 16;
+    L.steps[0] = 1 + L.zs; L.steps[1] = 1 + 8 + L.zs; L.steps[2] = 1 + 8 + L.zs; L.steps[3] = 1 + 8; L.steps[4] = 1 + 8;
     int64_t o = 0;
     for (int i = 0; i < 5; ++i) { L.off[i] = o; o += (int64_t)L.steps[i] * kB3StepU32; }
     L.off[5] = o;

@@ -48,7 +48,7 @@ __device__ __forceinline__ unsigned nvp_bf16_rne(float f) {           // bf16 bi
 
 // bf16 x 3 forward stream (mlp_layout.h "b3"): one thread per packed u32 = two consecutive k of one part
 __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
-    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3();
+    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L.off[5]) return;
     int seg = 0;
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* 
 
 extern "C" {
 
-int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3().off[5] : nvp_fwd_layout(d).off[5]; }
-int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_bwd_b3_off(7) : nvp_bwd_layout(d).off[7]; }
+int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3(d).off[5] : nvp_fwd_layout(d).off[5]; }
+int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) ? nvp_bwd_b3_off(7) : nvp_bwd_layout(d).off[7]; }
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
     return nvp_param_layout(d).total * (int64_t)n_chunks;       // one full gradient record per pixel chunk
@@ -180,7 +180,7 @@ const char* nvp_version(void) { return "nvp_hip 0.1 (gfx950)"; }
 int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
-        const int64_t nb = nvp_fwd_layout_b3().off[5];
+        const int64_t nb = nvp_fwd_layout_b3(d).off[5];
         hipLaunchKernelGGL(pack_fwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
         NVP_LAUNCH_CHECK();
         return 0;
@@ -193,7 +193,7 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
 
 int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
-    if (NVP_BWD_B3 && nvp_fwd_b3_ok(d)) {
+    if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
         const int64_t nb = nvp_bwd_b3_off(7);
         hipLaunchKernelGGL(pack_bwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
         NVP_LAUNCH_CHECK();

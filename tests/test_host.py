@@ -33,8 +33,11 @@ def test_library_size_queries_match_layout_arithmetic():
     for d in (114, 228, 57):
         zs = (d + 1) // 2
         steps = (1 + zs) + 2 * (65 + zs) + 2 * 65
-        # latents of <= 128 rows use the bf16 x 3 forward stream: 9 + 17 + 17 + 9 + 9 k-steps of 4 tiles x 3 parts x 64 lanes x 4 u32
-        want = (9 + 17 + 17 + 9 + 9) * 4 * 3 * 64 * 4 if (d + 3) // 4 * 4 <= 128 else steps * 64 * 4
+        # latents of <= 256 rows use the bf16 x 3 forward stream: (1 + zs) + 2 (1 + 8 + zs) + 2 (1 + 8) k-steps, zs = ceil(rows / 16),
+        # of 4 tiles x 3 parts x 64 lanes x 4 u32
+        rows = (d + 3) // 4 * 4
+        zs16 = (rows + 15) // 16
+        want = ((1 + zs16) + 2 * (9 + zs16) + 18) * 4 * 3 * 64 * 4 if rows <= 256 else steps * 64 * 4
         assert lib.nvp_packed_fwd_floats(d) == want
         H = 128
         total = H * d + H + 2 * (H * (H + d) + H) + (H + H) + 2 * (H * H + H) + 3 * H + 3
