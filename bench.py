@@ -61,7 +61,8 @@ BYTES_PX = {
 }
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_B3 = 2516.6e12 / 6    # bf16 dense peak / six bf16 products per fp32 product = 419 TF fp32-equivalent
-B3_STAGES = ("nvp_mlp_fwd", "nvp_mlp_bwd_dx")     # run on bf16x3 split MFMA for config_nvp_s; the dW GEMMs are fp32 MFMA
+# stages that run on bf16x3 split MFMA: forward for latents <= 256 rows, backward chain for <= 128 rows; dW: fp32 MFMA
+B3_STAGES = {"s": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx"), "l": ("nvp_mlp_fwd",)}
 PEAK_HBM = 8.0e12
 
 
@@ -196,7 +197,7 @@ def main():
         roof = None
         if dom in FLOP_PX:
             ach = FLOP_PX[dom] * N_PX / (kms[dom] * 1e-3)
-            pk = PEAK_MFMA_B3 if (dom in B3_STAGES and args.config == "s") else PEAK_MFMA_F32
+            pk = PEAK_MFMA_B3 if dom in B3_STAGES[args.config] else PEAK_MFMA_F32
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": round(pk / 1e12, 1),
                     "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": traffic.get(dom),
                     "ms_per_launch": kms[dom], "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
@@ -210,7 +211,7 @@ def main():
         for k, ms in kms.items():
             if k in FLOP_PX:
                 a = FLOP_PX[k] * N_PX / (ms * 1e-3)
-                b3 = k in B3_STAGES and args.config == "s"
+                b3 = k in B3_STAGES[args.config]
                 pk = PEAK_MFMA_B3 if b3 else PEAK_MFMA_F32
                 stages[k] = {"ms": ms, "bound": "mfma", "mfma": "bf16x3 split (fp32-equivalent FLOP)" if b3 else "fp32",
                              "achieved_tflops": round(a / 1e12, 2), "peak_tflops": round(pk / 1e12, 1), "frac": round(a / pk, 4)}
