@@ -61,8 +61,8 @@ BYTES_PX = {
 }
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_B3 = 2516.6e12 / 6    # bf16 dense peak / six bf16 products per fp32 product = 419 TF fp32-equivalent
-# stages that run on bf16x3 split MFMA: forward for latents <= 256 rows, backward chain for <= 128 rows; dW: fp32 MFMA
-B3_STAGES = {"s": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx"), "l": ("nvp_mlp_fwd",)}
+# stages that run on bf16x3 split MFMA: forward and backward chain for latents <= 256 rows; dW: fp32 MFMA
+B3_STAGES = {"s": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx"), "l": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx")}
 PEAK_HBM = 8.0e12
 
 

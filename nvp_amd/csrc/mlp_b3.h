@@ -69,6 +69,12 @@ __device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restric
     }
 }
 
+// the same k-step for four consecutive tiles of a longer accumulator array
+template <bool PF = true>
+__device__ __forceinline__ void step_b3_at(f32x16* acc, const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+    step_b3<PF>(*reinterpret_cast<f32x16(*)[4]>(acc), w, bh, bm, bl, lane);
+}
+
 // bias step: B = e_0 (1.0 at k = 0, exact in bf16), A[.][0] = hi/mid/lo of the bias
 __device__ __forceinline__ void bias_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, int lane) {
     const unsigned ul = (unsigned)lane;

@@ -1,7 +1,8 @@
 // Backward dX chain + latent gradient + per-tile records (see mlp_bwd.hip, whose structure this kernel shares line
 // for line) with every transposed GEMM on **bf16 x 3 split MFMA** (mlp_b3.h): dq / dp are split into hi + mid + lo
 // bf16 on the fly, the transposed weights come pre-split from pack_bwd_b3_kernel, six products per k-step are
-// accumulated in fp32.  Used for latents of <= 128 rows when the library is built with NVP_BWD_B3=1.
+// accumulated in fp32.  Used for latents of <= 256 rows when the library is built with NVP_BWD_B3=1 (latent gradient
+// fused up to 128 rows, separate mlp_bwd_dz_b3_kernel beyond).
 #include "mlp_b3.h"
 
 #ifndef NVP_BWD_B3_PF
@@ -16,6 +17,9 @@ __device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ 
     load_ptm16(v, tile_base, T, lane);
 }
 
+// FUSE_DZ: latent <= 128 rows - the latent gradient is a third chain per layer (accumulator parked in LDS); otherwise
+// mlp_bwd_dz_b3_kernel computes it from the dp streams afterwards.
+template <bool FUSE_DZ>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const unsigned* __restrict__ packed,
@@ -126,10 +130,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         f32x16 acc[4];
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h_b3<NVP_BWD_B3_PF>(acc, dx, wp + nvp_bwd_b3_off(2 - k) / 4, lane);   // streams 0 (sir2^T), 1 (sir1^T)
+        chain_h_b3<NVP_BWD_B3_PF>(acc, dx, wp + nvp_bwd_b3_off(2 - k, 4) / 4, lane);   // streams 0 (sir2^T), 1 (sir1^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
-        {
+        if (FUSE_DZ) {
             // dz += W_k[:, 128:]^T dp_k; the accumulator lives in LDS between layers (see above)
             float4* park = reinterpret_cast<float4*>(xl);
             if (k == 2) {
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
                         acc[T][4 * g] = t.x; acc[T][4 * g + 1] = t.y; acc[T][4 * g + 2] = t.z; acc[T][4 * g + 3] = t.w;
                     }
             }
-            chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 + k) / 4, lane);   // streams 6 (z2^T), 5 (z1^T)
+            chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 + k, 4) / 4, lane);   // streams 6 (z2^T), 5 (z1^T)
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         for (int T = 0; T < 4; ++T) nvp_pin(dh[T]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 - k) / 4, lane);   // streams 2 (mod2h^T), 3 (mod1h^T)
+        chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 - k, 4) / 4, lane);   // streams 2 (mod2h^T), 3 (mod1h^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
     }
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         for (int T = 0; T < 4; ++T) {
             f32x16 hn;
             if (T < 3) load_act16(hn, h0, T + 1, lane);
-            {
+            if (FUSE_DZ) {
                 if (T == 0) fetch_dz(0);
                 if (T < 3) fetch_dz(T + 1);
             }
@@ -225,10 +229,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         }
         rec[kRecSir0W + lane] = wl; rec[kRecSir0W + 64 + lane] = wh;
         rec[kRecSir0B + lane] = cl; rec[kRecSir0B + 64 + lane] = ch;
-        {
+        if (FUSE_DZ) {
             // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
             NVP_LOAD_FENCE();
-            chain_h_b3<NVP_BWD_B3_PF>(dzacc, dh, wp + nvp_bwd_b3_off(4) / 4, lane);     // stream 4 (z0^T)
+            chain_h_b3<NVP_BWD_B3_PF>(dzacc, dh, wp + nvp_bwd_b3_off(4, 4) / 4, lane);     // stream 4 (z0^T)
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
 #pragma unroll
@@ -243,6 +247,52 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
     }
 }
 
+// Latent gradient for wide latents (ZT = 8 output tiles: the accumulator alone is 128 registers):
+//   dz = W2[:,128:]^T dp2 + W1[:,128:]^T dp1 + W0^T dp0, reading the three dp streams the chain kernel just wrote.
+template <int ZT>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3_kernel(const float* __restrict__ dy, const unsigned* __restrict__ packed,
+                                                                       float* __restrict__ dzr, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (tile >= ntiles) return;
+    nvp_stagger_start();
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    const float* dyt = dy + tile * (int64_t)NVP_H * 32;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
+    f32x16 dz[ZT];
+#pragma unroll
+    for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
+#pragma unroll 1
+    for (int k = 2; k >= 0; --k) {
+        f32x16 b[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + (int64_t)k * act, T, lane);
+        NVP_LOAD_FENCE();
+        const u32x4* w = wp + nvp_bwd_b3_off(4 + k, ZT) / 4;       // streams 6 (z2^T), 5 (z1^T), 4 (z0^T)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = b[c >> 1][8 * (c & 1) + q];
+            u32x4 bh, bm, bl;
+            split8(x, bh, bm, bl);
+#pragma unroll
+            for (int T0 = 0; T0 < ZT; T0 += 4) step_b3_at<NVP_BWD_B3_PF>(dz + T0, w + (c * ZT + T0) * 3 * 64, bh, bm, bl, lane);
+        }
+    }
+    const int stride = nvp_dz_stride_dev(d);
+    float* o = dzr + (tile * 32 + j) * stride;
+#pragma unroll
+    for (int T = 0; T < ZT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int base = 32 * T + 8 * g + 4 * h;
+            if (base < stride)
+                *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
+        }
+}
+
 }  // namespace
 
 // called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on and the latent has <= 128 rows
@@ -251,8 +301,13 @@ int nvp_mlp_bwd_b3_launch(const float* drgb, const float* steps, const float* sa
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     const size_t lds = kWaves * kRecTileFloats * sizeof(float);
-    hipLaunchKernelGGL(mlp_bwd_b3_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p,
-                       reinterpret_cast<const unsigned*>(packed_bwd), dy, dz_rows, n, ntiles, d);
+    const unsigned* pk = reinterpret_cast<const unsigned*>(packed_bwd);
+    if (nvp_bwd_b3_zt(d) == 4) {
+        hipLaunchKernelGGL(mlp_bwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, n, ntiles, d);
+    } else {
+        hipLaunchKernelGGL(mlp_bwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_dz_b3_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, pk, dz_rows, ntiles, d);
+    }
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -114,7 +114,8 @@ constexpr int kB3StepU32 = 4 * 3 * 64 * 4;       // u32 per k-step (12 KiB)
 constexpr int kB3ZLdsSteps = 9;                  // latent k-steps kept in LDS per wave (144 rows = 18 KiB); the rest is read from the tensor
 
 __host__ __device__ inline bool nvp_fwd_b3_ok(int d) { return ((d + 3) & ~3) <= 256; }     // forward: latent up to 256 rows
-__host__ __device__ inline bool nvp_bwd_b3_ok(int d) { return ((d + 3) & ~3) <= 128; }     // backward chain: one 64-register latent accumulator
+__host__ __device__ inline bool nvp_bwd_b3_ok(int d) { return ((d + 3) & ~3) <= 256; }     // backward chain; <= 128 rows: latent gradient fused (mlp_bwd_b3.hip)
+__host__ __device__ inline int nvp_bwd_b3_zt(int d) { return ((d + 3) & ~3) <= 128 ? 4 : 8; }   // output tiles of the latent-gradient streams
 
 __host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3(int d) {
     NvpFwdLayoutB3 L;
@@ -129,5 +130,9 @@ __host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3(int d) {
 __host__ __device__ inline int nvp_b3_chain_in(int c, int h, int q) { return 32 * (c >> 1) + 8 * (2 * (c & 1) + (q >> 2)) + 4 * h + (q & 3); }
 
 // Backward b3 streams (A = W^T: row i = INPUT index 32T' + i, k = OUTPUT index nvp_b3_chain_in(c, h, q)), 8 steps each,
-// no bias step: 0 sir2^T, 1 sir1^T, 2 mod2h^T, 3 mod1h^T, 4 z0^T, 5 z1^T, 6 z2^T (latent rows beyond D are zero).
-__host__ __device__ inline int64_t nvp_bwd_b3_off(int stream) { return (int64_t)stream * 8 * kB3StepU32; }
+// no bias step: 0 sir2^T, 1 sir1^T, 2 mod2h^T, 3 mod1h^T (4 output tiles), 4 z0^T, 5 z1^T, 6 z2^T (zt = 4 or 8 output tiles: a
+// step then holds zt * 3 operand quads per lane; latent rows beyond D are zero).  Offsets in u32.
+__host__ __device__ inline int64_t nvp_bwd_b3_off(int stream, int zt) {
+    const int64_t h = 8 * (int64_t)kB3StepU32;
+    return stream <= 4 ? stream * h : 4 * h + (stream - 4) * h * (zt / 4);
+}

@@ -99,15 +99,19 @@ __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsi
 
 // bf16 x 3 backward streams (mlp_layout.h): one thread per packed u32
 __global__ __launch_bounds__(256) void pack_bwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
+    const int zt = nvp_bwd_b3_zt(d);
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nvp_bwd_b3_off(7)) return;
-    const int seg = (int)(idx / nvp_bwd_b3_off(1));
-    const int64_t loc = idx - nvp_bwd_b3_off(seg);
+    if (idx >= nvp_bwd_b3_off(7, zt)) return;
+    int seg = 0;
+    while (idx >= nvp_bwd_b3_off(seg + 1, zt)) ++seg;
+    const int64_t loc = idx - nvp_bwd_b3_off(seg, zt);
+    const int tiles = seg < 4 ? 4 : zt;            // output tiles per k-step of this stream
     const int pr = (int)(loc & 3);
     const int lane = (int)((loc >> 2) & 63);
-    const int part = (int)((loc >> 8) % 3);
-    const int tp = (int)(((loc >> 8) / 3) & 3);
-    const int step = (int)((loc >> 8) / 12);
+    const int quad = (int)(loc >> 8);              // (step * tiles + tile) * 3 + part
+    const int part = quad % 3;
+    const int tp = (quad / 3) % tiles;
+    const int step = quad / (3 * tiles);
     const int i = lane & 31, h = lane >> 5;
     const int in = 32 * tp + i;                    // A row = input index
     unsigned packed = 0;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* 
 extern "C" {
 
 int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3(d).off[5] : nvp_fwd_layout(d).off[5]; }
-int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) ? nvp_bwd_b3_off(7) : nvp_bwd_layout(d).off[7]; }
+int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) ? nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)) : nvp_bwd_layout(d).off[7]; }
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
     return nvp_param_layout(d).total * (int64_t)n_chunks;       // one full gradient record per pixel chunk
@@ -194,7 +198,7 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
 int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
-        const int64_t nb = nvp_bwd_b3_off(7);
+        const int64_t nb = nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d));
         hipLaunchKernelGGL(pack_bwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
         NVP_LAUNCH_CHECK();
         return 0;
