@@ -9,22 +9,35 @@
 // is identical to the fp32 kernel.
 #include "mlp_b3.h"
 
+#ifndef NVP_B3_ZUNROLL
+#define NVP_B3_ZUNROLL 1        // straight-line latent chain for the 8-step (nvp_s) case: 1.854 vs 1.879 ms
+#endif
+
 namespace {
 
 constexpr int kWaves = 4;
 // `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
 // step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
+__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const u32x4* __restrict__ w, int j, int h, int lane) {
+    const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+    const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+    const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    u32x4 bh, bm, bl;
+    split8(x, bh, bm, bl);
+    step_b3(acc, w + s * 12 * 64, bh, bm, bl, lane);
+}
+
 __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const u32x4* __restrict__ w, int lane) {
     const int j = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int s = 0; s < ns; ++s) {
-        const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
-        const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
-        const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3(acc, w + s * 12 * 64, bh, bm, bl, lane);
+#if NVP_B3_ZUNROLL
+    if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, w, j, h, lane);
+        return;
     }
+#endif
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, w, j, h, lane);
 }
 
 // k-steps [s0, s1) straight from the latent tensor (wide latents: rows the LDS tile does not hold); row-groups at or
