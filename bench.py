@@ -61,8 +61,8 @@ BYTES_PX = {
 }
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_B3 = 2516.6e12 / 6    # bf16 dense peak / six bf16 products per fp32 product = 419 TF fp32-equivalent
-# stages that run on bf16x3 split MFMA: forward and backward chain for latents <= 256 rows; dW: fp32 MFMA
-B3_STAGES = {"s": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx"), "l": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx")}
+# stages that run on bf16x3 split MFMA: forward, backward chain and dW GEMMs (latents <= 256 rows)
+B3_STAGES = {"s": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw"), "l": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")}
 PEAK_HBM = 8.0e12
 
 
@@ -225,8 +225,9 @@ def main():
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the forward / backward-chain GEMMs issue each fp32 product as six "
-                          "bf16 MFMA products of hi+mid+lo operand splits (error below an fp32 fma chain, DESIGN.md 4.1a); dW GEMMs: fp32 MFMA",
+            "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the MLP GEMMs (forward, backward chain, dW) issue each fp32 product as "
+                          "six bf16 MFMA products of hi+mid+lo operand splits (error below an fp32 fma chain, DESIGN.md 4.1a); roofline peak for "
+                          "those stages = bf16 dense peak / 6 in fp32-equivalent FLOP",
             "config": {"workload": ("configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s, " if args.config == "s" else
                                     "configs[2] geometry: 1920x1080x300 synthetic u8 RGB video, config_nvp_l, ") +
                                    f"{N_PX} (t,x,y) samples per GPU per step, random-init parameters",

@@ -22,7 +22,11 @@
 //    the records are summed per pixel chunk into the same partials.
 //
 // Bound: fp32 MFMA (219 648 FLOP/px for nvp_s) with ~6 KB/px of HBM reads riding along.
-#include "mlp_layout.h"
+#include "mlp_b3.h"
+
+#ifndef NVP_DW_B3
+#define NVP_DW_B3 1           // dW GEMMs on bf16 x 3 split MFMA (fragments split after the LDS read): 2.72 -> 2.21 ms
+#endif
 
 namespace {
 
@@ -221,6 +225,49 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
 #endif
         const float* la = lds + (BUFS == 2 ? cur : 0) * 2 * kTileFloats;
         const float* lb = la + kTileFloats;
+#if NVP_DW_B3
+        {
+            // bf16 x 3 split MFMA (mlp_b3.h): a lane's 16 pixels of a row are two k-steps of 8 (the SAME pixels on both
+            // operands); fragments are split into hi + mid + lo after the LDS read, six products per (row tile, column
+            // tile, k-step) accumulate in fp32
+            float fa[16], fb[2][16];
+            read_frag(fa, la, 64 * wr + i, h);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) read_frag(fb[c], lb, 64 * wc + 32 * c + i, h);
+            u32x4 pb[2][2][3];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float x[8] = {fb[c][8 * s2], fb[c][8 * s2 + 1], fb[c][8 * s2 + 2], fb[c][8 * s2 + 3],
+                                        fb[c][8 * s2 + 4], fb[c][8 * s2 + 5], fb[c][8 * s2 + 6], fb[c][8 * s2 + 7]};
+                    split8(x, pb[c][s2][0], pb[c][s2][1], pb[c][s2][2]);
+                }
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                if (r2 == 1) read_frag(fa, la, 64 * wr + 32 + i, h);
+                if (want_bias) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { if (r2 == 0) bsum0 += fa[k]; else bsum1 += fa[k]; }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float x[8] = {fa[8 * s2], fa[8 * s2 + 1], fa[8 * s2 + 2], fa[8 * s2 + 3], fa[8 * s2 + 4], fa[8 * s2 + 5], fa[8 * s2 + 6], fa[8 * s2 + 7]};
+                    u32x4 ah, am, al;
+                    split8(x, ah, am, al);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        acc[r2][c] = mf(al, pb[c][s2][0], acc[r2][c]);
+                        acc[r2][c] = mf(ah, pb[c][s2][2], acc[r2][c]);
+                        acc[r2][c] = mf(am, pb[c][s2][1], acc[r2][c]);
+                        acc[r2][c] = mf(am, pb[c][s2][0], acc[r2][c]);
+                        acc[r2][c] = mf(ah, pb[c][s2][1], acc[r2][c]);
+                        acc[r2][c] = mf(ah, pb[c][s2][0], acc[r2][c]);
+                    }
+                }
+            }
+        }
+#else
         {
             float fa[16], fb[2][16];
             read_frag(fa, la, 64 * wr + i, h);
@@ -249,6 +296,7 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
                 acc[1][1] = nvp_mfma(fa[k], fb[1][k], acc[1][1]);
             }
         }
+#endif
         if (BUFS == 1) {
             __syncthreads();                        // everyone finished reading the single buffer
             if (more) write_stage<XF>(lds, lds + kTileFloats, st, J, A, tab, t + 1, n, tid);
