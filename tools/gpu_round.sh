@@ -9,6 +9,7 @@ TAG=${1:-r}
 timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout 900 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/${TAG}_smoke.log
 timeout 900 python bench.py --steps ${STEPS:-10} --warmup 3 > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?" | tee -a gpurun_out/${TAG}_bench.log
+grep '^{' gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json      # the JSON line alone (copy THIS into profiles/)
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/${TAG}_prof" -o prof -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/${TAG}_rocprof.log" 2>&1 ); echo "rocprof rc=$?" | tee -a gpurun_out/${TAG}_rocprof.log
 find gpurun_out/${TAG}_prof -name "*stats*" | head
 tail -3 gpurun_out/${TAG}_pytest.log; tail -2 gpurun_out/${TAG}_smoke.log; tail -2 gpurun_out/${TAG}_bench.log
