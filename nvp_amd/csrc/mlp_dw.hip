@@ -1,7 +1,8 @@
 // Weight gradients of the modulator MLP + modulated SIREN (the dW half of R12):
 //   dW_k[out][in] = sum_px dY_k[out][px] * X_k[in][px]        db_k[out] = sum_px dY_k[out][px]
 // i.e. GEMMs whose CONTRACTION axis is the pixel axis (1.2 M long) and whose output is tiny
-// (128 x {114,242,128}).  They are run split-K over pixel chunks on fp32 MFMA:
+// (128 x {114,242,128}).  They are run split-K over pixel chunks on the matrix cores - bf16 x 3 split MFMA by
+// default (NVP_DW_B3, fragments split into hi + mid + lo after the LDS read, see mlp_b3.h), fp32 MFMA otherwise:
 //
 //  * both operands come from the PTM4 streams written by mlp_fwd/mlp_bwd.  A 128-row x 32-px
 //    tile is 16 KiB contiguous: the block stages it through LDS with full-line 16-B loads
@@ -11,8 +12,8 @@
 //  * a job = one (layer, group of 4 column tiles) = a 128 x 128 block of one dW; grid = (pixel
 //    chunk, job).  Each of the 4 waves owns a 64 x 64 sub-block = 2 x 2 MFMA tiles (64
 //    accumulator registers resident across the whole pixel chunk; 2 A + 2 B fragments feed
-//    64 MFMAs per 32-pixel tile); the next tile's fragments are prefetched into a second
-//    register set while the current tile's MFMAs run.
+//    64 fp32 / 48 bf16 MFMAs per 32-pixel tile); the next tile's global data is prefetched into
+//    registers while the current tile's MFMAs run.
 //  * per-chunk partial results are written in the parameters' natural [out][in] layout
 //    (a D fragment row is 32 consecutive `in` columns = one 128-B line), then summed over
 //    chunks by a second kernel in a fixed order -> deterministic gradients.
@@ -21,7 +22,7 @@
 //    chain kernel already reduced them over each tile's 32 pixels (mlp_bwd.hip, kRec* records); here
 //    the records are summed per pixel chunk into the same partials.
 //
-// Bound: fp32 MFMA (219 648 FLOP/px for nvp_s) with ~6 KB/px of HBM reads riding along.
+// Bound: matrix pipe + the operand-split VALU work + ~6 KB/px of HBM reads (219 648 FLOP/px for nvp_s); they add.
 #include "mlp_b3.h"
 
 #ifndef NVP_DW_B3
