@@ -162,3 +162,25 @@ def test_sin_only_polynomial_is_accurate():
     sn = fma((p * r2).astype(f), r, r)
     sn = np.where(n.astype(np.int64) & 1, -sn, sn)
     assert np.abs(sn - np.sin(x.astype(np.float64))).max() < 2e-7
+
+
+def test_sincos_pi_reduction_is_accurate():
+    """Host emulation of the default nvp_sincos (NVP_SINCOS_PI): one reduction by pi, degree-9 sine and degree-10 cosine."""
+    f = np.float32
+
+    def fma(a, b, c):
+        return f(np.float64(a) * np.float64(b) + np.float64(c))
+
+    x = ((np.random.default_rng(2).random(400000) * 2 - 1) * 1000).astype(f)
+    n = np.rint(x * f(0.318309886)).astype(f)
+    r = fma(n, f(-3.14159274), x)
+    r = fma(n, f(8.74227766e-08), r)
+    r2 = (r * r).astype(f)
+    p = fma(r2, f(2.6000545605e-06), f(-1.9806615092e-04)); p = fma(p, r2, f(8.3330172897e-03)); p = fma(p, r2, f(-1.6666657096e-01))
+    sn = fma((p * r2).astype(f), r, r)
+    c = fma(r2, f(-2.6077104766e-07), f(2.4761886211e-05)); c = fma(c, r2, f(-1.3888403507e-03)); c = fma(c, r2, f(4.1666640728e-02))
+    c = fma(c, r2, f(-4.9999999550e-01)); cs = fma(c, r2, f(1.0))
+    odd = n.astype(np.int64) & 1
+    sn = np.where(odd, -sn, sn); cs = np.where(odd, -cs, cs)
+    assert np.abs(sn - np.sin(x.astype(np.float64))).max() < 2e-7
+    assert np.abs(cs - np.cos(x.astype(np.float64))).max() < 2e-7
