@@ -102,3 +102,19 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
     }
 }
 
+// Two transposed GEMMs over the SAME input registers (the backward chain's dz and dh chains both consume dp): every k-step's
+// operand split is done once and feeds both weight streams.
+template <bool PF = true>
+__device__ __forceinline__ void chain_h2_b3(f32x16 (&acc_a)[4], const u32x4* __restrict__ wa, f32x16 (&acc_b)[4], const u32x4* __restrict__ wb,
+                                            const f32x16 (&hin)[4], int lane) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3<PF>(acc_a, wa + c * 12 * 64, bh, bm, bl, lane);
+        step_b3<PF>(acc_b, wb + c * 12 * 64, bh, bm, bl, lane);
+    }
+}

@@ -5,6 +5,9 @@
 // fused up to 128 rows, separate mlp_bwd_dz_b3_kernel beyond).
 #include "mlp_b3.h"
 
+#ifndef NVP_BWD_B3_SHARE
+#define NVP_BWD_B3_SHARE 1     // dz and dh chains share one operand split per k-step (dx' parked in LDS meanwhile): 2.44 -> 2.37 ms
+#endif
 #ifndef NVP_BWD_B3_PF
 #define NVP_BWD_B3_PF true       // operand prefetch inside a k-step: three more live quads, measured 2.51 vs 2.71 ms
 #endif
@@ -133,6 +136,52 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         chain_h_b3<NVP_BWD_B3_PF>(acc, dx, wp + nvp_bwd_b3_off(2 - k, 4) / 4, lane);   // streams 0 (sir2^T), 1 (sir1^T)
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+#if NVP_BWD_B3_SHARE
+        if (FUSE_DZ) {
+            // dz += W_k[:, 128:]^T dp_k and dh_{k-1} = W_k[:, :128]^T dp_k in ONE pass over dp (one operand split per
+            // k-step instead of two).  Both accumulators are live, so dx' waits in the wave's LDS tile meanwhile: the
+            // parked dz accumulator is swapped out for it before the pass and back in after it.
+            float4* park = reinterpret_cast<float4*>(xl);
+            f32x16 dzacc[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                if (k == 2) {
+                    dzacc[T] = nvp_zero16();
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 t = park[(T * 4 + g) * 64 + lane];
+                        dzacc[T][4 * g] = t.x; dzacc[T][4 * g + 1] = t.y; dzacc[T][4 * g + 2] = t.z; dzacc[T][4 * g + 3] = t.w;
+                    }
+                }
+                NVP_LOAD_FENCE();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)                        // dx' (tile T) takes the slot its dz quarter just left
+                    park[(T * 4 + g) * 64 + lane] = make_float4(dx[T][4 * g], dx[T][4 * g + 1], dx[T][4 * g + 2], dx[T][4 * g + 3]);
+                NVP_LOAD_FENCE();
+            }
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            chain_h2_b3<NVP_BWD_B3_PF>(dzacc, wp + nvp_bwd_b3_off(4 + k, 4) / 4, acc, wp + nvp_bwd_b3_off(4 - k, 4) / 4, dh, lane);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {                          // swap back: dx' into registers, dz accumulator into LDS
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = park[(T * 4 + g) * 64 + lane];
+                    dx[T][4 * g] = t.x; dx[T][4 * g + 1] = t.y; dx[T][4 * g + 2] = t.z; dx[T][4 * g + 3] = t.w;
+                }
+                NVP_LOAD_FENCE();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    park[(T * 4 + g) * 64 + lane] = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
+                nvp_pin(dx[T]);
+                NVP_LOAD_FENCE();
+            }
+            continue;
+        }
+#endif
         if (FUSE_DZ) {
             // dz += W_k[:, 128:]^T dp_k; the accumulator lives in LDS between layers (see above)
             float4* park = reinterpret_cast<float4*>(xl);
