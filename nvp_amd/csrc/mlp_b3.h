@@ -118,3 +118,13 @@ __device__ __forceinline__ void chain_h2_b3(f32x16 (&acc_a)[4], const u32x4* __r
         step_b3<PF>(acc_b, wb + c * 12 * 64, bh, bm, bl, lane);
     }
 }
+
+// the 16 values of table `t` for this lane's rows of tile T (see kB3TabFloats): four 16-B loads
+__device__ __forceinline__ void load_tab16(float (&v)[16], const float* __restrict__ tab, int t, int T, int h) {
+    const float4* p = reinterpret_cast<const float4*>(tab + ((t * 2 + h) * 4 + T) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 q = p[g];
+        v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w;
+    }
+}

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
     const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
     float* dyt = dy + tb;                  // dp0,dp1,dp2,(records),dq1,dq2
     const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
+    const float* tab = reinterpret_cast<const float*>(packed + nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)));      // sir_w0 / sir_b0 / last_w in D-register order
 
     // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
     // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
@@ -53,14 +54,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
 
     // ---- last layer: dx2 = V3^T drgb (VALU, 3 terms)
     {
-        const float* w3 = p.last_w;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
+            float v0[16], v1[16], v2[16];
+            load_tab16(v0, tab, 2, T, h);
+            load_tab16(v1, tab, 3, T, h);
+            load_tab16(v2, tab, 4, T, h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * T + nvp_frag_row(r, h);
-                dx[T][r] = __fmaf_rn(w3[2 * NVP_H + row], g2, __fmaf_rn(w3[NVP_H + row], g1, w3[row] * g0));
-            }
+            for (int r = 0; r < 16; ++r) dx[T][r] = __fmaf_rn(v2[r], g2, __fmaf_rn(v1[r], g1, v0[r] * g0));
             nvp_pin(dx[T]);
             NVP_LOAD_FENCE();
         }
@@ -246,11 +247,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
                 if (T == 0) fetch_dz(0);
                 if (T < 3) fetch_dz(T + 1);
             }
+            float w0v[16], c0v[16];
+            load_tab16(w0v, tab, 0, T, h);
+            load_tab16(c0v, tab, 1, T, h);
             NVP_LOAD_FENCE();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * T + nvp_frag_row(r, h);
-                const float q = 30.0f * __fmaf_rn(s, w0[row], c0[row]);
+                const float q = 30.0f * __fmaf_rn(s, w0v[r], c0v[r]);
                 float sn, cs;
                 nvp_sincos(q, sn, cs);
                 const float dxv = dx[T][r];

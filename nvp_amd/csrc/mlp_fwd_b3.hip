@@ -84,6 +84,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int rg_end = nvp_rows4(d) / 4;
     const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
+    const float* tab = reinterpret_cast<const float*>(packed + L.off[5]);      // sir_w0 / sir_b0 / last_w in D-register order
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
@@ -106,14 +107,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     }
     // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
     {
-        const float* w0 = p.sir_w[0];
-        const float* c0 = p.sir_b[0];
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
+            float w0v[16], c0v[16];
+            load_tab16(w0v, tab, 0, T, h);
+            load_tab16(c0v, tab, 1, T, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * T + nvp_frag_row(r, h);
-                const float q = 30.0f * __fmaf_rn(s, w0[row], c0[row]);
+                const float q = 30.0f * __fmaf_rn(s, w0v[r], c0v[r]);
                 x[T][r] = nvp_sin(q) * hm[T][r];
             }
             nvp_pin(x[T]);
@@ -153,17 +154,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     }
     // ---- last layer (3 x 128, Identity): VALU dot products + cross-half add
     {
-        const float* w3 = p.last_w;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
+            float v0[16], v1[16], v2[16];
+            load_tab16(v0, tab, 2, T, h);
+            load_tab16(v1, tab, 3, T, h);
+            load_tab16(v2, tab, 4, T, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * T + nvp_frag_row(r, h);
                 const float v = x[T][r];
-                o0 = __fmaf_rn(w3[row], v, o0);
-                o1 = __fmaf_rn(w3[NVP_H + row], v, o1);
-                o2 = __fmaf_rn(w3[2 * NVP_H + row], v, o2);
+                o0 = __fmaf_rn(v0[r], v, o0);
+                o1 = __fmaf_rn(v1[r], v, o1);
+                o2 = __fmaf_rn(v2[r], v, o2);
             }
             asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
             NVP_LOAD_FENCE();

@@ -127,6 +127,11 @@ __host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3(int d) {
     return L;
 }
 
+// Small per-row tables in D-REGISTER order, appended to both b3 packed buffers so that a lane fetches the 16 values of its
+// rows of one 32-row tile with four 16-B loads instead of 16 scalar ones: table id t (0 sir_w0, 1 sir_b0, 2..4 last_w rows
+// 0..2), lane half h, tile T, register r -> value at row 32 T + 8 (r>>2) + 4 h + (r&3):   tab[((t * 2 + h) * 4 + T) * 16 + r]
+constexpr int kB3TabFloats = 5 * 2 * 64;
+
 __host__ __device__ inline int nvp_b3_chain_in(int c, int h, int q) { return 32 * (c >> 1) + 8 * (2 * (c & 1) + (q >> 2)) + 4 * h + (q & 3); }
 
 // Backward b3 streams (A = W^T: row i = INPUT index 32T' + i, k = OUTPUT index nvp_b3_chain_in(c, h, q)), 8 steps each,

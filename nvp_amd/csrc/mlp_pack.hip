@@ -46,6 +46,15 @@ __device__ __forceinline__ unsigned nvp_bf16_rne(float f) {           // bf16 bi
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
+// the D-register-ordered tables behind a b3 packed buffer (mlp_layout.h, kB3TabFloats)
+__global__ __launch_bounds__(256) void pack_b3_tables_kernel(nvp_mlp_params p, float* __restrict__ tab) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kB3TabFloats) return;
+    const int r = idx & 15, T = (idx >> 4) & 3, h = (idx >> 6) & 1, t = idx >> 7;
+    const int row = 32 * T + 8 * (r >> 2) + 4 * h + (r & 3);
+    tab[idx] = t == 0 ? p.sir_w[0][row] : (t == 1 ? p.sir_b[0][row] : p.last_w[(t - 2) * NVP_H + row]);
+}
+
 // bf16 x 3 forward stream (mlp_layout.h "b3"): one thread per packed u32 = two consecutive k of one part
 __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
     const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
@@ -171,8 +180,8 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* 
 
 extern "C" {
 
-int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3(d).off[5] : nvp_fwd_layout(d).off[5]; }
-int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) ? nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)) : nvp_bwd_layout(d).off[7]; }
+int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3(d).off[5] + kB3TabFloats : nvp_fwd_layout(d).off[5]; }
+int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) ? nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)) + kB3TabFloats : nvp_bwd_layout(d).off[7]; }
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
     return nvp_param_layout(d).total * (int64_t)n_chunks;       // one full gradient record per pixel chunk
@@ -186,6 +195,7 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
         const int64_t nb = nvp_fwd_layout_b3(d).off[5];
         hipLaunchKernelGGL(pack_fwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
+        hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3TabFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
         NVP_LAUNCH_CHECK();
         return 0;
     }
@@ -200,6 +210,7 @@ int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
         const int64_t nb = nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d));
         hipLaunchKernelGGL(pack_bwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
+        hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3TabFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
         NVP_LAUNCH_CHECK();
         return 0;
     }

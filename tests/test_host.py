@@ -37,7 +37,8 @@ def test_library_size_queries_match_layout_arithmetic():
         # of 4 tiles x 3 parts x 64 lanes x 4 u32
         rows = (d + 3) // 4 * 4
         zs16 = (rows + 15) // 16
-        want = ((1 + zs16) + 2 * (9 + zs16) + 18) * 4 * 3 * 64 * 4 if rows <= 256 else steps * 64 * 4
+        # ... plus 5 tables x 2 lane halves x 64 rows in D-register order
+        want = ((1 + zs16) + 2 * (9 + zs16) + 18) * 4 * 3 * 64 * 4 + 640 if rows <= 256 else steps * 64 * 4
         assert lib.nvp_packed_fwd_floats(d) == want
         H = 128
         total = H * d + H + 2 * (H * (H + d) + H) + (H + H) + 2 * (H * H + H) + 3 * H + 3
