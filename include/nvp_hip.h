@@ -178,8 +178,10 @@ int nvp_mse_u8(const float* rgb, const uint8_t* gt_u8, float* drgb, float* loss_
  * ti [N], pi [N] int64 indices (drawn by the caller with torch.randint, temporal first,
  * same order as the reference); video u8 [T][H*W][3] resident on the device;
  * tcoord_tab = linspace(0,1,T), tstep_tab = linspace(.5/T, 1-.5/T, T) (dataio.py:93-99).
- * Writes coords [N,3] = (tcoord[ti], row/(H-1), col/(W-1)), steps [N], gt_u8 [N,3]. */
-int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi,
+ * Writes coords [N,3] = (tcoord[ti], row/(H-1), col/(W-1)), steps [N], gt_u8 [N,3].
+ * order (may be NULL): int64 [N] permutation - output row k is draw order[k] (the sampler delivers
+ * its batch sorted by image column without separate index passes). */
+int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi, const int64_t* order,
                       const float* tcoord_tab, const float* tstep_tab,
                       float* coords, float* steps, uint8_t* gt_u8,
                       int64_t n, int32_t t_frames, int32_t height, int32_t width, void* stream);

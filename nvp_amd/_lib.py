@@ -75,7 +75,7 @@ SIGNATURES = {
     "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _i64, _i32, _vp],
     "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
-    "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
+    "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
     "nvp_adamw_step": [C.POINTER(AdamwSeg), _i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _vp],
     "nvp_packed_fwd_floats": [_i32],
     "nvp_packed_bwd_floats": [_i32],

@@ -12,13 +12,15 @@ namespace {
 
 // coords = (tcoord_tab[ti], row/(H-1), col/(W-1)) with pi = row*W + col   (dataio.py:11-20,106-118)
 __global__ __launch_bounds__(256) void sample_gather_kernel(const uint8_t* __restrict__ video, const int64_t* __restrict__ ti,
-                                                            const int64_t* __restrict__ pi, const float* __restrict__ tcoord_tab,
+                                                            const int64_t* __restrict__ pi, const int64_t* __restrict__ order,
+                                                            const float* __restrict__ tcoord_tab,
                                                             const float* __restrict__ tstep_tab, float* __restrict__ coords,
                                                             float* __restrict__ steps, uint8_t* __restrict__ gt,
                                                             int64_t n, int height, int width) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
-    const int64_t t = ti[k], p = pi[k];
+    const int64_t src_k = order ? order[k] : k;          // optional delivery order (e.g. ascending image column)
+    const int64_t t = ti[src_k], p = pi[src_k];
     const int row = (int)(p / width), col = (int)(p - (int64_t)row * width);
     coords[k * 3 + 0] = tcoord_tab[t];
     coords[k * 3 + 1] = __fdiv_rn((float)row, (float)(height - 1));
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256) void mse_u8_kernel(const float* __restrict__ r
 
 extern "C" {
 
-int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi,
+int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi, const int64_t* order,
                       const float* tcoord_tab, const float* tstep_tab,
                       float* coords, float* steps, uint8_t* gt_u8,
                       int64_t n, int32_t t_frames, int32_t height, int32_t width, void* stream) {
@@ -60,7 +62,7 @@ int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi
         return NVP_ERR_BADARG;
     if (n == 0) return 0;
     hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       video, ti, pi, tcoord_tab, tstep_tab, coords, steps, gt_u8, n, height, width);
+                       video, ti, pi, order, tcoord_tab, tstep_tab, coords, steps, gt_u8, n, height, width);
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -69,17 +69,17 @@ class DeviceVideo:
         n = self.n
         ti = torch.randint(0, self.T, (n,), device=dev, generator=self.gen)
         pi = torch.randint(0, self.H * self.W, (n,), device=dev, generator=self.gen)
+        order = None
         if self.sort_by_y:
             # Same i.i.d. draws as the reference, delivered in ascending-y (= image column) order.  The MSE
             # is permutation-invariant; the order gives the grid gathers row locality and lets the
-            # gradient scatter skip one sort (NVP_COORDS_SORTED_BY_Y).
+            # gradient scatter skip one sort (NVP_COORDS_SORTED_BY_Y).  The gather kernel applies the permutation.
             order = torch.argsort((pi % self.W).to(torch.int16))
-            ti, pi = ti[order], pi[order]
         coords = torch.empty((n, 3), device=dev, dtype=torch.float32)
         steps = torch.empty((n,), device=dev, dtype=torch.float32)
         gt = torch.empty((n, 3), device=dev, dtype=torch.uint8)
         L.check(lib.nvp_sample_gather(L.ptr(self.video, torch.uint8), L.ptr(ti, torch.int64), L.ptr(pi, torch.int64),
-                                      L.ptr(self.tcoord_tab), L.ptr(self.tstep_tab), L.ptr(coords), L.ptr(steps),
+                                      L.ptr(order, torch.int64) if order is not None else None, L.ptr(self.tcoord_tab), L.ptr(self.tstep_tab), L.ptr(coords), L.ptr(steps),
                                       L.ptr(gt, torch.uint8), n, self.T, self.H, self.W, L.stream_ptr()), "nvp_sample_gather")
         mi = {"all_coords": coords.unsqueeze(0), "temporal_steps": steps.unsqueeze(0)}
         if self.sort_by_y:

@@ -523,10 +523,17 @@ def test_device_sampler_matches_reference_sampler_formulas():
     coords = torch.empty((n, 3), device=dev()); steps = torch.empty((n,), device=dev()); gt = torch.empty((n, 3), device=dev(), dtype=torch.uint8)
     lib = L.load()
     ti_d, pi_d = ti.to(dev()), pi.to(dev())            # keep the device copies alive across the launch
-    L.check(lib.nvp_sample_gather(L.ptr(vd, torch.uint8), L.ptr(ti_d, torch.int64), L.ptr(pi_d, torch.int64),
+    L.check(lib.nvp_sample_gather(L.ptr(vd, torch.uint8), L.ptr(ti_d, torch.int64), L.ptr(pi_d, torch.int64), None,
                                   L.ptr(data.tcoord_tab), L.ptr(data.tstep_tab), L.ptr(coords), L.ptr(steps), L.ptr(gt, torch.uint8),
                                   n, T, H, W, L.stream_ptr()), "nvp_sample_gather")
     assert torch.equal(coords.cpu(), coords_ref) and torch.equal(steps.cpu(), steps_ref) and torch.equal(gt.cpu(), gt_ref)
+    # with a delivery order: row k is draw order[k]
+    perm = torch.randperm(n, generator=gen)
+    perm_d = perm.to(dev())
+    L.check(lib.nvp_sample_gather(L.ptr(vd, torch.uint8), L.ptr(ti_d, torch.int64), L.ptr(pi_d, torch.int64), L.ptr(perm_d, torch.int64),
+                                  L.ptr(data.tcoord_tab), L.ptr(data.tstep_tab), L.ptr(coords), L.ptr(steps), L.ptr(gt, torch.uint8),
+                                  n, T, H, W, L.stream_ptr()), "nvp_sample_gather")
+    assert torch.equal(coords.cpu(), coords_ref[perm]) and torch.equal(steps.cpu(), steps_ref[perm]) and torch.equal(gt.cpu(), gt_ref[perm])
     # DeviceVideo: shapes, value ranges, and the y-sorted delivery is a permutation in ascending image-column order
     mi, g = harness.DeviceVideo(vd, n_samples=n, seed=5, sort_by_y=True).sample()
     c = mi["all_coords"][0]
