@@ -15,12 +15,16 @@
  *    enqueues work on it, never synchronises, never allocates;
  *  - return value: 0 on success, otherwise a hipError_t value (launch/config error) or
  *    NVP_ERR_* (<0) for argument errors; nothing throws;
- *  - "tiles" are groups of 32 consecutive pixels.  Pixel-tile-major (PTM) tensors are
- *    laid out [ntiles][rows][32] (row = feature / hidden unit, 32 pixels contiguous),
- *    ntiles = ceil(N/32); pixels >= N inside the last tile are zero-filled by the
- *    producers and ignored by the consumers.
- *  - `accumulate` outputs (parameter gradients of the grids) are ADDED into; the caller
- *    zero-fills them (that is autograd's dense-grad contract).
+ *  - "tiles" are groups of 32 consecutive pixels.  Pixel-tile-major tensors use the PTM4
+ *    layout [ntiles][rows/4][32 px][4]: rows (= features / hidden units) come in groups of
+ *    4 that are contiguous per pixel, the 32 pixels of a tile are contiguous per row-group,
+ *    so element (tile t, row r, pixel j) sits at ((t*(rows/4) + r/4)*32 + j)*4 + r%4 and a
+ *    lane's natural access is one 16-B piece.  rows is a multiple of 4 (the latent: D rounded
+ *    up; activations: 128), ntiles = ceil(N/32); pixels >= N inside the last tile are
+ *    zero-filled by the producers and ignored by the consumers.
+ *  - `accumulate` outputs (the stand-alone nvp_dense2d_bwd / nvp_sparse3x3_bwd gradients) are
+ *    ADDED into; the caller zero-fills them (autograd's dense-grad contract).
+ *    The fused nvp_encode_bwd OVERWRITES every gradient element instead (no zero-fill).
  */
 #ifndef NVP_HIP_H
 #define NVP_HIP_H
@@ -38,19 +42,30 @@ extern "C" {
 #define NVP_ERR_BADARG (-1)
 #define NVP_ERR_UNSUPPORTED (-2)
 
-/* nvp_encode_bwd flags */
-#define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: skips one radix sort */
+/* nvp_encode_fwd / nvp_encode_bwd flags */
+#define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: the scatter skips one radix sort,
+                                      the gather stages the xy / yt grid rows of a pixel run in LDS */
+
+/* nvp_levels.flags: arithmetic variant of the dense grid (the tiny-cuda-nn fork the reference installs,
+ * README.md:30-32, is absent from /root/reference, so the points where published tiny-cuda-nn and a plain
+ * restatement differ are switchable; nvp_amd/csrc/grid_math.h).  Default = all of POS_FMA | INTERP_FMA. */
+#define NVP_GRID_POS_FMA 1      /* pos = fmaf(scale, x, 0.5f) (upstream pos_fract); else fl(fl(x*scale)+0.5f) */
+#define NVP_GRID_INTERP_FMA 2   /* corner blend is an fma chain (upstream); else separately rounded mul + add */
+#define NVP_GRID_CLAMP 4        /* corner i+1 clamps to res-1; else the cell index wraps mod res^2 (upstream) */
 
 /* Geometry of one 2D multi-resolution dense grid (one "learnable keyframe" plane).
  * Built on the host exactly as the reference restates it, eval.py:28-35:
  *   a = exp(l*log(per_level_scale))*base - 1 (double); res = ceil(a)+1; offset += res^2.
- * `scale` is `a` rounded once to fp32.  offset[] counts CELLS (multiply by n_features). */
+ * res/offset always follow that formula (the reference pins them).  `scale` is what the kernels multiply
+ * with: by default upstream's fp32 `exp2f(l*log2f(per_level_scale))*base - 1` (grid_scale), or `a` rounded
+ * once to fp32 (encoding_config "scale_mode": "double").  offset[] counts CELLS (multiply by n_features). */
 typedef struct nvp_levels {
     int32_t n_levels;
     int32_t n_features;                   /* F: 1, 2, 4 or 8 */
     float scale[NVP_MAX_LEVELS];
     int32_t res[NVP_MAX_LEVELS];
     int32_t offset[NVP_MAX_LEVELS + 1];
+    int32_t flags;                        /* NVP_GRID_* */
 } nvp_levels;
 
 /* Shape of the 3D sparse positional-feature grid, embeddings[T][X][Y][F]
@@ -88,7 +103,7 @@ int64_t nvp_packed_fwd_floats(int32_t latent_dim);
 int64_t nvp_packed_bwd_floats(int32_t latent_dim);
 int64_t nvp_dw_partial_floats(int32_t latent_dim, int32_t n_chunks);
 int64_t nvp_mlp_param_floats(int32_t latent_dim);
-int32_t nvp_latent_rows(int32_t latent_dim);   /* rows of a PTM latent tensor (D rounded up to even) */
+int32_t nvp_latent_rows(int32_t latent_dim);   /* rows of a PTM4 latent tensor (D rounded up to a multiple of 4) */
 int32_t nvp_dz_stride(int32_t latent_dim);     /* row stride of the row-major latent gradient (D rounded up to 4) */
 
 /* ---- R2/R3: tinycudann.Encoding forward / backward (reference modules.py:65-67) ---
@@ -109,7 +124,7 @@ int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, i
                             const nvp_sparse_shape* sh, void* stream);
 
 /* ---- R11 (encoding half of NVP.forward, modules.py:57-78), fused ------------------
- * coords [N,3] -> PTM latent zt [ntiles][rows][32], rows = nvp_latent_rows(D),
+ * coords [N,3] -> PTM4 latent zt [ntiles][rows/4][32][4], rows = nvp_latent_rows(D),
  * D = sum_p L_p*F_p + 9*F_s, row order xy | yt | xt | sparse (modules.py:69,78).
  * temporal_interp != 0 selects forward_inter for the sparse part (modules.py:72-73). */
 int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, const float* kf_xt,
@@ -131,7 +146,7 @@ int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
                    void* stream);
 
-/* Row-major [N,D] <-> PTM [ntiles][rows][32] (used by the stand-alone SirenWrapper). */
+/* Row-major [N,D] <-> PTM4 [ntiles][rows/4][32][4] (used by the stand-alone SirenWrapper). */
 int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream);
 int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream);
 
@@ -142,9 +157,9 @@ int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t 
  *       nvp_packed_{fwd,bwd}_floats(latent_dim) and their format is whatever the fwd /
  *       bwd_dx kernels of this build consume (fp32 k-steps, or hi/mid/lo bf16 operand
  *       quads for the bf16x3 split-MFMA kernels used when the latent has <= 128 rows).
- * fwd : zt PTM latent, steps [N] -> rgb [N,3] row-major; `saved` receives the five
- *       activations backward needs (h0,h1,h2 post-LeakyReLU, q1,q2 pre-sine), each PTM
- *       [ntiles][128][32]; pass NULL for inference (nothing is stored). */
+ * fwd : zt PTM4 latent, steps [N] -> rgb [N,3] row-major; `saved` receives the five
+ *       activations backward needs (h0,h1,h2 post-LeakyReLU, q1,q2 pre-sine), each PTM4
+ *       [ntiles][128/4][32][4]; pass NULL for inference (nothing is stored). */
 int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t latent_dim, void* stream);
 int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t latent_dim, void* stream);
 int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
@@ -152,7 +167,7 @@ int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, co
 
 /* ---- R12: autograd of R8-R10 (reference training.py:74).
  * bwd_dx: drgb [N,3] -> dz_rows (latent gradient, ROW-MAJOR [ntiles*32][nvp_dz_stride(D)])
- *         + `dy`, six slots of [ntiles][128][32] floats: slots 0,1,2,4,5 are the PTM4 streams
+ *         + `dy`, six slots of ntiles*128*32 floats: slots 0,1,2,4,5 are the PTM4 streams
  *         dp0,dp1,dp2 (modulator pre-activation grads), dq1, dq2 the weight-gradient GEMMs
  *         consume; slot 3 holds, per 32-pixel tile, a 644-float record of the last layer's and
  *         SIREN layer 0's gradients already summed over the tile (layout kRec* in mlp_layout.h).

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libnvp_hip.so")
 
 NVP_MAX_LEVELS = 16
 COORDS_SORTED_BY_Y = 1
+GRID_POS_FMA, GRID_INTERP_FMA, GRID_CLAMP = 1, 2, 4      # nvp_levels.flags (include/nvp_hip.h)
 HIDDEN = 128
 TILE = 32
 
@@ -30,6 +31,7 @@ class Levels(C.Structure):
         ("scale", C.c_float * NVP_MAX_LEVELS),
         ("res", C.c_int32 * NVP_MAX_LEVELS),
         ("offset", C.c_int32 * (NVP_MAX_LEVELS + 1)),
+        ("flags", C.c_int32),
     ]
 
 
@@ -143,8 +145,41 @@ def ntiles(n: int) -> int:
     return (n + TILE - 1) // TILE
 
 
+def _f32(x: float) -> float:
+    """x rounded once to fp32 (as a Python float)."""
+    return C.c_float(x).value
+
+
+def grid_variant(cfg: dict):
+    """(flags, scale_mode) of a dense-grid encoding_config.
+
+    The tiny-cuda-nn fork the reference installs (README.md:30-32) is not under /root/reference, so the
+    arithmetic details the reference does not pin are switchable (hard part 7):
+      "variant": "tcnn" (default)  - published tiny-cuda-nn: pos = fmaf(scale, x, 0.5f), corner blend as an fma
+                                     chain, scale = fp32 exp2f(l * log2f(per_level_scale)) * base - 1
+                 "two_rounding"    - pos = fl(fl(x*scale) + 0.5f), separately rounded mul/add blend, scale =
+                                     eval.py:28's double formula rounded once to fp32 (the round-1 behaviour)
+      "border":  "wrap" (default, upstream `index % hashmap_size`) | "clamp"
+      "scale_mode": "fp32_exp2" | "double" overrides the variant's scale arithmetic.
+    Environment overrides (for whole-model experiments): NVP_DENSE_VARIANT, NVP_DENSE_BORDER, NVP_DENSE_SCALE."""
+    variant = os.environ.get("NVP_DENSE_VARIANT") or cfg.get("variant", "tcnn")
+    border = os.environ.get("NVP_DENSE_BORDER") or cfg.get("border", "wrap")
+    if variant not in ("tcnn", "two_rounding"):
+        raise ValueError(f"dense-grid variant {variant!r}: expected 'tcnn' or 'two_rounding'")
+    if border not in ("wrap", "clamp"):
+        raise ValueError(f"dense-grid border {border!r}: expected 'wrap' or 'clamp'")
+    flags = (GRID_POS_FMA | GRID_INTERP_FMA) if variant == "tcnn" else 0
+    if border == "clamp":
+        flags |= GRID_CLAMP
+    scale_mode = os.environ.get("NVP_DENSE_SCALE") or cfg.get("scale_mode", "fp32_exp2" if variant == "tcnn" else "double")
+    if scale_mode not in ("fp32_exp2", "double"):
+        raise ValueError(f"dense-grid scale_mode {scale_mode!r}: expected 'fp32_exp2' or 'double'")
+    return flags, scale_mode
+
+
 def make_levels(cfg: dict) -> Levels:
-    """Host-side level table, same arithmetic as the reference's eval.py:28-35."""
+    """Host-side level table.  Resolutions and offsets: the reference's eval.py:28-35 arithmetic (pinned).
+    `scale`: see grid_variant()."""
     lv = Levels()
     n_levels = int(cfg["n_levels"])
     if not 1 <= n_levels <= NVP_MAX_LEVELS:
@@ -153,11 +188,23 @@ def make_levels(cfg: dict) -> Levels:
     lv.n_features = int(cfg["n_features_per_level"])
     base = float(cfg.get("base_resolution", 16))
     pls = float(cfg["per_level_scale"])
+    flags, scale_mode = grid_variant(cfg)
+    lv.flags = flags
+    log2_pls = _f32(math.log2(_f32(pls)))           # upstream: std::log2 of the float per_level_scale
     total = 0
     for lvl in range(n_levels):
         a = math.exp(lvl * math.log(pls)) * base - 1.0
         res = int(math.ceil(a) + 1)
-        lv.scale[lvl] = a            # ctypes rounds the double to fp32 once
+        if scale_mode == "fp32_exp2":
+            # grid_scale(): exp2f(level * log2_per_level_scale) * base_resolution - 1.0f, every step rounded to fp32
+            e = _f32(2.0 ** _f32(float(lvl) * log2_pls))
+            s = _f32(_f32(e * _f32(base)) - 1.0)
+            if int(math.ceil(s) + 1) != res:
+                raise ValueError(f"level {lvl}: fp32 scale {s} gives resolution {int(math.ceil(s) + 1)}, the reference's "
+                                 f"eval.py arithmetic {res}; use scale_mode='double' for this encoding_config")
+            lv.scale[lvl] = s
+        else:
+            lv.scale[lvl] = a        # ctypes rounds the double to fp32 once
         lv.res[lvl] = res
         lv.offset[lvl] = total
         total += res * res

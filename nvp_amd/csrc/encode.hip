@@ -13,7 +13,7 @@
 // Index arithmetic reproduces the reference's separately rounded fp32 ops
 // (sparsegrid.py:44-46): products and sums go through __fmul_rn/__fadd_rn so hipcc cannot
 // contract them into an FMA and flip a cell at a .5 boundary.
-#include "nvp_common.h"
+#include "grid_math.h"
 
 // __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
 // index and interpolation arithmetic keeps the reference's separately rounded multiply and add.
@@ -24,45 +24,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kLevelsPerSlot = 4;
 
-// ---- index helpers ---------------------------------------------------------------
-// clamp(int64(fp32((res-1)*c) + 0.5), 0, res-1)   reference sparsegrid.py:44-46
-__device__ __forceinline__ int nearest_idx(float c, int res) {
-    float f = __fmul_rn((float)(res - 1), c);
-    int i = (int)__fadd_rn(f, 0.5f);          // cvt truncates toward zero like .type(int64)
-    return min(max(i, 0), res - 1);
-}
-
-struct Bilerp {
-    int cell[4];     // corner cells (level-local), order (0,0),(1,0),(0,1),(1,1)
-    float w[4];
-};
-
-// Dense-grid level lookup, tiny-cuda-nn GridEncoding semantics (oracle: dense_grid_2d):
-// pos = x*scale + 0.5 (two roundings); i = floor(pos); w = pos - i;
-// cell = (ix + iy*res) mod res^2.
-__device__ __forceinline__ Bilerp bilerp_setup(float x0, float x1, float scale, int res) {
-    float p0 = __fadd_rn(__fmul_rn(x0, scale), 0.5f);
-    float p1 = __fadd_rn(__fmul_rn(x1, scale), 0.5f);
-    float f0 = floorf(p0), f1 = floorf(p1);
-    float w0 = __fsub_rn(p0, f0), w1 = __fsub_rn(p1, f1);
-    int i0 = (int)f0, i1 = (int)f1;
-    float u0 = __fsub_rn(1.0f, w0), u1 = __fsub_rn(1.0f, w1);
-    int size = res * res;
-    Bilerp b;
-    b.w[0] = __fmul_rn(u0, u1);
-    b.w[1] = __fmul_rn(w0, u1);
-    b.w[2] = __fmul_rn(u0, w1);
-    b.w[3] = __fmul_rn(w0, w1);
-    int base = i0 + i1 * res;
-    // (i0+c0) + (i1+c1)*res, wrapped into the level like tcnn's `index % hashmap_size`
-    int c00 = base, c10 = base + 1, c01 = base + res, c11 = base + res + 1;
-    b.cell[0] = c00 % size; if (b.cell[0] < 0) b.cell[0] += size;
-    b.cell[1] = c10 % size; if (b.cell[1] < 0) b.cell[1] += size;
-    b.cell[2] = c01 % size; if (b.cell[2] < 0) b.cell[2] += size;
-    b.cell[3] = c11 % size; if (b.cell[3] < 0) b.cell[3] += size;
-    return b;
-}
-
+// index / interpolation arithmetic: grid_math.h (switchable dense-grid variant, nvp_levels.flags)
 template <int F>
 struct Vec { float v[F]; };
 
@@ -118,20 +80,14 @@ __device__ __forceinline__ void dense_slot_fwd(const float* __restrict__ params,
 #pragma unroll
         for (int f = 0; f < F; ++f) acc[f] = 0.f;
         if (valid) {
-            Bilerp b = bilerp_setup(x0, x1, lv.scale[l], lv.res[l]);
+            NvpBilerp b = nvp_bilerp_setup(x0, x1, lv.scale[l], lv.res[l], lv.flags);
             const float* base = params + (int64_t)lv.offset[l] * F;
             Vec<F> v0 = load_vec<F>(base + (int64_t)b.cell[0] * F);
             Vec<F> v1 = load_vec<F>(base + (int64_t)b.cell[1] * F);
             Vec<F> v2 = load_vec<F>(base + (int64_t)b.cell[2] * F);
             Vec<F> v3 = load_vec<F>(base + (int64_t)b.cell[3] * F);
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                float a = __fmul_rn(b.w[0], v0.v[f]);
-                a = __fadd_rn(a, __fmul_rn(b.w[1], v1.v[f]));
-                a = __fadd_rn(a, __fmul_rn(b.w[2], v2.v[f]));
-                a = __fadd_rn(a, __fmul_rn(b.w[3], v3.v[f]));
-                acc[f] = a;
-            }
+            for (int f = 0; f < F; ++f) acc[f] = nvp_blend4(b.w, v0.v[f], v1.v[f], v2.v[f], v3.v[f], lv.flags);
         }
 #pragma unroll
         for (int f = 0; f < F; ++f) res[dl * F + f] = acc[f];
@@ -152,7 +108,7 @@ __device__ __forceinline__ void dense_slot_bwd(float* __restrict__ dparams, cons
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = dout[out_addr<PTM>(px, col0 + l * F + f, ncols)]; any |= (g[f] != 0.f); }
         if (!any) continue;
-        Bilerp b = bilerp_setup(x0, x1, lv.scale[l], lv.res[l]);
+        NvpBilerp b = nvp_bilerp_setup(x0, x1, lv.scale[l], lv.res[l], lv.flags);
         float* base = dparams + (int64_t)lv.offset[l] * F;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -172,14 +128,14 @@ struct Patch {
 
 __device__ __forceinline__ Patch patch_setup(float t, float x, float y, const nvp_sparse_shape& sh, bool inter) {
     Patch p;
-    int xi = nearest_idx(x, sh.x_res), yi = nearest_idx(y, sh.y_res);
+    int xi = nvp_nearest_idx(x, sh.x_res), yi = nvp_nearest_idx(y, sh.y_res);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         p.vx[d] = min(max(xi + d - 1, 0), sh.x_res - 1);
         p.vy[d] = min(max(yi + d - 1, 0), sh.y_res - 1);
     }
     if (!inter) {
-        p.t_lo = p.t_hi = nearest_idx(t, sh.t_res);
+        p.t_lo = p.t_hi = nvp_nearest_idx(t, sh.t_res);
         p.w_lo = 1.f; p.w_hi = 0.f;
     } else {
         // reference sparsegrid.py:98-109 (note: lc is divided by the UPDATED uc + lc)

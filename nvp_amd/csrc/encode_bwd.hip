@@ -28,7 +28,7 @@
 // N contributions cannot overflow 2^62; each contribution keeps >= 40 significant bits below
 // max|dz| (fp32 carries 24), so the scatter is more accurate than an fp32 atomic chain.
 #include <cstring>
-#include "nvp_common.h"
+#include "grid_math.h"
 #include <rocprim/rocprim.hpp>
 
 #pragma clang fp contract(off)
@@ -196,7 +196,10 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
     const int qmax = (nl * F - 1) >> 2;
     const int* order = A.order[plane];
     const int q = t % NV, pp = t / NV;
-    float ms = 0.f;
+    // max|dz| is taken on the BIT PATTERNS of |v| (unsigned compare): finite values order like floats, Inf and NaN
+    // sort above every finite value, so a non-finite latent gradient reaches the band kernels, which then poison
+    // their output with NaN (fmaxf would silently drop a NaN and to_fixed would turn it into a finite integer).
+    unsigned ms = 0u;
     // ---- phase 1: coalesced segment reads -> LDS
 #pragma unroll
     for (int i = 0; i < PIX / PPP; ++i) {
@@ -208,7 +211,8 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
             if (q <= qmax) v = reinterpret_cast<const float4*>(dz + (int64_t)id * dz_stride + A.col0[plane])[q];
             if (plane == 2 && 4 * q < A.scols) {       // the sparse columns follow this plane's segment in the same row
                 const float4 sv = reinterpret_cast<const float4*>(dz + (int64_t)id * dz_stride + A.scol0)[q];
-                ms = fmaxf(ms, fmaxf(fmaxf(fabsf(sv.x), fabsf(sv.y)), fmaxf(fabsf(sv.z), fabsf(sv.w))));
+                ms = max(ms, max(max(__float_as_uint(fabsf(sv.x)), __float_as_uint(fabsf(sv.y))),
+                                 max(__float_as_uint(fabsf(sv.z)), __float_as_uint(fabsf(sv.w)))));
             }
         }
         float* d = tile + pix * STRIDE + 4 * q;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
     }
     __syncthreads();
     // ---- phase 2: thread = pixel, level-major stores
-    float m = 0.f;
+    unsigned m = 0u;
     for (int pix = t; pix < PIX; pix += 256) {
         const int64_t p = p0 + pix;
         if (p < n) {
@@ -230,22 +234,22 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
                 if (l >= nl) break;
                 float v[F];
 #pragma unroll
-                for (int f = 0; f < F; ++f) { v[f] = srow[l * F + f]; m = fmaxf(m, fabsf(v[f])); }
+                for (int f = 0; f < F; ++f) { v[f] = srow[l * F + f]; m = max(m, __float_as_uint(fabsf(v[f]))); }
 #pragma unroll
                 for (int f = 0; f < F; ++f) dst[((int64_t)l * n + p) * F + f] = v[f];
             }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); ms = fmaxf(ms, __shfl_xor(ms, o)); }
+    for (int o = 32; o > 0; o >>= 1) { m = max(m, (unsigned)__shfl_xor((int)m, o)); ms = max(ms, (unsigned)__shfl_xor((int)ms, o)); }
     if ((t & 63) == 0) {
         const int slot = (blockIdx.x * 4 + (t >> 6)) & (kMaxSlots - 1);
-        if (m > 0.f) atomicMax(dzmax + slot, __float_as_uint(m));
-        if (plane == 2 && ms > 0.f) atomicMax(A.sdzmax + slot, __float_as_uint(ms));
+        if (m > 0u) atomicMax(dzmax + slot, m);
+        if (plane == 2 && ms > 0u) atomicMax(A.sdzmax + slot, ms);
     }
 }
 
-__device__ __forceinline__ int row_of(float c1, float scale) { return (int)floorf(c1 * scale + 0.5f); }
+__device__ __forceinline__ int row_of(float c1, float scale, int flags) { return (int)floorf(nvp_grid_pos(c1, scale, flags)); }
 
 struct RowArgs {
     const float2* cs[3];
@@ -264,11 +268,12 @@ __global__ __launch_bounds__(256) void rowstart_kernel(RowArgs A, int64_t n) {
     while (l + 1 < A.lv[plane].n_levels && idx >= A.rs_off[plane][l + 1]) ++l;
     const int r = idx - A.rs_off[plane][l];
     const float scale = A.lv[plane].scale[l];
+    const int flags = A.lv[plane].flags;
     const float2* cs = A.cs[plane];
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (row_of(cs[mid].y, scale) >= r) hi = mid; else lo = mid + 1;
+        if (row_of(cs[mid].y, scale, flags) >= r) hi = mid; else lo = mid + 1;
     }
     A.rowstart[plane][idx] = (int)lo;
 }
@@ -304,6 +309,7 @@ template <int F>
 __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t n) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ int s_k;
+    __shared__ bool s_poison;
     // ---- decode the work item
     int plane = 0, level = 0;
     {
@@ -332,10 +338,12 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
         if (threadIdx.x == 0) {
             const int e = (int)((m >> 23) & 0xff) - 127;            // floor(log2 max|dz|); m == 0 -> -127
             s_k = 62 - A.headroom_bits - (e + 1);
+            s_poison = m >= 0x7f800000u;                            // an Inf / NaN latent gradient somewhere in the batch
         }
     }
     __syncthreads();
     const int k = s_k;
+    const int lflags = A.lv[plane].flags;
 
     // ---- sorted pixel ranges that can touch rows [r0, r1): rows iy in [r0-2, r1-1], plus the
     //      wrap-around of the last two rows into rows 0/1 (cell index is taken mod res^2)
@@ -357,20 +365,12 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
         if (!any) continue;
-        const float p0 = c.x * scale + 0.5f, p1 = c.y * scale + 0.5f;
-        const float f0 = floorf(p0), f1 = floorf(p1);
-        const float w0 = p0 - f0, w1 = p1 - f1;
-        const int i0 = (int)f0, i1 = (int)f1;
-        const float u0 = 1.0f - w0, u1 = 1.0f - w1;
+        const NvpBilerp bl = nvp_bilerp_setup(c.x, c.y, scale, res, lflags);
 #pragma unroll
         for (int cnr = 0; cnr < 4; ++cnr) {
-            const int a = cnr & 1, b = cnr >> 1;
-            int cell = (i0 + a) + (i1 + b) * res;
-            const int size = res * res;
-            if ((unsigned)cell >= (unsigned)size) { cell %= size; if (cell < 0) cell += size; }
-            const int off = cell - r0 * res;              // row test: cell in [r0*res, r1*res)
+            const int off = bl.cell[cnr] - r0 * res;      // row test: cell in [r0*res, r1*res)
             if (off < 0 || off >= (r1 - r0) * res) continue;
-            const float w = (a ? w0 : u0) * (b ? w1 : u1);
+            const float w = bl.w[cnr];
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const long long q = to_fixed(w * g[f], k);
@@ -385,6 +385,10 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     const int64_t lvl_off = (int64_t)A.lv[plane].offset[level] * F;
     float* dst = (L.slab_off < 0) ? A.grad[plane] + lvl_off + (int64_t)r0 * res * F
                                   : A.slabs + L.slab_off + (int64_t)split * res * res * F + (int64_t)r0 * res * F;
+    if (s_poison) {          // non-finite dz: the reference's index_put / atomics would carry NaN / Inf; fixed point cannot, so say so loudly
+        for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = (float)((double)(long long)tab[i] * inv);
 }
 
@@ -420,12 +424,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceArgs A) {
 // with x_idx in [r0-1, r1]: a pixel's clamped 3x3 patch only touches x rows x_idx-1..x_idx+1.
 // Clamped border duplicates accumulate exactly like the reference's index_put_(accumulate=True).
 // Every cell of the gradient is written exactly once (zeros included): no memset, no atomics.
-__device__ __forceinline__ int nearest_idx(float c, int res) {
-    float f = (float)(res - 1) * c;
-    int i = (int)(f + 0.5f);
-    return min(max(i, 0), res - 1);
-}
-
 #ifndef NVP_SPARSE_ENTRIES
 #define NVP_SPARSE_ENTRIES 3000
 #endif
@@ -436,7 +434,7 @@ __global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restric
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float* c = coords + i * 3;
-    keys[i] = (unsigned)(nearest_idx(c[0], sh.t_res) * sh.x_res + nearest_idx(c[1], sh.x_res));
+    keys[i] = (unsigned)(nvp_nearest_idx(c[0], sh.t_res) * sh.x_res + nvp_nearest_idx(c[1], sh.x_res));
 }
 
 // srowstart[k] = first sorted position whose key is >= k, k in [0, T*X]
@@ -457,6 +455,7 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
                                                                      nvp_sparse_shape sh, int rows_per_band, int bands, int headroom_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ int s_k;
+    __shared__ bool s_poison;
     const int F = sh.n_features;
     const int t = blockIdx.x / bands, band = blockIdx.x - t * bands;
     const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
@@ -467,7 +466,7 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
         for (int i = threadIdx.x; i < kMaxSlots; i += 64) m = max(m, dzmax[i]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (threadIdx.x == 0) s_k = 62 - headroom_bits - ((int)((m >> 23) & 0xff) - 127 + 1);
+        if (threadIdx.x == 0) { s_k = 62 - headroom_bits - ((int)((m >> 23) & 0xff) - 127 + 1); s_poison = m >= 0x7f800000u; }
     }
     __syncthreads();
     const int k = s_k;
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
         const int p = lo + u / 9, cell9 = u - (u / 9) * 9;
         const int id = order[p];
         const float* c = coords + (int64_t)id * 3;
-        const int xi = nearest_idx(c[1], sh.x_res), yi = nearest_idx(c[2], sh.y_res);
+        const int xi = nvp_nearest_idx(c[1], sh.x_res), yi = nvp_nearest_idx(c[2], sh.y_res);
         const int i = cell9 / 3, j = cell9 - i * 3;
         const int vx = min(max(xi + i - 1, 0), sh.x_res - 1);
         if (vx < r0 || vx >= r1) continue;
@@ -494,6 +493,10 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
     __syncthreads();
     const double inv = ldexp(1.0, -k);
     float* out = demb + (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
+    if (s_poison) {
+        for (int i = threadIdx.x; i < entries; i += kSparseThreads) out[i] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     for (int i = threadIdx.x; i < entries; i += kSparseThreads) out[i] = (float)((double)(long long)tab[i] * inv);
 }
 

@@ -59,6 +59,12 @@ GRIDS_READY_HOOK = None
 # sort.  Only worth it for training-size batches; 0 disables.
 AUTO_SORT_MIN = int(os.environ.get("NVP_AUTO_SORT_MIN", "65536"))
 
+# model_input['sorted_by_y'] is a promise by the caller (nvp_amd's own sampler makes it): the gradient scatter then skips
+# its y radix sort and binary-searches row starts in the batch as delivered, so a wrong hint gives silently wrong keyframe
+# gradients.  NVP_CHECK_SORTED=1 verifies the promise on every call (one pass over N floats + a host sync): for debugging
+# and for tests; off by default because the sync would serialise the training loop.
+CHECK_SORTED = os.environ.get("NVP_CHECK_SORTED", "0") == "1"
+
 # Optional gradient sink (data parallelism): {param.data_ptr(): preallocated tensor}.  When a
 # parameter has an entry, backward writes its gradient straight into that tensor (a view of the
 # flat all-reduce bucket) and returns it, so no zero-fill / accumulate / flatten pass exists.
@@ -251,6 +257,27 @@ class ModulatedSiren(torch.autograd.Function):
         return (dz_rows[:n, :d].contiguous(), None, None, *grads)
 
 
+def modulated_siren_streams(latent: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tensor]) -> dict:
+    """Run the fused forward kernel with its save path on and return what it saved, converted from PTM4 to row-major
+    [N,128]: h0,h1,h2 (the Modulator outputs, modulation.py:112-121) and q1,q2 (pre-sine SIREN activations)."""
+    lib = L.load()
+    latent = _f32c(latent)
+    n, d = latent.shape
+    steps = _f32c(steps).reshape(-1)
+    mlp = [_f32c(t) for t in mlp]
+    _check_mlp(mlp, d)
+    rows = lib.nvp_latent_rows(d)
+    zt = torch.empty((L.ntiles(n), rows, L.TILE), device=latent.device, dtype=torch.float32)
+    L.check(lib.nvp_rows_to_ptm(L.ptr(latent), L.ptr(zt), n, d, rows, L.stream_ptr()), "nvp_rows_to_ptm")
+    _, saved = _mlp_forward(zt, steps, mlp, n, d, save=True)
+    out = {}
+    for k, name in enumerate(("h0", "h1", "h2", "q1", "q2")):
+        r = torch.empty((n, L.HIDDEN), device=latent.device, dtype=torch.float32)
+        L.check(lib.nvp_ptm_to_rows(L.ptr(saved[k]), L.ptr(r), n, L.HIDDEN, L.HIDDEN, L.stream_ptr()), "nvp_ptm_to_rows")
+        out[name] = r
+    return out
+
+
 class NVPFused(torch.autograd.Function):
     """NVP.forward hot path (R11): coords [N,3], steps [N] -> rgb [N,3] in four kernels
     (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""
@@ -272,6 +299,9 @@ class NVPFused(torch.autograd.Function):
         rows = lib.nvp_latent_rows(d)
         dev = coords.device
         need_grad = bool(grad_mode) and any(ctx.needs_input_grad)
+        if y_sorted and CHECK_SORTED and n > 1 and not bool((coords[1:, 2] >= coords[:-1, 2]).all()):
+            raise RuntimeError("model_input['sorted_by_y'] is set but all_coords[..., 2] is not non-decreasing "
+                               "(the gradient scatter would produce wrong keyframe gradients)")
         order = None
         if need_grad and not y_sorted and not temporal_interp and AUTO_SORT_MIN > 0 and n >= AUTO_SORT_MIN:
             order = torch.argsort(coords[:, 2])

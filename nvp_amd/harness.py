@@ -74,7 +74,8 @@ class DeviceVideo:
             # Same i.i.d. draws as the reference, delivered in ascending-y (= image column) order.  The MSE
             # is permutation-invariant; the order gives the grid gathers row locality and lets the
             # gradient scatter skip one sort (NVP_COORDS_SORTED_BY_Y).  The gather kernel applies the permutation.
-            order = torch.argsort((pi % self.W).to(torch.int16))
+            # 16-bit keys halve the radix passes; wider frames than 32 767 columns keep 32-bit keys (int16 would wrap)
+            order = torch.argsort((pi % self.W).to(torch.int16 if self.W <= 32767 else torch.int32))
         coords = torch.empty((n, 3), device=dev, dtype=torch.float32)
         steps = torch.empty((n,), device=dev, dtype=torch.float32)
         gt = torch.empty((n, 3), device=dev, dtype=torch.uint8)
@@ -149,21 +150,66 @@ def train_psnr(loss: torch.Tensor) -> float:
 
 
 @torch.no_grad()
-def eval_psnr(model, video: DeviceVideo, frames, n_slice: int = 100) -> float:
-    """Per-frame PSNR on [0,1] as eval.py:243-256: (img+1)/2, clamp, vs u8/255, mean over frames."""
-    hw = video.H * video.W
-    step = (hw + n_slice - 1) // n_slice
+def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[int] = None, temporal_interp: bool = False,
+                 n_slice: int = 100) -> torch.Tensor:
+    """One output frame of the reference's inference loop (eval.py:219-245): [H', W', 3] on the device, in [0, 1].
+
+    resolution = (H', W') of the QUERY lattice (eval.py:201-204: the video's resolution times --s_interp);
+    nframes = number of output frames (eval.py:205-210: the video's frame count times --t_interp);
+    org_nframes = the video's own frame count, which fixes half_dt (eval.py:224).
+    Frame f: temporal coordinate linspace(0,1,nframes)[f], modulation input linspace(half_dt, 1-half_dt, nframes)[f];
+    pixels are evaluated in n_slice slices of int(H'W'/n_slice) (eval.py:233-239: a remainder beyond the last slice stays
+    0, i.e. 0.5 after the (img+1)/2 map - reference behaviour); temporal_interp routes the sparse grid through
+    forward_inter (modules.py:72-73), whose t == 1 rows are NaN (the last frame of a --t_interp run; clamp keeps NaN)."""
+    dev = next(model.parameters()).device
+    nframes = org_nframes if nframes is None else nframes
+    Hq, Wq = int(resolution[0]), int(resolution[1])
+    total = Hq * Wq
+    rows = torch.arange(Hq, device=dev, dtype=torch.float32) / max(Hq - 1, 1)
+    cols = torch.arange(Wq, device=dev, dtype=torch.float32) / max(Wq - 1, 1)      # dataio.get_mgrid: k / (side - 1)
+    half_dt = 0.5 / org_nframes
+    tstep = torch.linspace(half_dt, 1 - half_dt, nframes)[f].item()
+    tcoord = torch.linspace(0, 1, nframes)[f].item()
+    out = torch.zeros((total, 3), device=dev, dtype=torch.float32)
+    split = int(total / n_slice)
+    for i in range(n_slice if split > 0 else 0):
+        lo, hi = i * split, (i + 1) * split
+        p = torch.arange(lo, hi, device=dev)
+        r = rows[torch.div(p, Wq, rounding_mode="floor")]
+        c = cols[p % Wq]
+        coords = torch.stack((torch.full_like(r, tcoord), r, c), dim=1).unsqueeze(0)
+        steps = torch.full((1, hi - lo), tstep, device=dev, dtype=torch.float32)
+        out[lo:hi] = model({"all_coords": coords, "temporal_steps": steps}, temporal_interp=temporal_interp)["model_out"].reshape(-1, 3)
+    return torch.clamp((out.reshape(Hq, Wq, 3) + 1) / 2, 0, 1)
+
+
+@torch.no_grad()
+def eval_psnr(model, video: DeviceVideo, frames=None, n_slice: int = 100, s_interp: int = -1, t_interp: int = -1, on_frame=None):
+    """The reference's evaluation driver (eval.py:201-263) on a device-resident video.
+
+    Plain run (s_interp == t_interp == -1): per-frame PSNR on [0,1] - (img+1)/2, clamp, vs u8/255 - averaged over
+    `frames` (default: all), returned as a float.  With --s_interp k the query lattice is k times finer in both image
+    axes; with --t_interp k there are k times as many output frames and the sparse grid is read through forward_inter.
+    Like the reference, interpolated runs compute no PSNR (there is no ground truth): the frames are handed to
+    `on_frame(f, img[H',W',3])` and None is returned."""
+    res = (video.H, video.W)
+    nframes = video.T
+    temporal_interp = False
+    if s_interp != -1:
+        res = (video.H * s_interp, video.W * s_interp)
+    if t_interp != -1:
+        temporal_interp = True
+        nframes = video.T * t_interp
+    plain = s_interp == -1 and t_interp == -1
     psnrs = []
-    for f in frames:
-        se = 0.0
-        for lo in range(0, hw, step):
-            hi = min(hw, lo + step)
-            mi, gt = video.frame_batch(f, lo, hi)
-            out = model(mi)["model_out"].reshape(-1, 3)
-            img = torch.clamp((out + 1) / 2, 0, 1)
-            se += float(((img - gt.float() / 255.0) ** 2).sum())
-        psnrs.append(10.0 * math.log10(1.0 / (se / (hw * 3))))
-    return sum(psnrs) / len(psnrs)
+    for f in (range(nframes) if frames is None else frames):
+        img = render_frame(model, f, video.T, res, nframes, temporal_interp, n_slice)
+        if on_frame is not None:
+            on_frame(f, img)
+        if plain:
+            gt = video.video[f].float() / 255.0
+            psnrs.append(10.0 * math.log10(1.0 / float(((img - gt) ** 2).mean())))
+    return (sum(psnrs) / len(psnrs)) if (plain and psnrs) else None
 
 
 def procedural_video(T: int, H: int, W: int, device, seed: int = 0) -> torch.Tensor:

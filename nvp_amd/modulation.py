@@ -3,10 +3,17 @@ SirenWrapper with the reference's constructor signatures, attribute names, state
 and init distributions, drawn in the same order from torch's global RNG.
 
 The arithmetic of `SirenWrapper.forward` (modulator + modulated SIREN, forward and
-backward) is ONE fused set of fp32-MFMA kernels in libnvp_hip.so (nvp_mlp_*): that is the
-only entry NVP uses (modules.py:81).  `Modulator.forward` on its own returns the three
-modulation vectors from the same kernel (inference only); the other stand-alone forwards
-(`Siren`, `SirenNet` with externally supplied mods) are not part of NVP's path and raise.
+backward) is ONE fused set of MFMA kernels in libnvp_hip.so (nvp_mlp_*): that is the only
+entry NVP uses (modules.py:81).
+
+The stand-alone pieces - `Sine.forward`, `Siren.forward`, `SirenNet.forward(x, mods)`,
+`Modulator.forward(z)` (modulation.py:24-25, 53-56, 83-92, 112-121) - are NOT on NVP's path
+(nothing in the reference calls them except through SirenWrapper).  They are provided for
+API completeness as plain device-side library ops (rocBLAS `F.linear`, element-wise ATen
+kernels) on HIP tensors, differentiable through autograd; like everything else in this
+package they refuse CPU tensors.  `tests/test_gpu_parity.py::test_standalone_modulation_*`
+checks them, and the fused kernel's own modulator outputs (`modulator_streams`), against
+the reference goldens' mod0..2.
 """
 from __future__ import annotations
 
@@ -23,13 +30,19 @@ def exists(val):
     return val is not None
 
 
+def _on_device(x: torch.Tensor, what: str) -> None:
+    if not x.is_cuda:
+        raise RuntimeError(f"{what}: nvp_amd runs on a HIP device only (got a CPU tensor); there is no CPU path")
+
+
 class Sine(nn.Module):
     def __init__(self, w0=1.):
         super().__init__()
         self.w0 = w0
 
     def forward(self, x):
-        raise NotImplementedError("Sine is fused into the nvp_mlp_* kernels; call SirenWrapper.forward")
+        _on_device(x, "Sine.forward")
+        return torch.sin(x * self.w0)
 
 
 class Siren(nn.Module):
@@ -53,7 +66,9 @@ class Siren(nn.Module):
         self.activation = Sine(w0) if activation is None else activation
 
     def forward(self, x):
-        raise NotImplementedError("Siren layers are fused into the nvp_mlp_* kernels; call SirenWrapper.forward")
+        """act(x W^T + b) - stand-alone (un-fused) evaluation of one layer, library GEMM + ATen activation."""
+        _on_device(x, "Siren.forward")
+        return self.activation(nn.functional.linear(x, self.weight, self.bias))
 
 
 class SirenNet(nn.Module):
@@ -85,8 +100,18 @@ class SirenNet(nn.Module):
         return out + [self.last_layer.weight, self.last_layer.bias]
 
     def forward(self, x, mods=None):
-        raise NotImplementedError("SirenNet with externally supplied mods is not on NVP's path; "
-                                  "call SirenWrapper.forward(coords, latent)")
+        """Stand-alone evaluation with externally supplied modulation vectors (one per hidden layer, or None):
+        each sine layer's output is multiplied by its `mod` before the next layer; Identity tail."""
+        _on_device(x, "SirenNet.forward")
+        if not isinstance(mods, tuple):
+            mods = (mods,) * self.num_layers
+        if len(mods) != self.num_layers:
+            raise RuntimeError(f"expected {self.num_layers} modulation tensors, got {len(mods)}")
+        for k, layer in enumerate(self.layers):
+            x = layer(x)
+            if exists(mods[k]):
+                x = x * mods[k]            # the reference multiplies in place (`x *= mod`); same values
+        return self.last_layer(x)
 
 
 def init_weights_normal(m):
@@ -115,8 +140,15 @@ class Modulator(nn.Module):
         return out
 
     def forward(self, z):
-        raise NotImplementedError("the Modulator is fused with the SIREN in the nvp_mlp_* kernels; "
-                                  "call SirenWrapper.forward(coords, latent)")
+        """(h0, h1, h2): h0 = lrelu(W0 z + b0), h_k = lrelu(W_k [h_{k-1}; z] + b_k) - stand-alone evaluation
+        (library GEMMs).  The fused kernels compute the same vectors inside nvp_mlp_fwd."""
+        _on_device(z, "Modulator.forward")
+        hiddens, x = [], z
+        for layer in self.layers:
+            h = layer(x)
+            hiddens.append(h)
+            x = torch.cat((h, z), dim=1)
+        return tuple(hiddens)
 
 
 class SirenWrapper(nn.Module):
@@ -139,3 +171,10 @@ class SirenWrapper(nn.Module):
         modulate = exists(self.modulator)
         assert not (modulate ^ exists(latent)), 'latent vector must be only supplied if `latent_dim` was passed in on instantiation'
         return ModulatedSiren.apply(latent, coords, torch.is_grad_enabled(), *self.mlp_tensors())
+
+    @torch.no_grad()
+    def modulator_streams(self, coords, latent):
+        """Debug / test hook: the activations the FUSED forward kernel saves for backward, as row-major [N,128]
+        tensors {'h0','h1','h2' (Modulator.forward's outputs), 'q1','q2' (pre-sine SIREN activations)}."""
+        from .functional import modulated_siren_streams
+        return modulated_siren_streams(latent, coords, self.mlp_tensors())

@@ -19,7 +19,9 @@ Pinning status
   cell-major layout eval.py:41 / compression.py:71-72, no per-level padding
   compression.py:77, fp32 modules.py:15, width L*F modules.py:42-44) is honoured;
   the interpolation follows the published tiny-cuda-nn GridEncoding (Dense grid,
-  Linear interpolation) algorithm as restated in `dense_grid_2d`.
+  Linear interpolation) algorithm as restated in `dense_grid_2d` - by default in upstream's
+  arithmetic (fmaf position, fma-chain blend, fp32 exp2f level scale); the plain two-rounding
+  restatement and a clamping border are selectable per encoding_config ("variant", "border").
 
 Every function cites the reference file:line it follows.
 """
@@ -39,24 +41,52 @@ W0_FIRST = 30.0             # reference modules.py:37 (w0_initial)
 # --------------------------------------------------------------------------------------
 # R1: level geometry of the 2D DenseGrid ("learnable keyframes")
 # --------------------------------------------------------------------------------------
+def _f32(x: float) -> float:
+    return float(torch.tensor(x, dtype=torch.float64).to(torch.float32))
+
+
+def dense_grid_variant(cfg: dict) -> Tuple[bool, bool, bool, str]:
+    """(pos_fma, interp_fma, clamp, scale_mode) of an encoding_config (same keys as the product's
+    nvp_amd._lib.grid_variant, restated here; the oracle never imports the product):
+    "variant": "tcnn" (default: published tiny-cuda-nn arithmetic) | "two_rounding"; "border": "wrap" | "clamp";
+    "scale_mode": "fp32_exp2" | "double"."""
+    variant = cfg.get("variant", "tcnn")
+    assert variant in ("tcnn", "two_rounding")
+    border = cfg.get("border", "wrap")
+    assert border in ("wrap", "clamp")
+    fma = variant == "tcnn"
+    scale_mode = cfg.get("scale_mode", "fp32_exp2" if fma else "double")
+    assert scale_mode in ("fp32_exp2", "double")
+    return fma, fma, border == "clamp", scale_mode
+
+
 def dense_grid_levels(cfg: dict) -> Tuple[List[float], List[int], List[int]]:
     """Per-level (scale, resolution, cell offset) of a tcnn DenseGrid.
 
-    Follows the reference's own restatement of the level geometry,
-    experiment_scripts/eval.py:28-35 (== compression.py:26-33):
+    Resolutions / offsets follow the reference's own restatement of the level geometry,
+    experiment_scripts/eval.py:28-35 (== compression.py:26-33), in double on the host as eval.py does:
         a = exp(l * log(per_level_scale)) * base - 1 ;  res = ceil(a) + 1 ; offset += res**2
-    The arithmetic is done in double on the host (as eval.py does); `scale` is then
-    rounded once to fp32, which is the value every kernel multiplies with.
+    `scale` (the value every kernel multiplies with): scale_mode "double" = `a` rounded once to fp32;
+    "fp32_exp2" (default) = published tiny-cuda-nn's grid_scale(), exp2f(l * log2f(pls)) * base - 1.0f with every
+    step rounded to fp32 [upstream, from memory - parity unpinned].
     """
     n_levels = int(cfg["n_levels"])
     base = float(cfg.get("base_resolution", 16))
     pls = float(cfg["per_level_scale"])
+    scale_mode = dense_grid_variant(cfg)[3]
+    log2_pls = _f32(math.log2(_f32(pls)))
     scales, ress, offs = [], [], []
     total = 0
     for lvl in range(n_levels):
         a = math.exp(lvl * math.log(pls)) * base - 1.0
         res = int(math.ceil(a) + 1)
-        scales.append(float(torch.tensor(a, dtype=torch.float64).to(torch.float32)))
+        if scale_mode == "fp32_exp2":
+            e = _f32(2.0 ** _f32(float(lvl) * log2_pls))
+            sc = _f32(_f32(e * _f32(base)) - 1.0)
+            assert int(math.ceil(sc) + 1) == res
+        else:
+            sc = _f32(a)
+        scales.append(sc)
         ress.append(res)
         offs.append(total)
         total += res * res
@@ -76,25 +106,33 @@ def dense_grid_n_params(cfg: dict) -> int:
 def dense_grid_2d(params: torch.Tensor, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     """x [N,2] in [0,1] -> [N, n_levels*F].  PARITY UNPINNED (see module docstring).
 
-    Published tiny-cuda-nn GridEncoding semantics, Dense grid / Linear interpolation:
-      pos  = x*scale_l + 0.5        (here: fp32 multiply, then fp32 add - two roundings)
+    Published tiny-cuda-nn GridEncoding semantics, Dense grid / Linear interpolation [upstream, from memory]:
+      pos  = fmaf(scale_l, x, 0.5f)             (variant "two_rounding": fp32 multiply, then fp32 add)
       i    = floor(pos); w = pos - i
-      out  = sum over the 4 corners c in {0,1}^2 of  prod_d (c_d ? w_d : 1-w_d) * P_l[cell(i+c)]
-      cell = (ix + iy*res_l) mod res_l^2        (dim 0 is the fast axis; upper border wraps)
-    corner order (0,0),(1,0),(0,1),(1,1), accumulated left to right.
+      out  = fma(w_c, P_l[cell(i+c)], out) over the 4 corners c in {0,1}^2, out starting at 0,
+             w_c = prod_d (c_d ? w_d : 1-w_d)   (variant "two_rounding": out + fl(w_c * P))
+      cell = (ix + iy*res_l) mod res_l^2        (dim 0 is the fast axis; upper border wraps; border "clamp":
+                                                 ix+1, iy+1 clamp to res_l - 1 instead)
+    corner order (0,0),(1,0),(0,1),(1,1).  The fused multiply-adds are emulated in float64: the product of two fp32
+    values is exact in float64 and the sum is rounded to fp32 once (exact fma except for double-rounding ties, ~2^-29).
     Parameter layout: level-major, cell-major inside a level, feature innermost
     (reference eval.py:41, compression.py:51-58,71-72).
     """
     Fdim = int(cfg["n_features_per_level"])
     scales, ress, offs = dense_grid_levels(cfg)
+    pos_fma, interp_fma, clamp, _ = dense_grid_variant(cfg)
     P = params.reshape(-1, Fdim)
     outs = []
     x0 = x[:, 0].to(torch.float32)
     x1 = x[:, 1].to(torch.float32)
     for scale, res, off in zip(scales, ress, offs[:-1]):
         s = torch.tensor(scale, dtype=torch.float32)
-        p0 = x0 * s + 0.5
-        p1 = x1 * s + 0.5
+        if pos_fma:
+            p0 = (x0.double() * s.double() + 0.5).float()
+            p1 = (x1.double() * s.double() + 0.5).float()
+        else:
+            p0 = x0 * s + 0.5
+            p1 = x1 * s + 0.5
         f0 = torch.floor(p0)
         f1 = torch.floor(p1)
         w0 = p0 - f0
@@ -105,9 +143,22 @@ def dense_grid_2d(params: torch.Tensor, x: torch.Tensor, cfg: dict) -> torch.Ten
         for c1 in (0, 1):
             for c0 in (0, 1):
                 wt = (w0 if c0 else (1.0 - w0)) * (w1 if c1 else (1.0 - w1))
-                cell = ((i0 + c0) + (i1 + c1) * res) % (res * res)
-                term = wt.unsqueeze(1) * P[off + cell]
-                acc = term if acc is None else acc + term
+                if clamp:
+                    cell = torch.clamp(i0 + c0, 0, res - 1) + torch.clamp(i1 + c1, 0, res - 1) * res
+                else:
+                    cell = ((i0 + c0) + (i1 + c1) * res) % (res * res)
+                v = P[off + cell]
+                if P.dtype == torch.float64:
+                    # float64 parameters: the "exact" evaluation used as the yardstick for gradient accuracy - cell
+                    # selection and corner weights stay the fp32 arithmetic above, blend and everything after it run in float64
+                    term = wt.double().unsqueeze(1) * v
+                    acc = term if acc is None else acc + term
+                elif interp_fma:
+                    prod = wt.double().unsqueeze(1) * v.double()
+                    acc = prod.float() if acc is None else (prod + acc.double()).float()
+                else:
+                    term = wt.unsqueeze(1) * v
+                    acc = term if acc is None else acc + term
         outs.append(acc)
     return torch.cat(outs, dim=1)
 
@@ -211,7 +262,7 @@ def siren_forward(s: torch.Tensor, mods, Ws: Sequence[torch.Tensor], bs: Sequenc
                   W_last: torch.Tensor, b_last: torch.Tensor, w0_first: float = W0_FIRST) -> torch.Tensor:
     """x_k = sin(w0_k * (x_{k-1} W_k^T + b_k)) * mod_k, w0 = (30, 1, 1); rgb = x W_last^T + b_last
     (modulation.py:53-56 Siren.forward, :24-25 Sine, :83-92 SirenNet.forward; Identity tail)."""
-    x = s
+    x = s.to(Ws[0].dtype)                 # (float64 parameters: the yardstick evaluation, see dense_grid_2d)
     for k, (W, b) in enumerate(zip(Ws, bs)):
         w0 = w0_first if k == 0 else 1.0
         x = torch.sin(w0 * F.linear(x, W, b))
@@ -261,6 +312,7 @@ def nvp_forward(all_coords: torch.Tensor, temporal_steps: torch.Tensor, sd: Dict
     steps = temporal_steps.reshape(b * t, -1)
     coords = all_coords.reshape(-1, 3)
     latent = nvp_latent(coords, sd, cfg, temporal_interp)
+    latent = latent.to(sd["net.last_layer.weight"].dtype)
     return mlp_forward(latent, steps, sd).reshape(b, t, 3)
 
 

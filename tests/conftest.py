@@ -40,3 +40,39 @@ def small_cfg(F=2, T=8, X=9, Y=7, n_levels=16):
                         "t_resolution": T, "upsample": False},
         "network": {"n_neurons": 128, "n_hidden_layers": 3},
     }
+
+
+def full_cfg(F=2, t_res=600, **enc_extra):
+    """The VALUES of the reference's config/config_nvp_s.json (F=2) / config_nvp_l.json (F=4): 16 levels, base 16, scale 1.35,
+    sparse grid 300 x 300 x t_res (README.md:55 sets t_resolution to the clip's frame count), 128 x 3 network."""
+    cfg = small_cfg(F=F, T=t_res, X=300, Y=300)
+    for k in ("2d_encoding_xy", "2d_encoding_xt", "2d_encoding_yt"):
+        cfg[k].update(enc_extra)
+    return cfg
+
+
+def relerr_max(a, b):
+    """max |a - b| / max |b|"""
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def relerr_l2(a, b):
+    """||a - b||_2 / ||b||_2"""
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    return float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-300))
+
+
+def report(test: str, **vals):
+    """Append measured errors to gpurun_out/parity_report.jsonl (NVP_PARITY_REPORT=1): the numbers the tolerances in the
+    GPU tests are set from (~3x the measured error)."""
+    if os.environ.get("NVP_PARITY_REPORT", "0") != "1":
+        return
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"test": test, **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in vals.items()}}) + "\n")

@@ -11,11 +11,16 @@ import pytest
 import torch
 
 import nvp_oracle as O
-from conftest import GOLDEN, small_cfg
+from conftest import GOLDEN, relerr_l2, relerr_max, report, small_cfg
 
 pytestmark = pytest.mark.gpu
 
 RGB_TOL = 1e-5          # BASELINE.json north_star: reconstructed RGB <= 1e-5 max-abs
+# Gradient bounds against an fp32 CPU evaluation (golden or oracle): max-abs error relative to the tensor's largest
+# element, and relative L2 error.  Both sides carry fp32 summation error (the oracle's own error against a float64
+# evaluation is 1e-7..7e-7, tests/test_gpu_real_configs.py); set at ~3x the largest value measured on MI355X.
+GRAD_TOL_MAX = 5e-6
+GRAD_TOL_L2 = 3e-6
 
 
 def dev():
@@ -41,23 +46,7 @@ def _mlp_keys():
     return list(O.STATE_KEYS_MLP)
 
 
-def _load_state_into(model, sd):
-    """copy oracle-keyed tensors into an nvp_amd NVP module"""
-    with torch.no_grad():
-        for k, v in sd.items():
-            obj = model
-            parts = k.split(".")
-            for p in parts[:-1]:
-                obj = obj[int(p)] if p.isdigit() else getattr(obj, p)
-            getattr(obj, parts[-1]).copy_(v)
-
-
-def _grad_of(model, key):
-    obj = model
-    parts = key.split(".")
-    for p in parts[:-1]:
-        obj = obj[int(p)] if p.isdigit() else getattr(obj, p)
-    return getattr(obj, parts[-1]).grad
+from util_parity import _away_from_kinks, _grad_of, _load_state_into      # noqa: E402
 
 
 # ----------------------------------------------------------------------------------------
@@ -115,10 +104,14 @@ def test_sparse_grid_border_multiplicity():
 # ----------------------------------------------------------------------------------------
 # tinycudann.Encoding  (R2, R3) against the oracle restatement (parity unpinned upstream)
 # ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("F", [2, 4])
-def test_dense_grid_vs_oracle(F):
+@pytest.mark.parametrize("F,variant,border", [(2, "tcnn", "wrap"), (4, "tcnn", "wrap"), (2, "two_rounding", "wrap"),
+                                              (4, "two_rounding", "wrap"), (2, "tcnn", "clamp"), (2, "two_rounding", "clamp")])
+def test_dense_grid_vs_oracle(F, variant, border):
+    """Forward bit-exact against the oracle restatement in EVERY arithmetic variant (default "tcnn": fmaf position, fma-chain
+    blend, fp32 exp2f level scale, wrapping border - published tiny-cuda-nn; "two_rounding": the plain restatement; "clamp"
+    border), incl. the coordinates where pos = scale*x + 0.5 lands on an integer and the two formulations pick different cells."""
     from nvp_amd import tinycudann as tcnn
-    cfg = small_cfg(F=F)["2d_encoding_xy"]
+    cfg = dict(small_cfg(F=F)["2d_encoding_xy"], variant=variant, border=border)
     enc = tcnn.Encoding(n_input_dims=2, encoding_config=cfg).to(dev())
     gen = torch.Generator().manual_seed(5)
     P = torch.randn(enc.params.numel(), generator=gen)
@@ -127,17 +120,43 @@ def test_dense_grid_vs_oracle(F):
     n = 4099
     x = torch.rand((n, 2), generator=gen)
     x[0] = torch.tensor([0.0, 0.0]); x[1] = torch.tensor([1.0, 1.0]); x[2] = torch.tensor([1.0, 0.0]); x[3] = torch.tensor([0.5, 0.5])
+    scales, ress, _ = O.dense_grid_levels(cfg)
+    k = 4
+    for sc, res in zip(scales, ress):                      # cell-flip coordinates of every level, +- one fp32 step
+        for m in (1, res // 2, res - 2):
+            v = np.float32((m - 0.5) / sc)
+            for c in (v, np.nextafter(v, np.float32(0)), np.nextafter(v, np.float32(2))):
+                x[k, 0] = float(c); x[k + 1, 1] = float(c); k += 2
     ref_p = P.clone().requires_grad_(True)
     ref = O.dense_grid_2d(ref_p, x, cfg)
     out = enc(x.to(dev()))
     assert out.shape == (n, 16 * F)
-    # same op order with separately rounded mul/add on both sides -> bit-exact
     assert _eq(out.detach().cpu().numpy(), ref.detach().numpy())
     w = torch.randn(ref.shape, generator=gen)
     (ref * w).sum().backward()
     (out * w.to(dev())).sum().backward()
     got, want = enc.params.grad.cpu().numpy(), ref_p.grad.numpy()
-    assert _relerr(got, want) < 1e-5      # atomic add order only
+    report("dense_grid_bwd", F=F, variant=variant, border=border, max_err=relerr_max(got, want), l2_err=relerr_l2(got, want))
+    assert relerr_max(got, want) < 3e-6 and relerr_l2(got, want) < 1e-6      # fp32 atomic-add order only (measured ~5e-7)
+
+
+def test_dense_grid_variants_differ_where_they_should():
+    """The variants are not aliases: on random grids the fp32-exp2f / double level scales (a few ulps apart) move the
+    interpolation weights; the border mode only matters where a corner coordinate reaches res (x close to 1: pos >= res - 1)."""
+    from nvp_amd import tinycudann as tcnn
+    base = small_cfg(F=2)["2d_encoding_xy"]
+    gen = torch.Generator().manual_seed(6)
+    x = torch.rand((2048, 2), generator=gen) * 0.9           # interior: i + 1 < res on every level
+    x[:64, 0] = 1.0                                          # upper border of dim 0: i + 1 == res, weight > 0
+    outs = {}
+    for variant, border in (("tcnn", "wrap"), ("two_rounding", "wrap"), ("tcnn", "clamp")):
+        enc = tcnn.Encoding(n_input_dims=2, encoding_config=dict(base, variant=variant, border=border)).to(dev())
+        with torch.no_grad():
+            enc.params.copy_(torch.randn(enc.params.numel(), generator=torch.Generator().manual_seed(1)))
+        outs[(variant, border)] = enc(x.to(dev())).detach().cpu()
+    assert not torch.equal(outs[("tcnn", "wrap")], outs[("two_rounding", "wrap")])
+    assert torch.equal(outs[("tcnn", "wrap")][64:], outs[("tcnn", "clamp")][64:])
+    assert not torch.equal(outs[("tcnn", "wrap")][:64], outs[("tcnn", "clamp")][:64])
 
 
 # ----------------------------------------------------------------------------------------
@@ -160,11 +179,53 @@ def test_mlp_golden(D):
     gt = torch.from_numpy(g["gt"]).to(dev())
     loss = ((out.reshape(1, -1, 3) - gt) ** 2).mean()
     loss.backward()
-    # gradients: fp32 MFMA split-K over pixels vs MKL: relative to each tensor's max
+    # gradients vs the reference's own fp32 autograd (MKL summation order there, split-K MFMA here); bounds ~3x the
+    # error measured on MI355X (gpurun_out/parity_report.jsonl)
     for k in _mlp_keys():
-        e = _relerr(_grad_of(holder, k).cpu().numpy(), g["g:" + k])
-        assert e < 2e-4, f"grad {k}: rel-to-max err {e}"
-    assert _relerr(latent.grad.cpu().numpy(), g["dlatent"]) < 2e-4
+        got = _grad_of(holder, k).cpu().numpy()
+        report("mlp_golden", D=D, tensor=k, max_err=relerr_max(got, g["g:" + k]), l2_err=relerr_l2(got, g["g:" + k]))
+        assert relerr_max(got, g["g:" + k]) < GRAD_TOL_MAX, f"grad {k}: rel-to-max err {relerr_max(got, g['g:' + k])}"
+        assert relerr_l2(got, g["g:" + k]) < GRAD_TOL_L2, f"grad {k}: rel-L2 err {relerr_l2(got, g['g:' + k])}"
+    report("mlp_golden", D=D, tensor="dlatent", max_err=relerr_max(latent.grad.cpu().numpy(), g["dlatent"]))
+    assert relerr_max(latent.grad.cpu().numpy(), g["dlatent"]) < GRAD_TOL_MAX
+
+
+@pytest.mark.parametrize("D", [114, 228])
+def test_standalone_modulation_and_fused_streams_golden(D):
+    """R8 checked directly: the reference goldens' mod0..2 (Modulator.forward outputs, modulation.py:112-121) against
+    (a) the h0..h2 streams the FUSED forward kernel saves, (b) the stand-alone Modulator.forward; and the stand-alone
+    SirenNet.forward(x, mods) / Siren / Sine (modulation.py:83-92, 53-56, 24-25) against the golden RGB."""
+    from nvp_amd import modulation
+    g = _load(f"mlp_d{D}.npz")
+    net = modulation.SirenNet(dim_in=1, dim_hidden=128, dim_out=3, num_layers=3, w0_initial=30.)
+    wrapper = modulation.SirenWrapper(net, latent_dim=D).to(dev())
+    holder = torch.nn.Module()
+    holder.net, holder.wrapper = wrapper.net, wrapper
+    _load_state_into(holder, {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("p:")})
+    latent = torch.from_numpy(g["latent"]).to(dev())
+    steps = torch.from_numpy(g["steps"]).to(dev())
+    streams = wrapper.modulator_streams(steps, latent)
+    mods = wrapper.modulator(latent)
+    assert isinstance(mods, tuple) and len(mods) == 3
+    for k in range(3):
+        want = g[f"mod{k}"]
+        e_fused = np.abs(streams[f"h{k}"].cpu().numpy() - want).max()
+        e_alone = np.abs(mods[k].detach().cpu().numpy() - want).max()
+        report("modulator_direct", D=D, layer=k, fused_max_abs=e_fused, standalone_max_abs=e_alone, scale=float(np.abs(want).max()))
+        assert e_fused <= 2e-6 * max(1.0, np.abs(want).max()), f"fused h{k}: {e_fused}"
+        assert e_alone <= 2e-6 * max(1.0, np.abs(want).max()), f"stand-alone mod{k}: {e_alone}"
+    out = net(steps, mods)                                  # SirenNet.forward with externally supplied mods
+    assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= RGB_TOL
+    # pre-sine streams: q1 = V1 x0 + c1 with x0 = sin(30 (w s + c)) * h0
+    x0 = net.layers[0](steps) * mods[0]
+    q1 = torch.nn.functional.linear(x0, net.layers[1].weight, net.layers[1].bias)
+    assert float((streams["q1"] - q1).abs().max()) <= 5e-6 * max(1.0, float(q1.abs().max()))
+    # the stand-alone path is differentiable (library ops + autograd): same latent gradient as the golden
+    lat = latent.clone().requires_grad_(True)
+    gt = torch.from_numpy(g["gt"]).to(dev())
+    (((net(steps, wrapper.modulator(lat))).reshape(1, -1, 3) - gt) ** 2).mean().backward()
+    assert relerr_max(lat.grad.cpu().numpy(), g["dlatent"]) < 1e-5
+    assert float((modulation.Sine(30.)(steps) - torch.sin(30. * steps)).abs().max()) == 0.0
 
 
 def test_e2e_minus_keyframes_golden_and_trajectory():
@@ -198,14 +259,17 @@ def test_e2e_minus_keyframes_golden_and_trajectory():
         loss.backward()
         if it == 0:
             assert np.abs(out.detach().cpu().numpy() - g["out"]).max() <= RGB_TOL
-            assert _relerr(grid.embeddings.grad.cpu().numpy(), g["g:sparse_grid.embeddings"]) < 2e-4
-            assert _relerr(kf.grad.cpu().numpy(), g["dkf"]) < 2e-4
-            for k in _mlp_keys():
-                assert _relerr(_grad_of(holder, k).cpu().numpy(), g["g:" + k]) < 2e-4, k
+            for name, got, want in [("sparse_grid.embeddings", grid.embeddings.grad, g["g:sparse_grid.embeddings"]), ("dkf", kf.grad, g["dkf"])] + \
+                                   [(k, _grad_of(holder, k), g["g:" + k]) for k in _mlp_keys()]:
+                got = got.cpu().numpy()
+                report("e2e_minus_kf", tensor=name, max_err=relerr_max(got, want), l2_err=relerr_l2(got, want))
+                assert relerr_max(got, want) < GRAD_TOL_MAX and relerr_l2(got, want) < GRAD_TOL_L2, name
         opt.step()
         sched.step()
         losses.append(float(loss.detach()))
-    np.testing.assert_allclose(losses, _load("traj3.npz")["losses"], rtol=2e-4)
+    want = _load("traj3.npz")["losses"]
+    report("traj3", rel=[abs(a - b) / b for a, b in zip(losses, want.tolist())])
+    np.testing.assert_allclose(losses, want, rtol=2e-5)
 
 
 # ----------------------------------------------------------------------------------------
@@ -225,20 +289,6 @@ def _nvp_pair(F, seed=0, T=8, X=9, Y=7):
     return cfg, sd, model.to(dev())
 
 
-def _away_from_kinks(coords, sd, cfg, n, margin=1e-4):
-    """Keep the first n candidate pixels whose three LeakyReLU inputs all satisfy |p| > margin.
-    At p ~ 0 the slope jumps 0.01 -> 1, so a 1-ulp difference in p (MFMA vs MKL summation
-    order) flips that unit's gradient; such pixels say nothing about kernel correctness."""
-    with torch.no_grad():
-        lat = O.nvp_latent(coords, sd, cfg)
-        pre = O.modulator_preacts(lat, [sd[f"wrapper.modulator.layers.{k}.0.weight"] for k in range(3)],
-                                  [sd[f"wrapper.modulator.layers.{k}.0.bias"] for k in range(3)])
-        ok = torch.stack([p.abs().min(dim=1).values for p in pre]).min(dim=0).values > margin
-    idx = torch.nonzero(ok).flatten()[:n]
-    assert idx.numel() == n, "not enough candidates away from the LeakyReLU kinks"
-    return idx
-
-
 @pytest.mark.parametrize("F,n", [(2, 4096), (4, 2048), (2, 1), (2, 31), (2, 33), (2, 1000)])
 def test_nvp_forward_backward_vs_oracle(F, n):
     cfg, sd, model = _nvp_pair(F)
@@ -254,6 +304,8 @@ def test_nvp_forward_backward_vs_oracle(F, n):
     sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = O.nvp_forward(coords, steps, sd_ref, cfg)
     O.image_mse(ref, gt).backward()
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}          # float64 yardstick (test_gpu_real_configs.py)
+    O.image_mse(O.nvp_forward(coords, steps, sd64, cfg), gt.double()).backward()
 
     out = model({"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())})["model_out"]
     assert out.shape == (1, n, 3)
@@ -262,11 +314,18 @@ def test_nvp_forward_backward_vs_oracle(F, n):
     ((out - gt.to(dev())) ** 2).mean().backward()
     for k in sd:
         got = _grad_of(model, k).cpu().numpy()
-        want = sd_ref[k].grad.numpy()
+        want, exact = sd_ref[k].grad.numpy(), sd64[k].grad.numpy()
         assert got.shape == want.shape
-        assert _relerr(got, want) < 3e-4, f"grad {k}: {_relerr(got, want)}"
-        # untouched grid cells must stay exactly zero (dense-grad contract)
-        assert np.array_equal(got == 0, want == 0) or _relerr(got, want) < 3e-4
+        e_hip, e_ora = relerr_max(got, exact), relerr_max(want, exact)
+        report("nvp_fwd_bwd", F=F, n=n, tensor=k, max_hip_vs_f64=e_hip, max_oracle_vs_f64=e_ora, max_hip_vs_oracle=relerr_max(got, want))
+        # as close to the exact gradient as the reference's fp32 arithmetic is (x2), floor ~3x the measured error
+        assert e_hip <= max(2.0 * e_ora, 3e-6), f"grad {k}: {e_hip:.3e} vs float64 (fp32 oracle: {e_ora:.3e})"
+        if k.endswith(".params") or k.endswith("embeddings"):
+            # dense-grad contract: a cell no pixel touches is EXACTLY zero, a touched cell is not lost
+            z_want, z_got = want == 0, got == 0
+            assert not np.any(z_want & ~z_got), f"{k}: non-zero gradient in an untouched cell"
+            lost = ~z_want & z_got
+            assert not np.any(lost) or np.abs(want[lost]).max() <= 1e-9 * np.abs(want).max(), f"{k}: a touched cell has zero gradient"
 
 
 def test_auto_sort_returns_rows_in_caller_order(monkeypatch):
@@ -289,7 +348,7 @@ def test_auto_sort_returns_rows_in_caller_order(monkeypatch):
     assert float((out.detach().cpu() - ref.detach()).abs().max()) <= RGB_TOL
     ((out - gt.to(dev())) ** 2).mean().backward()
     for k in sd:
-        assert _relerr(_grad_of(model, k).cpu().numpy(), sd_ref[k].grad.numpy()) < 3e-4, k
+        assert relerr_max(_grad_of(model, k).cpu().numpy(), sd_ref[k].grad.numpy()) < GRAD_TOL_MAX, k
     # no_grad evaluation (inference) is never re-ordered
     with torch.no_grad():
         out2 = model({"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())})["model_out"]
@@ -406,62 +465,101 @@ def test_full_batch_properties(F):
 # PSNR at equal step count: the HIP path and the oracle trained on IDENTICAL batches
 # (BASELINE.json configs[0]: 64x64x16 synthetic RGB, config_nvp_s values; north_star: +-0.02 dB)
 # ----------------------------------------------------------------------------------------
-def test_psnr_at_equal_steps_matches_oracle():
+def _ulp_perturbed(sd, seed):
+    """Every parameter moved by at most one fp32 ulp (half of the elements, random direction)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        up = torch.rand(v.shape, generator=g) < 0.25
+        dn = torch.rand(v.shape, generator=g) < 0.25
+        w = torch.where(up, torch.nextafter(v, torch.full_like(v, float("inf"))), v)
+        out[k] = torch.where(dn & ~up, torch.nextafter(v, torch.full_like(v, float("-inf"))), w)
+    return out
+
+
+def _psnr_trajectories(seed, steps_total, n_levels=16, log=None):
+    """Train (a) the oracle, (b) the oracle started <= 1 ulp away, (c) the HIP path with the product's own AdamW kernel on
+    IDENTICAL batches drawn with the reference's sampler; returns per-step train PSNRs (training.py:58) and the three
+    final parameter sets' full-frame eval PSNRs (eval.py:243-256)."""
     import math
     from nvp_amd import harness
     from nvp_amd.modules import NVP
+    from nvp_amd.optim import AdamW as _NvpAdamW
     T, H, W, n = 16, 64, 64, 8192
-    steps_total = int(os.environ.get("NVP_PSNR_STEPS", "30"))        # tools/psnr_track.sh runs a longer horizon
-    cfg = small_cfg(F=2, T=T, X=20, Y=20)
-    sd = O.init_state(cfg, seed=3)                       # reference init distributions
+    cfg = small_cfg(F=2, T=T, X=20, Y=20, n_levels=n_levels)
+    sd = O.init_state(cfg, seed=seed)                       # reference init distributions
     model = NVP(out_features=3, encoding_config=cfg)
     _load_state_into(model, sd)
     model = model.to(dev())
-    video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=1)       # u8 [T,H,W,3]
-    vid_dev = video.to(dev())
-    sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    keys = list(sd_ref)
-    opt_r = torch.optim.AdamW([sd_ref[k] for k in keys], lr=1e-2, weight_decay=0.001)
-    sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=steps_total, eta_min=1e-5)
-    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)      # the product's optimiser: nvp_adamw_step + cosine
-    from nvp_amd.optim import AdamW as _NvpAdamW
-    assert isinstance(opt_g, _NvpAdamW)
-    gen = torch.Generator().manual_seed(0)
+    video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=seed)       # u8 [T,H,W,3]
     flat = video.reshape(T, H * W, 3)
-    diffs = []
+
+    def make_ref(state):
+        ref = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+        opt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)
+        return ref, opt, torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps_total, eta_min=1e-5)
+
+    ref_a, opt_a, sch_a = make_ref(sd)
+    ref_b, opt_b, sch_b = make_ref(_ulp_perturbed(sd, seed + 1000))
+    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)      # the product's optimiser: nvp_adamw_step + cosine
+    assert isinstance(opt_g, _NvpAdamW)
+    gen = torch.Generator().manual_seed(seed)
+    pa, pb, pg = [], [], []
     for it in range(steps_total):
         ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)          # the reference's sampler order
         gt_u8 = flat[ti, pi].unsqueeze(0)
-        # oracle step (training.py:50-76 order)
-        out_r = O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), sd_ref, cfg)
-        loss_r = O.image_mse(out_r, O.normalise_gt(gt_u8))
-        opt_r.zero_grad(); loss_r.backward(); opt_r.step(); sch_r.step()
-        # HIP step on the same batch
+        for ref, opt, sch, acc in ((ref_a, opt_a, sch_a, pa), (ref_b, opt_b, sch_b, pb)):
+            out_r = O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg)        # training.py:50-76 order
+            loss_r = O.image_mse(out_r, O.normalise_gt(gt_u8))
+            opt.zero_grad(); loss_r.backward(); opt.step(); sch.step()
+            acc.append(10 * math.log10(4 / float(loss_r)))                                  # training.py:58
         mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
         out_g = model(mi)["model_out"]
         loss_g = harness.image_mse_u8(out_g, gt_u8.to(dev()))
         opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
-        psnr_r = 10 * math.log10(4 / float(loss_r)); psnr_g = 10 * math.log10(4 / float(loss_g))   # training.py:58
-        diffs.append(abs(psnr_r - psnr_g))
-        if os.environ.get("NVP_PSNR_LOG"):
-            with open(os.environ["NVP_PSNR_LOG"], "a") as f:
-                f.write(f'{{"step": {it + 1}, "psnr_oracle": {psnr_r:.4f}, "psnr_hip": {psnr_g:.4f}}}\n')
-    assert psnr_g > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
-    assert max(diffs) <= 0.02, f"train-PSNR gap {max(diffs):.4f} dB"
-    # evaluation PSNR on full frames (eval.py:243-256) with both final parameter sets
-    data = harness.DeviceVideo(vid_dev, n_samples=n, seed=0)
-    psnr_eval_g = harness.eval_psnr(model, data, frames=[0, 7, 15], n_slice=4)
-    with torch.no_grad():
-        se = 0.0
-        mg = O.get_mgrid_2d(H, W)
-        ps = []
-        for f in (0, 7, 15):
-            c = torch.cat((torch.linspace(0, 1, T)[f].expand(H * W, 1), mg), dim=1).unsqueeze(0)
-            s_ = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[f].expand(1, H * W)
-            img = torch.clamp((O.nvp_forward(c, s_, {k: v.detach() for k, v in sd_ref.items()}, cfg) + 1) / 2, 0, 1)
-            mse = float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())
-            ps.append(10 * math.log10(1 / mse))
-    assert abs(psnr_eval_g - sum(ps) / len(ps)) <= 0.02
+        pg.append(10 * math.log10(4 / float(loss_g)))
+        if log:
+            with open(log, "a") as f:
+                f.write(f'{{"seed": {seed}, "step": {it + 1}, "psnr_oracle": {pa[-1]:.4f}, "psnr_oracle_1ulp": {pb[-1]:.4f}, "psnr_hip": {pg[-1]:.4f}}}\n')
+    # evaluation PSNR on full frames (eval.py:243-256) with the final parameter sets
+    frames = (0, 7, 15)
+    data = harness.DeviceVideo(video.to(dev()), n_samples=n, seed=0)
+    ev_g = harness.eval_psnr(model, data, frames=list(frames), n_slice=4)
+
+    def eval_ref(ref):
+        with torch.no_grad():
+            mg, ps = O.get_mgrid_2d(H, W), []
+            for f in frames:
+                c = torch.cat((torch.linspace(0, 1, T)[f].expand(H * W, 1), mg), dim=1).unsqueeze(0)
+                s_ = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[f].expand(1, H * W)
+                img = torch.clamp((O.nvp_forward(c, s_, {k: v.detach() for k, v in ref.items()}, cfg) + 1) / 2, 0, 1)
+                ps.append(10 * math.log10(1 / float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())))
+            return sum(ps) / len(ps)
+
+    return pa, pb, pg, eval_ref(ref_a), eval_ref(ref_b), ev_g
+
+
+@pytest.mark.parametrize("seed,n_levels", [(3, 16), (4, 12), (5, 12)])
+def test_psnr_at_equal_steps_matches_oracle(seed, n_levels):
+    """north_star: PSNR within +-0.02 dB at equal step count.  100 steps (NVP_PSNR_STEPS), three seeds.
+
+    Two fp32 trainings of this model separate over a long horizon whatever computes them (sine layers with w0 = 30 amplify
+    rounding differences): the oracle started <= 1 ulp away from itself drifts by the same order.  So: the first 30 steps are
+    held to the strict 0.02 dB; over the whole horizon the HIP-vs-oracle gap must stay inside max(0.02 dB, 2 x the
+    oracle-vs-1-ulp-oracle envelope measured on the same batches in this very test).  Signed final differences are reported
+    (gpurun_out/parity_report.jsonl) - DESIGN.md section 5 discusses their sign."""
+    steps_total = int(os.environ.get("NVP_PSNR_STEPS", "100"))
+    pa, pb, pg, ev_a, ev_b, ev_g = _psnr_trajectories(seed, steps_total, n_levels, log=os.environ.get("NVP_PSNR_LOG"))
+    import math
+    assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
+    gap = [abs(a - g) for a, g in zip(pa, pg)]
+    env = [abs(a - b) for a, b in zip(pa, pb)]
+    report("psnr_equal_steps", seed=seed, n_levels=n_levels, steps=steps_total, gap30=max(gap[:30]), gap=max(gap), envelope=max(env),
+           final_hip_minus_oracle=pg[-1] - pa[-1], final_1ulp_minus_oracle=pb[-1] - pa[-1],
+           eval_hip_minus_oracle=ev_g - ev_a, eval_1ulp_minus_oracle=ev_b - ev_a, final_psnr=pa[-1])
+    assert max(gap[:30]) <= 0.02, f"train-PSNR gap over the first 30 steps {max(gap[:30]):.4f} dB"
+    assert max(gap) <= max(0.02, 2.0 * max(env)), f"train-PSNR gap {max(gap):.4f} dB vs 1-ulp envelope {max(env):.4f} dB"
+    assert abs(ev_g - ev_a) <= max(0.02, 2.0 * abs(ev_b - ev_a)), f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
 
 
 @pytest.mark.gpu
@@ -542,3 +640,96 @@ def test_device_sampler_matches_reference_sampler_formulas():
     mi2, g2 = harness.DeviceVideo(vd, n_samples=n, seed=5, sort_by_y=False).sample()      # same draws, raw order
     key = lambda cc, ss: torch.sort(cc[:, 0] * 1e6 + cc[:, 1] * 1e3 + cc[:, 2] + ss * 1e-3).values
     assert torch.allclose(key(c, mi["temporal_steps"][0]), key(mi2["all_coords"][0], mi2["temporal_steps"][0]))
+
+
+# ----------------------------------------------------------------------------------------
+# N3: the reference's evaluation drivers --t_interp / --s_interp (eval.py:133-134, 201-245)
+# ----------------------------------------------------------------------------------------
+def _oracle_frame(sd, cfg, f, org_nframes, res, nframes, temporal_interp, n_slice):
+    """eval.py:219-245 restated on the oracle: [H', W', 3] in [0,1] (NaN where forward_inter yields NaN)."""
+    Hq, Wq = res
+    total = Hq * Wq
+    mg = O.get_mgrid_2d(Hq, Wq)
+    half_dt = 0.5 / org_nframes
+    tstep = torch.linspace(half_dt, 1 - half_dt, nframes)[f] * torch.ones(total)
+    tcoord = torch.linspace(0, 1, nframes)[f] * torch.ones(total)
+    allc = torch.cat((tcoord.unsqueeze(1), mg), dim=1).unsqueeze(0)
+    out = torch.zeros((1, total, 3))
+    split = int(total / n_slice)
+    with torch.no_grad():
+        for i in range(n_slice):
+            out[:, i * split:(i + 1) * split] = O.nvp_forward(allc[:, i * split:(i + 1) * split], tstep[None, i * split:(i + 1) * split],
+                                                              sd, cfg, temporal_interp=temporal_interp)
+    return torch.clamp((out.reshape(Hq, Wq, 3) + 1) / 2, 0, 1)
+
+
+def test_eval_drivers_t_interp_and_s_interp_vs_oracle():
+    from nvp_amd import harness
+    T, H, W = 6, 20, 30
+    cfg, sd, model = _nvp_pair(2, seed=4, T=T, X=11, Y=9)
+    video = torch.randint(0, 256, (T, H, W, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(2))
+    data = harness.DeviceVideo(video.to(dev()), n_samples=64, seed=0)
+    n_slice = 7                                              # 600 px -> 7 slices of 85, 5 px left at 0 (-> 0.5): eval.py:233-239
+    # plain run: PSNR over all frames
+    got = harness.eval_psnr(model, data, n_slice=n_slice)
+    import math
+    ps = []
+    for f in range(T):
+        img = _oracle_frame(sd, cfg, f, T, (H, W), T, False, n_slice)
+        ps.append(10 * math.log10(1 / float(((img - video[f].float() / 255.0) ** 2).mean())))
+    assert abs(got - sum(ps) / T) < 1e-4
+    # --t_interp 2: 12 output frames through forward_inter; the LAST one is the reference's NaN frame (t == 1)
+    frames = {}
+    assert harness.eval_psnr(model, data, n_slice=n_slice, t_interp=2, on_frame=lambda f, im: frames.__setitem__(f, im.cpu())) is None
+    assert sorted(frames) == list(range(2 * T))
+    for f in (0, 1, 5, 10, 11):
+        want = _oracle_frame(sd, cfg, f, T, (H, W), 2 * T, True, n_slice)
+        a, b = frames[f], want
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), f"frame {f}: NaN pattern"
+        assert float((a - b)[~torch.isnan(b)].abs().max()) <= RGB_TOL / 2 + 1e-7
+    assert bool(torch.isnan(frames[2 * T - 1][:2]).all()) and not bool(torch.isnan(frames[2 * T - 2]).any())
+    # --s_interp 2: query lattice 40 x 60, no temporal interpolation
+    frames.clear()
+    assert harness.eval_psnr(model, data, frames=[0, 3], n_slice=n_slice, s_interp=2, on_frame=lambda f, im: frames.__setitem__(f, im.cpu())) is None
+    for f in (0, 3):
+        want = _oracle_frame(sd, cfg, f, T, (2 * H, 2 * W), T, False, n_slice)
+        assert frames[f].shape == (2 * H, 2 * W, 3)
+        assert float((frames[f] - want).abs().max()) <= RGB_TOL / 2 + 1e-7
+
+
+# ----------------------------------------------------------------------------------------
+# robustness of the fixed-point scatter and of the sorted-batch promise (ADVICE round 1)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_nonfinite_latent_gradient_poisons_grid_gradients(bad):
+    """A NaN / Inf upstream gradient must not come out as finite garbage: integer fixed point cannot carry it, so the band
+    kernels write NaN into every grid gradient of the step (the reference's index_put would carry NaN in the touched cells;
+    either way the optimiser sees the divergence)."""
+    cfg, sd, model = _nvp_pair(2)
+    gen = torch.Generator().manual_seed(1)
+    n = 3000
+    coords = torch.rand((1, n, 3), generator=gen).to(dev())
+    steps = torch.rand((1, n), generator=gen).to(dev())
+    w = torch.ones((1, n, 3))
+    w[0, 17, 1] = bad
+    (model({"all_coords": coords, "temporal_steps": steps})["model_out"] * w.to(dev())).sum().backward()
+    for p in (model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings):
+        assert not bool(torch.isfinite(p.grad).all()), "non-finite upstream gradient vanished in the scatter"
+    # and the next, finite step is clean again
+    model.zero_grad(set_to_none=True)
+    model({"all_coords": coords, "temporal_steps": steps})["model_out"].sum().backward()
+    for p in (model.keyframes_xy.params, model.sparse_grid.embeddings):
+        assert bool(torch.isfinite(p.grad).all())
+
+
+def test_sorted_hint_is_checked_on_request(monkeypatch):
+    from nvp_amd import functional
+    cfg, sd, model = _nvp_pair(2)
+    gen = torch.Generator().manual_seed(8)
+    coords = torch.rand((1, 500, 3), generator=gen).to(dev())             # NOT sorted
+    mi = {"all_coords": coords, "temporal_steps": torch.rand((1, 500), generator=gen).to(dev()), "sorted_by_y": True}
+    monkeypatch.setattr(functional, "CHECK_SORTED", True)
+    with pytest.raises(RuntimeError, match="sorted_by_y"):
+        model(mi)["model_out"].sum().backward()
+    srt = coords[0][torch.argsort(coords[0][:, 2])].unsqueeze(0)
+    model({"all_coords": srt, "temporal_steps": mi["temporal_steps"], "sorted_by_y": True})["model_out"].sum().backward()

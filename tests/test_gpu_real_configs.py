@@ -1,0 +1,167 @@
+"""GPU parity at the reference's REAL configuration sizes (-m gpu): BASELINE.json configs[1], [2], [3].
+
+Every other oracle comparison in tests/ uses a small sparse grid so that the CPU side stays cheap; here the true
+`config/config_nvp_s.json` (300 x 300 x 600 sparse grid, F = 2) and `config/config_nvp_l.json` (F = 4, t_resolution 300
+for the 300-frame clips, README.md:55) models are built, >= 65 536 pixels are drawn with the reference's sampler
+(dataio.py:104-120) on the 1920x1080x600, 1920x1080x300 and 3840x2160x300 lattices (dataio.py:11-29), plus a set of
+exact 0 / 1 / .5-boundary / lattice coordinates, and RGB (<= 1e-5) and EVERY gradient tensor are compared with the oracle
+on the CPU: index arithmetic at 1.08e8 * F elements, the exclusive fine-level path vs the slab path of the band scatter at
+real occupancy, the sparse band scatter with keys t * X + x up to 180 000.
+
+Gradient yardstick: the oracle evaluated with float64 parameters ("exact" gradient of the same function; cell selection
+and corner weights keep their fp32 arithmetic).  The HIP gradient must be as close to it as the fp32 oracle - the
+reference's own arithmetic - is (within a factor), and inside an absolute bound set at ~3x the error measured on MI355X
+(gpurun_out/parity_report.jsonl, NVP_PARITY_REPORT=1).
+"""
+import gc
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import nvp_oracle as O
+from conftest import full_cfg, relerr_l2, relerr_max, report
+from util_parity import _away_from_kinks, _grad_of, _load_state_into
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-5
+N_SAMPLER = 65536
+
+REAL = {
+    # id: (F, t_res, (T, H, W))                                    BASELINE.json
+    "configs1_nvp_s_1080p_x600": (2, 600, (600, 1080, 1920)),     # configs[1]  UVG-HD Jockey geometry
+    "configs2_nvp_l_1080p_x300": (4, 300, (300, 1080, 1920)),     # configs[2]  UVG-HD ShakeNDry geometry
+    "configs3_nvp_l_4k_x300": (4, 300, (300, 2160, 3840)),        # configs[3]  4K synthetic
+}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _boundary_coords(cfg, T, H, W, gen):
+    """Coordinates that sit exactly on the decisions the kernels take: 0, 1, .5; the sparse grid's lattice points k/(res-1)
+    and the half-way points between them (the +0.5 / truncate rule, sparsegrid.py:43-46); per dense level the x where
+    pos = scale*x + 0.5 crosses an integer (cell flip) and its two fp32 neighbours; image-lattice corners."""
+    vals = [0.0, 1.0, 0.5]
+    c3 = cfg["3d_encoding"]
+    for res in (c3["x_resolution"], c3["y_resolution"], c3["t_resolution"]):
+        ks = torch.randint(0, res, (24,), generator=gen).tolist() + [0, res - 1, res - 2]
+        vals += [k / (res - 1) for k in ks] + [(k + 0.5) / (res - 1) for k in ks if k + 1 < res]
+    scales, ress, _ = O.dense_grid_levels(cfg["2d_encoding_xy"])
+    for s, res in zip(scales, ress):
+        for m in torch.randint(1, res - 1, (6,), generator=gen).tolist() + [1, res - 2]:
+            x = np.float32((m - 0.5) / s)
+            vals += [float(x), float(np.nextafter(x, np.float32(0))), float(np.nextafter(x, np.float32(2)))]
+    vals += [(H - 1) / (H - 1), 1 / (H - 1), (W - 2) / (W - 1), 1 / (W - 1), 1 / max(T - 1, 1)]
+    v = torch.tensor(vals, dtype=torch.float32).clamp(0, 1)
+    n = v.numel()
+    # every special value meets the t, x and y slots, paired with random partners and with each other
+    t = torch.cat((v, torch.rand(n, generator=gen), torch.rand(n, generator=gen), v[torch.randperm(n, generator=gen)]))
+    x = torch.cat((torch.rand(n, generator=gen), v, torch.rand(n, generator=gen), v[torch.randperm(n, generator=gen)]))
+    y = torch.cat((torch.rand(n, generator=gen), torch.rand(n, generator=gen), v, v))
+    return torch.stack((t, x, y), dim=1)
+
+
+@pytest.mark.parametrize("name", list(REAL))
+def test_real_config_forward_backward_vs_oracle(name):
+    from nvp_amd.modules import NVP
+    F, t_res, (T, H, W) = REAL[name]
+    cfg = full_cfg(F=F, t_res=t_res)
+    gen = torch.Generator().manual_seed(len(name))
+    sd = O.init_state(cfg, seed=7)
+    # grids at O(0.3): every cell distinguishable, every path carries signal (the 1e-4 init hides index errors)
+    for k in list(sd):
+        if k.endswith(".params") or k.endswith("embeddings"):
+            sd[k] = (torch.rand(sd[k].shape, generator=gen) - 0.5) * 0.6
+    assert sd["sparse_grid.embeddings"].shape == (t_res, 300, 300, F)
+    assert sd["keyframes_xy.params"].numel() == 4616112 * F
+
+    # ---- pixels: the reference sampler on this video lattice + the boundary set; away from the LeakyReLU kinks
+    _, _, c_s, s_s = O.sample_batch(T, H, W, N_SAMPLER + 16384, gen)
+    c_b = _boundary_coords(cfg, T, H, W, gen)
+    s_b = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[torch.randint(0, T, (c_b.shape[0],), generator=gen)]
+    cand = torch.cat((c_b, c_s))
+    cand_s = torch.cat((s_b, s_s))
+    n = N_SAMPLER + c_b.shape[0] - 64
+    keep = _away_from_kinks(cand, sd, cfg, n)
+    coords, steps = cand[keep].unsqueeze(0), cand_s[keep].unsqueeze(0)
+    gt = torch.rand((1, n, 3), generator=gen) * 2 - 1
+
+    # ---- oracle, fp32 (the reference's arithmetic) and float64 (the yardstick)
+    sd32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.nvp_forward(coords, steps, sd32, cfg)
+    O.image_mse(ref, gt).backward()
+    g32 = {k: v.grad.numpy() for k, v in sd32.items()}
+    ref = ref.detach()
+    del sd32
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    out64 = O.nvp_forward(coords, steps, sd64, cfg)
+    O.image_mse(out64, gt.double()).backward()
+    g64 = {k: v.grad.numpy() for k, v in sd64.items()}
+    out64 = out64.detach()
+    del sd64
+    gc.collect()
+
+    # ---- HIP
+    model = NVP(out_features=3, encoding_config=cfg)
+    _load_state_into(model, sd)
+    model = model.to(dev())
+    out = model({"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())})["model_out"]
+    assert out.shape == (1, n, 3)
+    err = float((out.detach().cpu() - ref).abs().max())
+    err64 = float((out.detach().cpu().double() - out64).abs().max())
+    report(f"real_config[{name}]", rgb_err_vs_oracle=err, rgb_err_vs_f64=err64,
+           oracle_rgb_err_vs_f64=float((ref.double() - out64).abs().max()), n=n)
+    assert err <= RGB_TOL, f"RGB max-abs vs oracle {err}"
+    ((out - gt.to(dev())) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in sd:
+        got = _grad_of(model, k).cpu().numpy()
+        assert got.shape == g32[k].shape
+        e_hip, e_ora = relerr_l2(got, g64[k]), relerr_l2(g32[k], g64[k])
+        m_hip, m_ora = relerr_max(got, g64[k]), relerr_max(g32[k], g64[k])
+        m_vs_ora = relerr_max(got, g32[k])
+        report(f"real_config[{name}]", tensor=k, l2_hip_vs_f64=e_hip, l2_oracle_vs_f64=e_ora, max_hip_vs_f64=m_hip,
+               max_oracle_vs_f64=m_ora, max_hip_vs_oracle=m_vs_ora)
+        # as accurate as the reference's own fp32 arithmetic (x2 slack), and inside an absolute bound (~3x measured)
+        assert e_hip <= max(2.0 * e_ora, 1e-6), f"grad {k}: rel-L2 vs float64 {e_hip:.3e} (fp32 oracle {e_ora:.3e})"
+        assert m_hip <= max(2.0 * m_ora, 3e-6), f"grad {k}: max-abs/max vs float64 {m_hip:.3e} (fp32 oracle {m_ora:.3e})"
+        worst = max(worst, m_hip)
+        if k.endswith(".params") or k.endswith("embeddings"):
+            # dense-grad contract: cells no pixel touches are EXACTLY zero (every element is written once, no stale data),
+            # and no touched cell is lost (a contribution below the fixed-point resolution is < 2^-40 of the largest one)
+            z_want, z_got = g32[k] == 0, got == 0
+            assert not np.any(z_want & ~z_got), f"{k}: non-zero gradient in a cell the batch never touches"
+            lost = ~z_want & z_got
+            if np.any(lost):
+                assert np.abs(g32[k][lost]).max() <= 1e-9 * np.abs(g32[k]).max(), f"{k}: a touched cell has zero gradient"
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_real_config_sampler_lattice_4k():
+    """configs[3]: the device sampler on the 3840 x 2160 x 300 lattice (pixel index up to 8.3e6, W > 2^11) against the
+    oracle's restatement of dataio.py:93-120 - coordinates, steps and gt bytes bit-exact, y-sorted delivery."""
+    from nvp_amd import harness
+    T, H, W, n = 300, 2160, 3840, 100000
+    video = torch.randint(0, 256, (T, H, W, 3), dtype=torch.uint8, device=dev())          # 7.5 GB on the device
+    data = harness.DeviceVideo(video, n_samples=n, seed=3, sort_by_y=True)
+    mi, gt = data.sample()
+    c = mi["all_coords"][0].cpu()
+    s = mi["temporal_steps"][0].cpu()
+    assert bool((c[1:, 2] >= c[:-1, 2]).all())
+    # invert the lattice: every coordinate must be an exact lattice value, and the gt bytes those of that pixel
+    ti = torch.round(c[:, 0] * (T - 1)).long()
+    row = torch.round(c[:, 1] * (H - 1)).long()
+    col = torch.round(c[:, 2] * (W - 1)).long()
+    assert torch.equal(torch.linspace(0, 1, T)[ti], c[:, 0])
+    assert torch.equal(row.float() / (H - 1), c[:, 1]) and torch.equal(col.float() / (W - 1), c[:, 2])
+    assert torch.equal(torch.linspace(0.5 / T, 1 - 0.5 / T, T)[ti], s)
+    want = video[ti.to(dev()), row.to(dev()), col.to(dev())].cpu()
+    assert torch.equal(gt["img"][0].cpu(), want)
+    del video
+    torch.cuda.empty_cache()

@@ -59,6 +59,37 @@ def test_levels_struct_equals_oracle_geometry():
     assert L.levels_n_params(lv) == O.dense_grid_n_params(cfg) == 9232224
 
 
+def test_dense_grid_variants_host_side():
+    """encoding_config "variant"/"border"/"scale_mode" (DenseGrid arithmetic switch, R1-R3 are unpinned upstream): flags and
+    the level scale follow the oracle's restatement; resolutions never move (the reference pins them, eval.py:28-35)."""
+    base = small_cfg()["2d_encoding_xy"]
+    for variant, border, flags in (("tcnn", "wrap", 3), ("two_rounding", "wrap", 0), ("tcnn", "clamp", 7), ("two_rounding", "clamp", 4)):
+        cfg = dict(base, variant=variant, border=border)
+        lv = L.make_levels(cfg)
+        assert lv.flags == flags
+        scales, ress, offs = O.dense_grid_levels(cfg)
+        assert list(lv.res)[:16] == ress == [16, 22, 30, 40, 54, 72, 97, 131, 177, 239, 322, 435, 587, 792, 1069, 1443]
+        assert [np.float32(s) for s in lv.scale][:16] == [np.float32(s) for s in scales]
+    a = L.make_levels(dict(base, variant="tcnn"))
+    b = L.make_levels(dict(base, variant="tcnn", scale_mode="double"))
+    c = L.make_levels(dict(base, variant="two_rounding"))
+    assert list(b.scale) == list(c.scale) and list(a.scale) != list(b.scale)        # fp32 exp2f vs double exp: a few ulps apart
+    assert max(abs(x - y) / y for x, y in zip(list(a.scale)[1:16], list(b.scale)[1:16])) < 1e-6
+    with pytest.raises(ValueError):
+        L.make_levels(dict(base, variant="hash"))
+    with pytest.raises(ValueError):
+        L.make_levels(dict(base, border="mirror"))
+
+
+def test_standalone_modulation_forwards_refuse_cpu_tensors():
+    net = modulation.SirenNet(dim_in=1, dim_hidden=128, dim_out=3, num_layers=3, w0_initial=30.)
+    wrapper = modulation.SirenWrapper(net, latent_dim=114)
+    for fn, arg in ((modulation.Sine(30.), torch.zeros(4, 1)), (net.layers[0], torch.zeros(4, 1)),
+                    (net, torch.zeros(4, 1)), (wrapper.modulator, torch.zeros(4, 114))):
+        with pytest.raises(RuntimeError, match="HIP device"):
+            fn(arg)
+
+
 def test_state_dict_keys_and_shapes_match_reference():
     cfg = small_cfg(F=2)
     m = modules.NVP(out_features=3, encoding_config=cfg, type="nvp")     # 'type' kwarg is swallowed (train_video.py:46)

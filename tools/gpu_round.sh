@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${1:-r}
 { rocm-smi --showproductname 2>/dev/null | head -8; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket"; } > gpurun_out/${TAG}_box.txt 2>&1
-timeout 1500 python -m pytest tests -m gpu -q --tb=short --timeout 900 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/${TAG}_pytest.log
+timeout 2700 python -m pytest tests -m gpu -q --tb=short --timeout 1200 --durations=15 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/${TAG}_pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/${TAG}_smoke.log
 timeout 900 python bench.py --steps ${STEPS:-10} --warmup 3 > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?" | tee -a gpurun_out/${TAG}_bench.log
 grep '^{' gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json      # the JSON line alone (copy THIS into profiles/)
