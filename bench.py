@@ -42,27 +42,48 @@ CONFIG_NVP_S = {  # values of the reference's config/config_nvp_s.json
                     "t_resolution": 600, "upsample": False},
     "network": {"n_neurons": 128, "n_hidden_layers": 3},
 }
-VIDEO = (600, 1080, 1920)       # T, H, W  (UVG-HD Jockey geometry)
 N_PX = 1245184                  # reference dataio.py:91
 
-# Algorithmic work per pixel (SURVEY.md 8d / DESIGN.md): GEMM MACs x 2 only.
-F = 2
-D = 57 * F
-FLOP_PX = {
-    "nvp_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),          # 219 648
-    "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 2 * 128 * 128 + 2 * 128 * 128 + 3 * 128),              # dX of every layer but SIREN 0
-    "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),       # dW: same MACs as fwd
+# workloads: BASELINE.json configs[1] (the headline line), configs[2] and configs[3] (nvp_l = config_nvp_l.json: F = 4;
+# t_resolution = the clip's frame count, README.md:55)
+WORKLOADS = {
+    "s": {"F": 2, "video": (600, 1080, 1920), "label": "configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s"},
+    "l": {"F": 4, "video": (300, 1080, 1920), "label": "configs[2] geometry: 1920x1080x300 synthetic u8 RGB video, config_nvp_l"},
+    "4k": {"F": 4, "video": (300, 2160, 3840), "label": "configs[3]: 3840x2160x300 synthetic u8 RGB video, config_nvp_l"},
 }
-BYTES_PX = {
-    # gather: coords 12 + 192 corner F-vectors + 9 sparse F-vectors (4F bytes each) + latent write 4D
-    "nvp_encode_fwd": 12 + (192 + 9) * 4 * F + 4 * D,
-    # scatter: coords 12 + latent-grad read 4D + the same cells read-modify-written once
-    "nvp_encode_bwd": 12 + 4 * D + (192 + 9) * 4 * F,
-}
+
+
+def make_cfg(F: int, t_res: int) -> dict:
+    import copy
+    cfg = copy.deepcopy(CONFIG_NVP_S)
+    for k in cfg:
+        if "n_features_per_level" in cfg[k]:
+            cfg[k]["n_features_per_level"] = F
+    cfg["3d_encoding"]["t_resolution"] = t_res
+    return cfg
+
+
+def work_per_pixel(F: int):
+    """Algorithmic work per pixel (SURVEY.md 8d / DESIGN.md): GEMM MACs x 2 only; gather / scatter bytes."""
+    D = 57 * F
+    flop = {
+        "nvp_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),          # 219 648 (F = 2)
+        "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 2 * 128 * 128 + 2 * 128 * 128 + 3 * 128),              # dX of every layer but SIREN 0
+        "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),       # dW: same MACs as fwd
+    }
+    byts = {
+        # gather: coords 12 + 192 corner F-vectors + 9 sparse F-vectors (4F bytes each) + latent write 4D
+        "nvp_encode_fwd": 12 + (192 + 9) * 4 * F + 4 * D,
+        # scatter: coords 12 + latent-grad read 4D + the same cells read-modify-written once
+        "nvp_encode_bwd": 12 + 4 * D + (192 + 9) * 4 * F,
+    }
+    return flop, byts
+
+
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_B3 = 2516.6e12 / 6    # bf16 dense peak / six bf16 products per fp32 product = 419 TF fp32-equivalent
 # stages that run on bf16x3 split MFMA (DESIGN.md 4.1a): forward, backward chain and dW GEMMs (latents <= 256 rows)
-B3_STAGES = {"s": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw"), "l": ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")}
+B3_STAGES = ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
 PEAK_HBM = 8.0e12
 
 
@@ -76,7 +97,7 @@ def cpu_baseline(n_sample: int, reps: int = 1):
     for v in sd.values():
         v.requires_grad_(True)
     gen = torch.Generator().manual_seed(0)
-    T, H, W = VIDEO
+    T, H, W = WORKLOADS["s"]["video"]
     times = []
     for it in range(reps + 1):
         _, _, coords, steps = O.sample_batch(T, H, W, n_sample, gen)
@@ -103,8 +124,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=262144)
-    ap.add_argument("--config", choices=["s", "l"], default="s",
-                    help="s = BASELINE.json configs[1] (the headline line); l = configs[2] geometry (nvp_l, 300 frames), informational")
+    ap.add_argument("--config", choices=list(WORKLOADS), default="s",
+                    help="s = BASELINE.json configs[1] (the headline line); l = configs[2] (nvp_l, 1080p x 300); 4k = configs[3] (nvp_l, 4K x 300)")
+    ap.add_argument("--dp", choices=["auto", "sharded", "a2a", "replicated"], default=os.environ.get("NVP_DP_MODE", "auto"),
+                    help="N > 1 gradient exchange: sharded = reduce-scatter + sharded AdamW + all-gather (ZeRO-1), a2a = the same with the "
+                         "one-hop all_to_all exchange, replicated = chunked all-reduce + full AdamW; auto = time 3 untimed steps of each "
+                         "before the warm-up and keep the fastest (all ranks agree through a MAX all-reduce of the timings)")
     args = ap.parse_args()
 
     from nvp_amd import _lib, functional, harness, parallel
@@ -121,67 +146,93 @@ def main():
     _lib.load()
 
     torch.manual_seed(0)                       # identical parameters on every rank
-    cfg = CONFIG_NVP_S
-    T, H, W = VIDEO
-    if args.config == "l":                     # config_nvp_l.json differs only in n_features_per_level = 4; ShakeNDry has 300 frames
-        import copy
-        cfg = copy.deepcopy(CONFIG_NVP_S)
-        for k in cfg:
-            if "n_features_per_level" in cfg[k]:
-                cfg[k]["n_features_per_level"] = 4
-        cfg["3d_encoding"]["t_resolution"] = 300
-        T = 300
-        global F, D
-        F, D = 4, 57 * 4
-        for k in FLOP_PX:
-            FLOP_PX[k] = {"nvp_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),
-                          "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 4 * 128 * 128 + 3 * 128),
-                          "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128)}[k]
-        for k in BYTES_PX:
-            BYTES_PX[k] = 12 + (192 + 9) * 4 * F + 4 * D
+    wl = WORKLOADS[args.config]
+    F = wl["F"]
+    T, H, W = wl["video"]
+    cfg = make_cfg(F, T)
+    FLOP_PX, BYTES_PX = work_per_pixel(F)
     model = NVP(out_features=3, encoding_config=cfg).to(dev)
     parallel.broadcast_parameters(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    video = torch.randint(0, 256, (T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)   # synthetic u8 RGB, 3.7 GB
+    video = torch.randint(0, 256, (T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)   # synthetic u8 RGB (3.7 GB; 7.5 GB for 4K)
     # NVP_BENCH_UNSORTED=1: batches in the reference sampler's raw order (what a drop-in caller delivers); informational
     data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank,   # rank-offset sampler seed
                                sort_by_y=os.environ.get("NVP_BENCH_UNSORTED", "0") != "1")
     total = args.steps + args.warmup
-    opt, sched = harness.make_optimizer(model, total_steps=max(total, 1))
-    # NVP_FORCE_BUCKET=1 exercises the flat-gradient-bucket code path on a single GPU (the collective is a no-op)
-    # NVP_DP_OVERLAP=0 falls back to ONE all-reduce of the whole flat gradient after backward; by default the
-    # four grid gradients (99.9 % of the bytes) are reduced asynchronously underneath the dW GEMMs.
-    early = None
-    if os.environ.get("NVP_DP_OVERLAP", "1") != "0":
-        early = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings]
-    bucket = (parallel.GradBucket(parallel.unique_parameters(model), early=early)
-              if (world > 1 or os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1") else None)
+    multi = world > 1 or os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1"
 
-    def one_step():
+    def make_state(mode):
+        """(opt, sched, bucket) for one exchange scheme; single GPU: the plain fused AdamW, no bucket"""
+        if not multi:
+            opt, sched = harness.make_optimizer(model, total_steps=max(total, 1))
+            return opt, sched, None
+        if mode in ("sharded", "a2a"):
+            return harness.make_dp(model, max(total, 1), mode="sharded", algo="all_to_all" if mode == "a2a" else "reduce_scatter")
+        # NVP_DP_OVERLAP=0: ONE blocking all-reduce of the whole flat gradient instead of the early chunked ones
+        return harness.make_dp(model, max(total, 1), mode="replicated", early=os.environ.get("NVP_DP_OVERLAP", "1") != "0")
+
+    post_bwd = []          # (event after backward, event after the optimizer) per step: exposed exchange + optimizer time
+
+    def one_step(state, record=False):
+        opt, sched, bucket = state
         mi, gt = data.sample()
-        return harness.train_step(model, opt, sched, mi, gt, bucket=bucket)
-
-    for _ in range(args.warmup):
-        one_step()
+        if not record:
+            return harness.train_step(model, opt, sched, mi, gt, bucket=bucket)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        harness.AFTER_BACKWARD_HOOK = e0.record           # right after backward has been enqueued on the compute stream
+        try:
+            loss_ = harness.train_step(model, opt, sched, mi, gt, bucket=bucket)
+        finally:
+            harness.AFTER_BACKWARD_HOOK = None
+        e1.record()
+        post_bwd.append((e0, e1))
+        return loss_
 
     def barrier():
         if world > 1 or (dist.is_available() and dist.is_initialized()):
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(state, n_steps, record=False):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            loss_ = one_step(state, record)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt)
+        return dt_, loss_
+
+    # ---- exchange scheme (N > 1): chosen by measurement, before the warm-up, on untimed steps
+    mode, tune = args.dp, None
+    if multi and mode == "auto":
+        tune = {}
+        for cand in ("sharded", "a2a", "replicated"):
+            st = make_state(cand)
+            one_step(st)                                  # first step of a scheme allocates / connects
+            tune[cand] = round(timed(st, 3)[0] / 3 * 1e3, 3)
+            del st
+            torch.cuda.empty_cache()
+        mode = min(tune, key=tune.get)
+    state = make_state(mode)
+
+    for _ in range(args.warmup):
+        one_step(state)
+
     functional.TIMER = functional.KernelTimer()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, loss = timed(state, args.steps, record=True)
     kernels = functional.TIMER.summary()
     functional.TIMER = None
+    post_ms = sum(a.elapsed_time(b) for a, b in post_bwd) / max(len(post_bwd), 1)
+    post_all = [post_ms]
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+        tt = torch.zeros(world, device=dev, dtype=torch.float64)
+        tt[rank] = post_ms
+        dist.all_reduce(tt)
+        post_all = [round(float(v), 3) for v in tt]
 
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = world * N_PX / (ms_per_step * 1e-3) / 1e6
@@ -191,13 +242,13 @@ def main():
         # bench.py cannot collect counters itself, so it reports the committed measurement if present.
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == "s":
             traffic = json.load(open(tpath))
         dom = max(kms, key=kms.get) if kms else None
         roof = None
         if dom in FLOP_PX:
             ach = FLOP_PX[dom] * N_PX / (kms[dom] * 1e-3)
-            pk = PEAK_MFMA_B3 if dom in B3_STAGES[args.config] else PEAK_MFMA_F32
+            pk = PEAK_MFMA_B3 if dom in B3_STAGES else PEAK_MFMA_F32
             roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": round(pk / 1e12, 1),
                     "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": traffic.get(dom),
                     "ms_per_launch": kms[dom], "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
@@ -211,7 +262,7 @@ def main():
         for k, ms in kms.items():
             if k in FLOP_PX:
                 a = FLOP_PX[k] * N_PX / (ms * 1e-3)
-                b3 = k in B3_STAGES[args.config]
+                b3 = k in B3_STAGES
                 pk = PEAK_MFMA_B3 if b3 else PEAK_MFMA_F32
                 stages[k] = {"ms": ms, "bound": "mfma", "mfma": "bf16x3 split (fp32-equivalent FLOP)" if b3 else "fp32",
                              "achieved_tflops": round(a / 1e12, 2), "peak_tflops": round(pk / 1e12, 1), "frac": round(a / pk, 4)}
@@ -220,27 +271,38 @@ def main():
                 stages[k] = {"ms": ms, "bound": "hbm", "achieved_gbs": round(a / 1e9, 1), "frac": round(a / PEAK_HBM, 4),
                              "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None}
         hot_ms = sum(kms.values())
+        n_params = sum(p.numel() for p in parallel.unique_parameters(model))
+        exchange = {"replicated": "chunked all-reduce (grid grads async under the dW GEMMs) + AdamW on every rank",
+                    "sharded": "reduce-scatter (grid pieces async under the dW GEMMs) + AdamW on the own 1/N shard + all-gather of the parameters",
+                    "a2a": "one-hop all_to_all + local sum (grid pieces async under the dW GEMMs) + AdamW on the own 1/N shard + all-gather of the parameters"}
         line = {
-            "metric": "Mpixels/sec fwd+bwd (full optimisation step), UVG-HD 1080p geometry",
+            "metric": "Mpixels/sec fwd+bwd (full optimisation step), UVG-HD 1080p geometry" if args.config != "4k" else
+                      "Mpixels/sec fwd+bwd (full optimisation step), 4K geometry",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the MLP GEMMs (forward, backward chain, dW) issue each fp32 product as "
                           "six bf16 MFMA products of hi+mid+lo operand splits (error below an fp32 fma chain, DESIGN.md 4.1a); roofline peak for "
                           "those stages = bf16 dense peak / 6 in fp32-equivalent FLOP",
-            "config": {"workload": ("configs[1]: 1920x1080x600 synthetic u8 RGB video, config_nvp_s, " if args.config == "s" else
-                                    "configs[2] geometry: 1920x1080x300 synthetic u8 RGB video, config_nvp_l, ") +
-                                   f"{N_PX} (t,x,y) samples per GPU per step, random-init parameters",
+            "config": {"workload": wl["label"] + f", {N_PX} (t,x,y) samples per GPU per step, random-init parameters",
                        "pixels_per_gpu_step": N_PX, "global_batch_pixels": world * N_PX,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "step_contents": "device sampler + fwd + mse + bwd + " + ("allreduce (grid grads async under the dW GEMMs) + " if world > 1 else "") + "AdamW + cosine"},
+                       "step_contents": "device sampler + fwd + mse + bwd + " + ((exchange[mode] + " + ") if multi else "AdamW + ") + "cosine"},
             "roofline": roof,
             "kernels_ms": kms,
             "stages": stages,
             "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
             "final_loss": float(loss),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if multi:
+            # what a rank spends between the end of backward and the end of the optimizer: exposed gradient exchange + its share
+            # of AdamW (28 B per owned parameter at ~5.9 TB/s) + (sharded) the exposed part of the parameter all-gather
+            own = n_params / (world if mode in ("sharded", "a2a") else 1)
+            adam_ms = own * 28 / 5.9e12 * 1e3
+            line["dp"] = {"mode": mode, "autotune_ms_per_step": tune, "gradient_bytes": 4 * n_params,
+                          "post_backward_ms_per_rank": post_all, "adamw_share_ms_est": round(adam_ms, 3),
+                          "exposed_exchange_ms_per_rank_est": [round(max(v - adam_ms, 0.0), 3) for v in post_all]}
+        if world == 1 and not args.no_cpu_baseline and args.config == "s":
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         else:
             line["cpu_baseline"] = None

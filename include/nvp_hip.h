@@ -126,11 +126,14 @@ int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, i
 /* ---- R11 (encoding half of NVP.forward, modules.py:57-78), fused ------------------
  * coords [N,3] -> PTM4 latent zt [ntiles][rows/4][32][4], rows = nvp_latent_rows(D),
  * D = sum_p L_p*F_p + 9*F_s, row order xy | yt | xt | sparse (modules.py:69,78).
- * temporal_interp != 0 selects forward_inter for the sparse part (modules.py:72-73). */
+ * temporal_interp != 0 selects forward_inter for the sparse part (modules.py:72-73).
+ * flags: NVP_COORDS_SORTED_BY_Y if coords[:,2] is non-decreasing - the xy and yt planes (whose grid ROW is indexed by y) are
+ * then read through LDS: each 256-pixel run stages the <= 3 grid rows per level it touches with coalesced loads
+ * (nvp_amd/csrc/encode_fwd_lds.hip); results are bit-identical with and without the flag. */
 int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, const float* kf_xt,
                    const float* emb, float* zt, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, int temporal_interp, void* stream);
+                   const nvp_sparse_shape* sh, int temporal_interp, int32_t flags, void* stream);
 /* R3 + R6 fused: latent gradient -> gradients of the four grids (nvp_amd/csrc/encode_bwd.hip).
  * dz: ROW-MAJOR [>= N][dz_stride] latent gradient as written by nvp_mlp_bwd_dx (columns
  * xy | yt | xt | sparse).  d_kf_* and d_emb: every element is OVERWRITTEN (deterministic

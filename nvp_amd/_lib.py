@@ -64,7 +64,7 @@ SIGNATURES = {
     "nvp_sparse3x3_bwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
     "nvp_sparse3x3_inter_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
     "nvp_encode_fwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
-                       C.POINTER(SparseShape), C.c_int, _vp],
+                       C.POINTER(SparseShape), C.c_int, _i32, _vp],
     "nvp_encode_bwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), _vp, _i64, _i32, _vp],
     "nvp_encode_bwd_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],

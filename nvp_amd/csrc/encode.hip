@@ -13,6 +13,7 @@
 // Index arithmetic reproduces the reference's separately rounded fp32 ops
 // (sparsegrid.py:44-46): products and sums go through __fmul_rn/__fadd_rn so hipcc cannot
 // contract them into an FMA and flip a cell at a .5 boundary.
+#include <cstdlib>
 #include "grid_math.h"
 
 // __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
@@ -41,6 +42,20 @@ __device__ __forceinline__ Vec<F> load_vec(const float* p) {
         for (int f = 0; f < F; ++f) r.v[f] = p[f];
     }
     return r;
+}
+
+// 16 bytes at an 8-byte aligned address (gfx950 global loads only need dword alignment; hipcc then emits global_load_dwordx4)
+struct __attribute__((packed, aligned(8))) Quad8 { float v[4]; };
+struct __attribute__((packed, aligned(8))) Hex8 { float v[6]; };
+
+__device__ __forceinline__ void load_pair2(Vec<2>& a, Vec<2>& b, const float* __restrict__ base, int ca, int cb) {
+    if (cb == ca + 1) {
+        const Quad8 q = *reinterpret_cast<const Quad8*>(base + (int64_t)ca * 2);
+        a.v[0] = q.v[0]; a.v[1] = q.v[1]; b.v[0] = q.v[2]; b.v[1] = q.v[3];
+    } else {
+        a = load_vec<2>(base + (int64_t)ca * 2);
+        b = load_vec<2>(base + (int64_t)cb * 2);
+    }
 }
 
 // Output addressing: row-major [N, C] or PTM4 [ntiles][rows/4][32][4] (rows a multiple of 4;
@@ -82,10 +97,18 @@ __device__ __forceinline__ void dense_slot_fwd(const float* __restrict__ params,
         if (valid) {
             NvpBilerp b = nvp_bilerp_setup(x0, x1, lv.scale[l], lv.res[l], lv.flags);
             const float* base = params + (int64_t)lv.offset[l] * F;
-            Vec<F> v0 = load_vec<F>(base + (int64_t)b.cell[0] * F);
-            Vec<F> v1 = load_vec<F>(base + (int64_t)b.cell[1] * F);
-            Vec<F> v2 = load_vec<F>(base + (int64_t)b.cell[2] * F);
-            Vec<F> v3 = load_vec<F>(base + (int64_t)b.cell[3] * F);
+            Vec<F> v0, v1, v2, v3;
+            if constexpr (F == 2) {
+                // corners (0,b) and (1,b) are neighbours in memory unless the column wrapped / clamped: one 16-byte gather
+                // per grid row instead of two 8-byte ones (the TA cost of a random gather is per lane-request, not per byte)
+                load_pair2(v0, v1, base, b.cell[0], b.cell[1]);
+                load_pair2(v2, v3, base, b.cell[2], b.cell[3]);
+            } else {
+                v0 = load_vec<F>(base + (int64_t)b.cell[0] * F);
+                v1 = load_vec<F>(base + (int64_t)b.cell[1] * F);
+                v2 = load_vec<F>(base + (int64_t)b.cell[2] * F);
+                v3 = load_vec<F>(base + (int64_t)b.cell[3] * F);
+            }
 #pragma unroll
             for (int f = 0; f < F; ++f) acc[f] = nvp_blend4(b.w, v0.v[f], v1.v[f], v2.v[f], v3.v[f], lv.flags);
         }
@@ -181,6 +204,61 @@ __device__ __forceinline__ void sparse_fwd(const float* __restrict__ emb, const 
     }
 }
 
+// Fused-path variant with F known at compile time: the three cells of a patch row are contiguous in memory (y is the
+// fastest grid axis), so each row is ONE contiguous 3F-float read ([y0, y0+2] with y0 = clamp(yi-1, 0, Y-3); the clamped
+// border duplicates are picked from it by index) instead of 3F scalar loads, and the 9F (+ pad) latent rows leave as
+// 16-byte PTM4 stores.  Needs Y >= 3 and 16-byte aligned row-groups (col0 % 4 == 0); otherwise the generic code runs.
+template <int F>
+__device__ __forceinline__ void sparse_fwd_ptm(const float* __restrict__ emb, const nvp_sparse_shape& sh, bool inter,
+                                               float t, float x, float y, bool valid,
+                                               float* __restrict__ out, int64_t px, int col0, int rows, int d) {
+    constexpr int NV = 9 * F;
+    constexpr int NVP4 = (NV + 3) & ~3;
+    float v[NVP4];
+#pragma unroll
+    for (int c = 0; c < NVP4; ++c) v[c] = 0.f;
+    if (valid) {
+        const Patch p = patch_setup(t, x, y, sh, inter);
+        const int y0 = min(max(p.vy[1] - 1, 0), sh.y_res - 3);
+        const int64_t plane = (int64_t)sh.x_res * sh.y_res;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int64_t cell = (int64_t)p.vx[i] * sh.y_res + y0;
+            float lo[3 * F], hi[3 * F];
+            const float* pl = emb + ((int64_t)p.t_lo * plane + cell) * F;
+            if constexpr (F == 2) {
+                const Hex8 q = *reinterpret_cast<const Hex8*>(pl);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) lo[c] = q.v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3 * F; ++c) lo[c] = pl[c];
+            }
+            if (inter) {
+                const float* ph = emb + ((int64_t)p.t_hi * plane + cell) * F;
+#pragma unroll
+                for (int c = 0; c < 3 * F; ++c) hi[c] = ph[c];
+#pragma unroll
+                for (int c = 0; c < 3 * F; ++c) lo[c] = __fadd_rn(__fmul_rn(lo[c], p.w_lo), __fmul_rn(hi[c], p.w_hi));
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int sel = p.vy[j] - y0;                 // 0, 1 or 2
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+                    v[(i * 3 + j) * F + f] = sel == 0 ? lo[f] : (sel == 1 ? lo[F + f] : lo[2 * F + f]);
+            }
+        }
+    }
+    // rows col0 .. col0 + 9F - 1, then zero pad rows up to `rows` (d = col0 + 9F is the latent width)
+    float4* o4 = reinterpret_cast<float4*>(out);
+    const int64_t zbase = ((px >> 5) * (int64_t)(rows >> 2)) * 32 + (px & 31);
+#pragma unroll
+    for (int q = 0; q < NVP4 / 4; ++q)
+        if (col0 + 4 * q < rows) o4[zbase + (int64_t)((col0 >> 2) + q) * 32] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    (void)d;
+}
+
 template <bool PTM>
 __device__ __forceinline__ void sparse_bwd(float* __restrict__ demb, const nvp_sparse_shape& sh,
                                            float t, float x, float y,
@@ -242,6 +320,7 @@ struct EncodeArgs {
     int slots[3];              // slots per plane
     int rows;                  // PTM4 rows (D rounded up to a multiple of 4)
     int d;                     // latent dim
+    int s_first;               // first slot this launch covers (the LDS-staged kernel takes the xy / yt slots of y-sorted batches)
 };
 
 // slot decode: blockIdx.y in [0, slots0+slots1+slots2] ; last = sparse (+ pad rows)
@@ -255,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_kernel(const float* __res
     bool valid = px < n;
     float t = 0.f, x = 0.f, y = 0.f;
     if (valid) { const float* c = coords + px * 3; t = c[0]; x = c[1]; y = c[2]; }
-    int s = blockIdx.y;
+    int s = blockIdx.y + a.s_first;
     if (s < a.slots[0]) {          // xy plane <- (x, y)            reference modules.py:61
         dense_slot_fwd<F, true>(kf0, a.lv[0], s * kLevelsPerSlot, x, y, valid, zt, px, a.col0[0], a.rows);
     } else if ((s -= a.slots[0]) < a.slots[1]) {   // yt plane <- (t, y)   modules.py:63
@@ -263,8 +342,12 @@ __global__ __launch_bounds__(kThreads) void encode_fwd_kernel(const float* __res
     } else if ((s -= a.slots[1]) < a.slots[2]) {   // xt plane <- (t, x)   modules.py:62
         dense_slot_fwd<F, true>(kf2, a.lv[2], s * kLevelsPerSlot, t, x, valid, zt, px, a.col0[2], a.rows);
     } else {
-        sparse_fwd<true>(emb, a.sh, inter != 0, t, x, y, valid, zt, px, a.col0[3], a.rows);
-        for (int r = a.d; r < a.rows; ++r) zt[out_addr<true>(px, r, a.rows)] = 0.f;   // pad rows (rows = D rounded up to 4)
+        if (a.sh.n_features == F && a.sh.y_res >= 3 && (a.col0[3] & 3) == 0) {
+            sparse_fwd_ptm<F>(emb, a.sh, inter != 0, t, x, y, valid, zt, px, a.col0[3], a.rows, a.d);     // writes the pad rows too
+        } else {
+            sparse_fwd<true>(emb, a.sh, inter != 0, t, x, y, valid, zt, px, a.col0[3], a.rows);
+            for (int r = a.d; r < a.rows; ++r) zt[out_addr<true>(px, r, a.rows)] = 0.f;   // pad rows (rows = D rounded up to 4)
+        }
     }
 }
 
@@ -346,10 +429,15 @@ int make_args(EncodeArgs& a, const nvp_levels* lv_xy, const nvp_levels* lv_yt, c
     a.col0[3] = col;
     a.d = col + 9 * sh->n_features;
     a.rows = nvp_rows4(a.d);
+    a.s_first = 0;
     return 0;
 }
 
 }  // namespace
+
+// encode_fwd_lds.hip
+int nvp_encode_fwd_lds_launch(const float* coords, const float* kf_xy, const float* kf_yt, float* zt, int64_t n, int64_t npad,
+                              const nvp_levels* lv_xy, const nvp_levels* lv_yt, int col0_xy, int col0_yt, int rows, hipStream_t stream);
 
 extern "C" {
 
@@ -406,14 +494,24 @@ int nvp_sparse3x3_bwd(const float* coords, const float* dout, float* demb, int64
 
 int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, const float* kf_xt, const float* emb,
                    float* zt, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, int temporal_interp, void* stream) {
+                   const nvp_sparse_shape* sh, int temporal_interp, int32_t flags, void* stream) {
     EncodeArgs a;
     int rc = make_args(a, lv_xy, lv_yt, lv_xt, sh);
     if (rc) return rc;
     if (n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
     int64_t npad = nvp_ntiles(n) * NVP_T;
-    dim3 grid((unsigned)((npad + kThreads - 1) / kThreads), a.slots[0] + a.slots[1] + a.slots[2] + 1);
+    // y-sorted batches: the xy and yt planes (row coordinate = y) go through the LDS-staged kernel, this kernel keeps the
+    // xt plane and the sparse grid.  NVP_ENCODE_LDS=0 (environment, read once) keeps everything on the global gather.
+    static const bool lds_on = [] { const char* e = getenv("NVP_ENCODE_LDS"); return !(e && e[0] == '0'); }();
+    const int F = a.lv[0].n_features;
+    const bool lds = lds_on && (flags & NVP_COORDS_SORTED_BY_Y) && a.lv[1].n_features == F && (F == 1 || ((a.col0[0] | a.col0[1]) & 3) == 0);
+    if (lds) {
+        rc = nvp_encode_fwd_lds_launch(coords, kf_xy, kf_yt, zt, n, npad, &a.lv[0], &a.lv[1], a.col0[0], a.col0[1], a.rows, (hipStream_t)stream);
+        if (rc) return rc;
+        a.s_first = a.slots[0] + a.slots[1];
+    }
+    dim3 grid((unsigned)((npad + kThreads - 1) / kThreads), a.slots[0] + a.slots[1] + a.slots[2] + 1 - a.s_first);
     rc = dispatch_f(a.lv[0].n_features, [&](auto f) {
         hipLaunchKernelGGL((encode_fwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream,
                            coords, kf_xy, kf_yt, kf_xt, emb, zt, n, npad, a, temporal_interp);

@@ -1,0 +1,245 @@
+// Workgroup-shared weight operands for the bf16 x 3 split-MFMA chains (mlp_fwd_b3r.hip, mlp_bwd_b3r.hip).
+//
+// Why.  In mlp_fwd_b3 / mlp_bwd_b3 every wave streams the complete packed weight set (12 KiB per 16-input k-step, 732 /
+// 672 KiB per 32-pixel tile) through its own vector-memory path: 29 GB of L2->L1->VGPR traffic per launch.  A CU's vector
+// L1 returns 64 B/clk; eight waves x 12 KiB per k-step is 1536 clk of that path per k-step - exactly the time the four
+// SIMDs need for the k-step's 8 x 24 MFMAs.  The weight stream alone saturates the L1 return path, so the matrix pipe can
+// never be much more than half busy (measured: 42 % forward, 28 % backward; 3.2e7 VMEM wave-instructions per launch).
+//
+// What.  The four waves of a workgroup walk the layers in lock step and share each k-step's 12 KiB through LDS:
+//   * every wave fetches ONE QUARTER of the step (3 x 1 KiB, three 16-byte loads per lane) two steps ahead into registers,
+//   * writes it to the free slot of a two-slot ring one step ahead (ds_write_b128, lane-contiguous),
+//   * all four read their A operands from the current slot (ds_read_b128, lane-contiguous: conflict-free),
+//   * one s_barrier per k-step both publishes slot (s+1) and retires slot (s-1).
+// Vector-memory traffic for weights drops 4x (LDS returns 256 B/clk/CU, four times the L1 path), and the two workgroups
+// that share a CU (one wave each per SIMD) stay out of phase with each other, so one's VALU phases overlap the other's
+// MFMA phases as before.
+//
+// The packed stream must be laid out in CONSUMPTION order: k-step s of the kernel is the 768 u32x4 at stream + 768 s.
+#pragma once
+#include "mlp_b3.h"
+
+constexpr int kRingQuads = 12 * 64;            // u32x4 per k-step (12 KiB)
+
+struct WRing {
+    u32x4* lds;                // two slots of kRingQuads
+    const u32x4* g;            // packed stream, k-step 0
+    int total;                 // k-steps in the stream
+    int wv, lane;
+    u32x4 sg[3];               // this wave's quarter of the step that is two ahead of the one being consumed
+
+    // pieces 3 wv .. 3 wv + 2 of step s
+    __device__ __forceinline__ void fetch(int s) {
+        const u32x4* p = g + (int64_t)s * kRingQuads + (3 * wv) * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
+    }
+    __device__ __forceinline__ void publish(int s) {
+        u32x4* d = lds + (s & 1) * kRingQuads + (3 * wv) * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
+    }
+    __device__ __forceinline__ void prologue() {
+        fetch(0);
+        publish(0);
+        if (total > 1) fetch(1);
+        __syncthreads();
+    }
+    // start of k-step s: hand step s+1 to the ring, fetch step s+2; returns the slot holding step s
+    __device__ __forceinline__ const u32x4* begin(int s) {
+        if (s + 1 < total) publish(s + 1);
+        if (s + 2 < total) fetch(s + 2);
+        return lds + (s & 1) * kRingQuads;
+    }
+    // end of k-step s: everyone has read slot s, slot s+1 is complete.  NOT __syncthreads(): its workgroup-scope release
+    // fence makes hipcc wait for vmcnt(0) - i.e. for the weight fetch issued two steps ahead and for every stream store in
+    // flight - at every k-step.  Only LDS traffic has to be settled here.
+    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+
+// one k-step into four output tiles, A operands from the ring slot `w` (LDS); the reads of tile T+1 are issued ahead of
+// the MFMAs of tile T
+__device__ __forceinline__ void step_b3_ring(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+    const unsigned ul = (unsigned)lane;
+    u32x4 a[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        if (T < 3) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+        }
+        NVP_CHAIN_FENCE();
+        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
+        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
+        acc[T] = mf(ah, bl, acc[T]);
+        acc[T] = mf(am, bm, acc[T]);
+        acc[T] = mf(am, bh, acc[T]);
+        acc[T] = mf(ah, bm, acc[T]);
+        acc[T] = mf(ah, bh, acc[T]);
+    }
+}
+
+// bias step: B = e_0 (1.0 at k = 0, exact in bf16), A[.][0] = hi/mid/lo of the bias
+__device__ __forceinline__ void bias_b3_ring(f32x16 (&acc)[4], const u32x4* __restrict__ w, int lane) {
+    const unsigned ul = (unsigned)lane;
+    const u32x4 e0 = {lane < 32 ? 0x00003f80u : 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const u32x4 ah = (w + (T * 3 + 0) * 64)[ul], am = (w + (T * 3 + 1) * 64)[ul], al = (w + (T * 3 + 2) * 64)[ul];
+        acc[T] = mf(al, e0, acc[T]);
+        acc[T] = mf(am, e0, acc[T]);
+        acc[T] = mf(ah, e0, acc[T]);
+    }
+}
+
+// 8 k-steps over the previous layer's D registers; `s` is the running k-step index of the kernel.  `pre` (optional) runs
+// at the start of the LAST k-step: the caller prefetches what the following chain needs (its first latent rows) there,
+// one k-step ahead, instead of keeping those registers alive through the whole chain.
+template <typename Pre>
+__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], WRing& R, int& s, int lane, Pre pre) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const u32x4* w = R.begin(s);
+        if (c == 7) pre();
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3_ring(acc, w, bh, bm, bl, lane);
+        R.end();
+        ++s;
+    }
+}
+
+__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], WRing& R, int& s, int lane) {
+    chain_h_b3_ring(acc, hin, R, s, lane, [] {});
+}
+
+// ---- half-step ring (mlp_bwd_b3r.hip) ------------------------------------------------------------------------------
+// The backward chain keeps a 16.9 KiB transpose / parking tile per wave in LDS, which leaves 12 KiB per workgroup when two
+// workgroups share a CU: the ring's slots then hold HALF a k-step (two output tiles x three parts = 6 KiB), one barrier
+// per half-step.  Six 1-KiB pieces per half-step over four waves: the wave pair {0,1} takes two pieces each on even
+// half-steps and one each on odd ones, the pair {2,3} the other way round (three pieces per wave and k-step).
+constexpr int kHalfQuads = 6 * 64;
+
+struct HRing {
+    u32x4* lds;                // two slots of kHalfQuads
+    const u32x4* g;            // packed stream in consumption order, half-step 0
+    int chain_end;             // first half-step beyond the chain that is open
+    int wv, lane;
+    u32x4 sg[2];
+
+    // wave w moves pieces w and 4 + (w & 1): pieces 4 and 5 are moved twice (identical data to identical addresses), which
+    // keeps fetch / publish free of wave-dependent branches (a conditional second quad cost ~450 spill instructions: the
+    // branches split the chains' scheduling regions)
+    __device__ __forceinline__ void fetch(int hs) {
+        const u32x4* p = g + (int64_t)hs * kHalfQuads;
+        sg[0] = (p + wv * 64)[(unsigned)lane];
+        sg[1] = (p + (4 + (wv & 1)) * 64)[(unsigned)lane];
+    }
+    __device__ __forceinline__ void publish(int hs) {
+        u32x4* d = lds + (hs & 1) * kHalfQuads;
+        (d + wv * 64)[(unsigned)lane] = sg[0];
+        (d + (4 + (wv & 1)) * 64)[(unsigned)lane] = sg[1];
+    }
+    // Open a chain of `nh` half-steps starting at hs0: fill slot hs0, fetch hs0 + 1.  The ring is filled chain by chain (not
+    // across chains) so that the staging registers are DEAD during the element-wise stages between the chains, where the
+    // backward kernel has no register to spare (kept alive there they cost ~480 spill instructions); the price is one exposed
+    // L2 round trip per chain (seven per tile, ~2-3 % of a tile's cycles, mostly covered by the partner workgroup's wave).
+    __device__ __forceinline__ void open(int hs0, int nh) {
+        chain_end = hs0 + nh;
+        fetch(hs0);
+        publish(hs0);
+        if (nh > 1) fetch(hs0 + 1);
+        end();
+    }
+    __device__ __forceinline__ const u32x4* begin(int hs) {
+        if (hs + 1 < chain_end) publish(hs + 1);
+        if (hs + 2 < chain_end) fetch(hs + 2);
+        return lds + (hs & 1) * kHalfQuads;
+    }
+    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+
+// one k-step (two half-steps of the ring) into four output tiles.  LEAN: one tile's three operand quads live at a time
+// (the backward chain has two accumulator sets live in its shared pass and no registers to spare); otherwise the second
+// tile's quads are read ahead of the first tile's MFMAs.
+#ifndef NVP_HRING_LEAN
+#define NVP_HRING_LEAN 1
+#endif
+__device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& hs, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+    const unsigned ul = (unsigned)lane;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const u32x4* w = R.begin(hs);
+#if NVP_HRING_LEAN
+#pragma unroll
+        for (int Tl = 0; Tl < 2; ++Tl) {
+            const int T = 2 * half + Tl;
+            const u32x4 al = (w + (Tl * 3 + 2) * 64)[ul];
+            const u32x4 am = (w + (Tl * 3 + 1) * 64)[ul];
+            const u32x4 ah = (w + (Tl * 3 + 0) * 64)[ul];
+            NVP_CHAIN_FENCE();
+            acc[T] = mf(al, bh, acc[T]);              // smallest terms first
+            acc[T] = mf(ah, bl, acc[T]);
+            acc[T] = mf(am, bm, acc[T]);
+            acc[T] = mf(am, bh, acc[T]);
+            acc[T] = mf(ah, bm, acc[T]);
+            acc[T] = mf(ah, bh, acc[T]);
+            NVP_CHAIN_FENCE();
+        }
+#else
+        u32x4 a[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[1][q] = (w + (3 + q) * 64)[ul];
+#pragma unroll
+        for (int Tl = 0; Tl < 2; ++Tl) {
+            const int T = 2 * half + Tl;
+            NVP_CHAIN_FENCE();
+            const u32x4 ah = a[Tl][0], am = a[Tl][1], al = a[Tl][2];
+            acc[T] = mf(al, bh, acc[T]);              // smallest terms first
+            acc[T] = mf(ah, bl, acc[T]);
+            acc[T] = mf(am, bm, acc[T]);
+            acc[T] = mf(am, bh, acc[T]);
+            acc[T] = mf(ah, bm, acc[T]);
+            acc[T] = mf(ah, bh, acc[T]);
+        }
+#endif
+        R.end();
+        ++hs;
+    }
+}
+
+__device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 (&hin)[4], HRing& R, int& hs, int lane) {
+    R.open(hs, 16);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3_hring(acc, R, hs, bh, bm, bl, lane);
+    }
+}
+
+// two transposed GEMMs over the SAME input registers, one operand split per k-step; the packed stream interleaves the two
+// weight streams k-step by k-step (a's step c, then b's step c)
+__device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&acc_b)[4], const f32x16 (&hin)[4], HRing& R, int& hs, int lane) {
+    R.open(hs, 32);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+        u32x4 bh, bm, bl;
+        split8(x, bh, bm, bl);
+        step_b3_hring(acc_a, R, hs, bh, bm, bl, lane);
+        step_b3_hring(acc_b, R, hs, bh, bm, bl, lane);
+    }
+}

@@ -1,3 +1,4 @@
+#include <cstdlib>
 // Backward of the modulator MLP + modulated SIREN w.r.t. activations (the "dX chain" of
 // R12): from dL/drgb produce the latent gradient, the five per-pixel dY streams the
 // weight-gradient GEMMs (mlp_dw.hip) contract over the pixel axis, and - already reduced over
@@ -331,6 +332,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_kernel(const float*
 
 }  // namespace
 
+int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
+                           const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream);      // mlp_bwd_b3r.hip
 int nvp_mlp_bwd_b3_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
                           const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream);   // mlp_bwd_b3.hip
 
@@ -338,7 +341,12 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
                               const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
     if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
-    if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
+    if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
+        // NVP_MLP_RING=0 (environment, read once): per-wave weight streaming (mlp_bwd_b3.hip) instead of the workgroup-shared LDS ring
+        static const bool ring = [] { const char* e = getenv("NVP_MLP_RING"); return !(e && e[0] == '0'); }();
+        if (ring && nvp_bwd_b3_zt(d) == 4) return nvp_mlp_bwd_b3r_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
+        return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
+    }
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));

@@ -1,0 +1,278 @@
+// Backward dX chain + latent gradient + per-tile records (mlp_bwd_b3.hip, latent <= 128 rows, fused latent gradient) with
+// WORKGROUP-SHARED weight operands: the A operands of every transposed GEMM come from a two-slot LDS ring that the four
+// waves of the workgroup fill cooperatively (mlp_b3_ring.h, half-step ring: the per-wave transpose / parking tiles leave
+// 12 KiB per workgroup with two workgroups per CU) instead of 12 KiB of per-wave global loads per k-step.  Arithmetic,
+// streams, records and the latent gradient are those of mlp_bwd_b3_kernel<true>, bit for bit (same MFMA order per
+// accumulator); the packed weights are read from the consumption-ordered copy behind the tables (mlp_layout.h).
+#include "mlp_b3_ring.h"
+
+namespace {
+
+constexpr int kWaves = 4;
+
+__device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ tile_base, int T, int lane) {
+    load_ptm16(v, tile_base, T, lane);
+}
+
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
+                                                                    const float* __restrict__ saved, nvp_mlp_params p,
+                                                                    const unsigned* __restrict__ packed,
+                                                                    float* __restrict__ dy, float* __restrict__ dzr,
+                                                                    int64_t n, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t tile = (int64_t)blockIdx.x * kWaves + wv;   // provably wave-uniform
+    // Every wave of the workgroup walks the ring (barriers).  A wave beyond the last tile recomputes the last tile and
+    // rewrites that tile's outputs with the very same values (benign: identical bits), so no store needs a predicate.
+    if (tile >= ntiles) tile = ntiles - 1;
+    nvp_stagger_start();
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t px = tile * 32 + j;
+    const bool valid = px < n;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    const int64_t tb = tile * (int64_t)NVP_H * 32;
+    const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
+    float* dyt = dy + tb;                  // dp0,dp1,dp2,(records),dq1,dq2
+    const float* tab = reinterpret_cast<const float*>(packed + nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)));      // sir_w0 / sir_b0 / last_w in D-register order
+
+    // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
+    // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
+    extern __shared__ __attribute__((aligned(16))) float xl_all[];          // [4 waves][kRecTileFloats] | ring: 2 x kHalfQuads u32x4
+    float* xl = xl_all + wv * kRecTileFloats;
+    HRing R;
+    R.lds = reinterpret_cast<u32x4*>(xl_all + kWaves * kRecTileFloats);
+    R.g = reinterpret_cast<const u32x4*>(packed + nvp_bwd_b3_ring_off(4));
+    R.chain_end = 0; R.wv = wv; R.lane = lane;
+    int hs = 0;                                        // running half-step: the ring copy of the weights is in consumption order
+    float* rec = dy + 3 * act + tile * (int64_t)NVP_H * 32;      // this tile's record (stream-3 slot)
+
+    f32x16 dx[4], dh[4];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (valid) { g0 = drgb[px * 3 + 0]; g1 = drgb[px * 3 + 1]; g2 = drgb[px * 3 + 2]; }
+
+    // ---- last layer: dx2 = V3^T drgb (VALU, 3 terms)
+    {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            float v0[16], v1[16], v2[16];
+            load_tab16(v0, tab, 2, T, h);
+            load_tab16(v1, tab, 3, T, h);
+            load_tab16(v2, tab, 4, T, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[T][r] = __fmaf_rn(v2[r], g2, __fmaf_rn(v1[r], g1, v0[r] * g0));
+            nvp_pin(dx[T]);
+            NVP_LOAD_FENCE();
+        }
+#pragma unroll
+        for (int T = 0; T < 4; ++T) dh[T] = nvp_zero16();
+    }
+
+    // ---- layers 2, 1: element-wise stage (dx,dh -> dq,dp in place) then the two transposed GEMMs
+#pragma unroll
+    for (int k = 2; k >= 1; --k) {
+        const float* hk = sv + (int64_t)k * act;
+        const float* qk = sv + (int64_t)(2 + k) * act;
+        // vmcnt retires in order: a wait for loads issued AFTER a store burst also waits for those stores
+        // (an HBM write round trip).  So block T+1's loads are issued before block T's stores.
+        f32x16 hv, qv;
+        load_act16(hv, hk, 0, lane);
+        load_act16(qv, qk, 0, lane);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 hn, qn;
+            if (T < 3) {
+                load_act16(hn, hk, T + 1, lane);
+                load_act16(qn, qk, T + 1, lane);
+            }
+            NVP_LOAD_FENCE();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sn, cs;
+                nvp_sincos(qv[r], sn, cs);
+                const float dxv = dx[T][r];
+                dx[T][r] = dxv * hv[r] * cs;                      // dq
+                const float dhv = dh[T][r] + dxv * sn;
+                dh[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;       // dp
+                if (k == 2) xl[(32 * T + nvp_frag_row(r, h)) * kRecRowStride + j] = sn * hv[r];     // x2 = sin(q2) h2
+            }
+            nvp_pin(dx[T]);
+            nvp_pin(dh[T]);
+            store_ptm16(dyt + (int64_t)(3 + k) * act, dx[T], T, lane);
+            store_ptm16(dyt + (int64_t)k * act, dh[T], T, lane);
+            NVP_LOAD_FENCE();
+            if (T < 3) { hv = hn; qv = qn; }
+        }
+        if (k == 2) {
+            // d last_w[c][f] = sum_px drgb[c][px] x2[f][px],  d last_b[c] = sum_px drgb[c][px]      (modulation.py:92)
+            // lane l owns features l and l + 64; pixel px's drgb sits in lane px (readlane -> SGPR broadcast)
+            NVP_LOAD_FENCE();
+            float a[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+            const float* r0 = xl + lane * kRecRowStride;
+            const float* r1 = xl + (lane + 64) * kRecRowStride;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const float c0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0), q));
+                const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1), q));
+                const float c2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g2), q));
+                const float x0 = r0[q], x1 = r1[q];
+                a[0][0] = __fmaf_rn(c0, x0, a[0][0]); a[0][1] = __fmaf_rn(c1, x0, a[0][1]); a[0][2] = __fmaf_rn(c2, x0, a[0][2]);
+                a[1][0] = __fmaf_rn(c0, x1, a[1][0]); a[1][1] = __fmaf_rn(c1, x1, a[1][1]); a[1][2] = __fmaf_rn(c2, x1, a[1][2]);
+                b0 += c0; b1 += c1; b2 += c2;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                rec[kRecLastW + c * NVP_H + lane] = a[0][c];
+                rec[kRecLastW + c * NVP_H + 64 + lane] = a[1][c];
+            }
+            if (lane < 3) rec[kRecLastB + lane] = lane == 0 ? b0 : (lane == 1 ? b1 : b2);
+            NVP_LOAD_FENCE();
+        }
+        // dx_{k-1} = V_k^T dq_k
+        f32x16 acc[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+        chain_h_b3_hring(acc, dx, R, hs, lane);        // streams 0 (sir2^T), 1 (sir1^T)
+#pragma unroll
+        for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+        if (true) {
+            // dz += W_k[:, 128:]^T dp_k and dh_{k-1} = W_k[:, :128]^T dp_k in ONE pass over dp (one operand split per
+            // k-step instead of two).  Both accumulators are live, so dx' waits in the wave's LDS tile meanwhile: the
+            // parked dz accumulator is swapped out for it before the pass and back in after it.
+            float4* park = reinterpret_cast<float4*>(xl);
+            f32x16 dzacc[4];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                if (k == 2) {
+                    dzacc[T] = nvp_zero16();
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 t = park[(T * 4 + g) * 64 + lane];
+                        dzacc[T][4 * g] = t.x; dzacc[T][4 * g + 1] = t.y; dzacc[T][4 * g + 2] = t.z; dzacc[T][4 * g + 3] = t.w;
+                    }
+                }
+                NVP_LOAD_FENCE();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)                        // dx' (tile T) takes the slot its dz quarter just left
+                    park[(T * 4 + g) * 64 + lane] = make_float4(dx[T][4 * g], dx[T][4 * g + 1], dx[T][4 * g + 2], dx[T][4 * g + 3]);
+                NVP_LOAD_FENCE();
+            }
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            chain_h2_b3_hring(dzacc, acc, dh, R, hs, lane);          // streams 6/2 (z2^T, mod2h^T), 5/3 (z1^T, mod1h^T), interleaved per k-step
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {                          // swap back: dx' into registers, dz accumulator into LDS
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = park[(T * 4 + g) * 64 + lane];
+                    dx[T][4 * g] = t.x; dx[T][4 * g + 1] = t.y; dx[T][4 * g + 2] = t.z; dx[T][4 * g + 3] = t.w;
+                }
+                NVP_LOAD_FENCE();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    park[(T * 4 + g) * 64 + lane] = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
+                nvp_pin(dx[T]);
+                NVP_LOAD_FENCE();
+            }
+            continue;
+        }
+    }
+
+    // ---- layer 0: q0 = 30 (w s + c) is recomputed
+    {
+        const float s = valid ? steps[px] : 0.f;
+        const float* w0 = p.sir_w[0];
+        const float* c0 = p.sir_b[0];
+        const float* h0 = sv;
+        f32x16 hv;
+        load_act16(hv, h0, 0, lane);
+        // The parked dz accumulator is fetched back quarter by quarter, just ahead of the dq0 rows that overwrite
+        // its LDS region (quarter T of the accumulator sits in floats [1024 T, 1024 T + 1024), rows 32 T .. 32 T + 31 of
+        // the dq0 tile in [1056 T, 1056 T + 1056)): that keeps the register peak of this stage below 256.
+        f32x16 dzacc[4];
+        auto fetch_dz = [&](int T) {
+            const float4* park = reinterpret_cast<const float4*>(xl);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = park[(T * 4 + g) * 64 + lane];
+                dzacc[T][4 * g] = t.x; dzacc[T][4 * g + 1] = t.y; dzacc[T][4 * g + 2] = t.z; dzacc[T][4 * g + 3] = t.w;
+            }
+            nvp_pin(dzacc[T]);
+        };
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            f32x16 hn;
+            if (T < 3) load_act16(hn, h0, T + 1, lane);
+            if (true) {
+                if (T == 0) fetch_dz(0);
+                if (T < 3) fetch_dz(T + 1);
+            }
+            float w0v[16], c0v[16];
+            load_tab16(w0v, tab, 0, T, h);
+            load_tab16(c0v, tab, 1, T, h);
+            NVP_LOAD_FENCE();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = 30.0f * __fmaf_rn(s, w0v[r], c0v[r]);
+                float sn, cs;
+                nvp_sincos(q, sn, cs);
+                const float dxv = dx[T][r];
+                dx[T][r] = 30.0f * (dxv * hv[r] * cs);        // dq0: gradient w.r.t. (w s + c)
+                const float dhv = dh[T][r] + dxv * sn;
+                dh[T][r] = hv[r] > 0.f ? dhv : dhv * 0.01f;   // dp0
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xl[(32 * T + nvp_frag_row(r, h)) * kRecRowStride + j] = dx[T][r];
+            nvp_pin(dh[T]);
+            store_ptm16(dyt, dh[T], T, lane);
+            NVP_LOAD_FENCE();
+            if (T < 3) hv = hn;
+        }
+        // d sir_w0[f] = sum_px dq0[f][px] s[px],  d sir_b0[f] = sum_px dq0[f][px]        (modulation.py:53-56)
+        float wl = 0.f, wh = 0.f, cl = 0.f, ch = 0.f;
+        const float* r0 = xl + lane * kRecRowStride;
+        const float* r1 = xl + (lane + 64) * kRecRowStride;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float sp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s), q));
+            const float d0 = r0[q], d1 = r1[q];
+            wl = __fmaf_rn(d0, sp, wl); wh = __fmaf_rn(d1, sp, wh);
+            cl += d0; ch += d1;
+        }
+        rec[kRecSir0W + lane] = wl; rec[kRecSir0W + 64 + lane] = wh;
+        rec[kRecSir0B + lane] = cl; rec[kRecSir0B + 64 + lane] = ch;
+        if (true) {
+            // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
+            NVP_LOAD_FENCE();
+            chain_h_b3_hring(dzacc, dh, R, hs, lane);     // stream 4 (z0^T)
+            const int stride = nvp_dz_stride_dev(d);
+            float* o = dzr + (tile * 32 + j) * stride;
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int base = 32 * T + 8 * g + 4 * h;
+                    if (base < stride)
+                        *reinterpret_cast<float4*>(o + base) = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
+                }
+        }
+    }
+}
+
+
+}  // namespace
+
+// called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on, the latent has <= 128 rows and NVP_MLP_RING != 0
+int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
+                           const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
+    const int64_t ntiles = nvp_ntiles(n);
+    dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    const size_t lds = kWaves * kRecTileFloats * sizeof(float) + 2 * kHalfQuads * sizeof(u32x4);        // 67 584 + 12 288 B: two workgroups per CU
+    const unsigned* pk = reinterpret_cast<const unsigned*>(packed_bwd);
+    hipLaunchKernelGGL(mlp_bwd_b3r_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, n, ntiles, d);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,3 +1,4 @@
+#include <cstdlib>
 // Fused forward of the modulator MLP + modulated SIREN (R8-R10) on fp32 MFMA.
 //
 // One wavefront owns one tile of 32 pixels for the whole 7-layer network.  Every GEMM is
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_kernel(const float* __
 
 }  // namespace
 
+int nvp_mlp_fwd_b3r_launch(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
+                           float* rgb, float* saved, int64_t n, int32_t d, void* stream);
 int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
                           float* rgb, float* saved, int64_t n, int32_t d, void* stream);        // mlp_fwd_b3.hip
 
@@ -151,7 +154,12 @@ extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_pa
                            float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
     if (!zt || !steps || !p || !packed_fwd || !rgb || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
-    if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) return nvp_mlp_fwd_b3_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
+    if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
+        // NVP_MLP_RING=0 (environment, read once): per-wave weight streaming (mlp_fwd_b3.hip) instead of the workgroup-shared LDS ring
+        static const bool ring = [] { const char* e = getenv("NVP_MLP_RING"); return !(e && e[0] == '0'); }();
+        if (ring) return nvp_mlp_fwd_b3r_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
+        return nvp_mlp_fwd_b3_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
+    }
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     const int lrows = nvp_rows4(d) < kZLdsRows ? nvp_rows4(d) : kZLdsRows;

@@ -117,12 +117,16 @@ __host__ __device__ inline bool nvp_fwd_b3_ok(int d) { return ((d + 3) & ~3) <= 
 __host__ __device__ inline bool nvp_bwd_b3_ok(int d) { return ((d + 3) & ~3) <= 256; }     // backward chain; <= 128 rows: latent gradient fused (mlp_bwd_b3.hip)
 __host__ __device__ inline int nvp_bwd_b3_zt(int d) { return ((d + 3) & ~3) <= 128 ? 4 : 8; }   // output tiles of the latent-gradient streams
 
+// Streams are stored in the order the forward kernel CONSUMES them - mod0, mod1, sir1, mod2, sir2 - so that the kernel's
+// running k-step index addresses the packed buffer linearly (mlp_b3_ring.h); off[] is still indexed by layer id
+// (0 mod0, 1 mod1, 2 mod2, 3 sir1, 4 sir2), off[5] = total.
 __host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3(int d) {
     NvpFwdLayoutB3 L;
     L.zs = (((d + 3) & ~3) + 15) / 16;
     L.steps[0] = 1 + L.zs; L.steps[1] = 1 + 8 + L.zs; L.steps[2] = 1 + 8 + L.zs; L.steps[3] = 1 + 8; L.steps[4] = 1 + 8;
+    const int order[5] = {0, 1, 3, 2, 4};
     int64_t o = 0;
-    for (int i = 0; i < 5; ++i) { L.off[i] = o; o += (int64_t)L.steps[i] * kB3StepU32; }
+    for (int i = 0; i < 5; ++i) { L.off[order[i]] = o; o += (int64_t)L.steps[order[i]] * kB3StepU32; }
     L.off[5] = o;
     return L;
 }
@@ -140,4 +144,23 @@ __host__ __device__ inline int nvp_b3_chain_in(int c, int h, int q) { return 32 
 __host__ __device__ inline int64_t nvp_bwd_b3_off(int stream, int zt) {
     const int64_t h = 8 * (int64_t)kB3StepU32;
     return stream <= 4 ? stream * h : 4 * h + (stream - 4) * h * (zt / 4);
+}
+
+
+// ---- consumption-ordered copy of the backward b3 streams for the workgroup-shared ring (mlp_bwd_b3r.hip, zt == 4) ------
+// The ring kernel walks ONE linear sequence of k-steps: sir2^T (8), then z2^T / mod2h^T interleaved per k-step (16),
+// sir1^T (8), z1^T / mod1h^T interleaved (16), z0^T (8) = 56 k-steps of kB3StepU32.  The copy sits behind the tables.
+constexpr int kBwdRingSteps = 56;
+__host__ __device__ inline int64_t nvp_bwd_b3_ring_off(int zt) { return nvp_bwd_b3_off(7, zt) + kB3TabFloats; }
+// position (k-step index in the ring copy) of k-step c of stream `stream`
+__host__ __device__ inline int nvp_bwd_b3_ring_pos(int stream, int c) {
+    switch (stream) {
+        case 0: return c;
+        case 6: return 8 + 2 * c;
+        case 2: return 9 + 2 * c;
+        case 1: return 24 + c;
+        case 5: return 32 + 2 * c;
+        case 3: return 33 + 2 * c;
+        default: return 48 + c;      // stream 4
+    }
 }

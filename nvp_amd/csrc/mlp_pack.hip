@@ -60,8 +60,9 @@ __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsi
     const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L.off[5]) return;
-    int seg = 0;
-    while (idx >= L.off[seg + 1]) ++seg;
+    int seg = 0;                                   // layer whose stream holds idx (streams are stored in consumption order, not by id)
+    for (int k = 0; k < 5; ++k)
+        if (idx >= L.off[k] && idx < L.off[k] + (int64_t)L.steps[k] * kB3StepU32) seg = k;
     const int64_t loc = idx - L.off[seg];
     const int pr = (int)(loc & 3);                 // which pair of the lane's eight k
     const int lane = (int)((loc >> 2) & 63);
@@ -146,6 +147,8 @@ __global__ __launch_bounds__(256) void pack_bwd_b3_kernel(nvp_mlp_params p, unsi
         packed |= (bits & 0xffffu) << (16 * e);
     }
     out[idx] = packed;
+    if (zt == 4)        // the consumption-ordered copy the workgroup-shared ring kernel reads (mlp_layout.h)
+        out[nvp_bwd_b3_ring_off(zt) + (int64_t)nvp_bwd_b3_ring_pos(seg, step) * kB3StepU32 + (loc - (int64_t)step * kB3StepU32)] = packed;
 }
 
 __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* __restrict__ out, int d) {
@@ -181,7 +184,11 @@ __global__ __launch_bounds__(256) void pack_bwd_kernel(nvp_mlp_params p, float* 
 extern "C" {
 
 int64_t nvp_packed_fwd_floats(int32_t d) { return (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) ? nvp_fwd_layout_b3(d).off[5] + kB3TabFloats : nvp_fwd_layout(d).off[5]; }
-int64_t nvp_packed_bwd_floats(int32_t d) { return (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) ? nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)) + kB3TabFloats : nvp_bwd_layout(d).off[7]; }
+int64_t nvp_packed_bwd_floats(int32_t d) {
+    if (!(NVP_BWD_B3 && nvp_bwd_b3_ok(d))) return nvp_bwd_layout(d).off[7];
+    const int zt = nvp_bwd_b3_zt(d);
+    return nvp_bwd_b3_off(7, zt) + kB3TabFloats + (zt == 4 ? (int64_t)kBwdRingSteps * kB3StepU32 : 0);      // + the ring-ordered copy
+}
 int64_t nvp_mlp_param_floats(int32_t d) { return nvp_param_layout(d).total; }
 int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
     return nvp_param_layout(d).total * (int64_t)n_chunks;       // one full gradient record per pixel chunk

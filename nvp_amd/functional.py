@@ -310,7 +310,7 @@ class NVPFused(torch.autograd.Function):
         if n:
             L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
-                                       1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_fwd")
+                                       1 if temporal_interp else 0, L.COORDS_SORTED_BY_Y if y_sorted else 0, L.stream_ptr()), "nvp_encode_fwd")
         rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
         if need_grad:
             if temporal_interp:

@@ -15,6 +15,10 @@ from . import _lib as L
 
 N_SAMPLES = 1245184          # reference dataio.py:91
 
+# Optional callable fired inside train_step right after loss.backward() has returned (everything of backward is enqueued,
+# nothing of the gradient exchange / optimizer yet): bench.py records a HIP event there to time the exposed exchange.
+AFTER_BACKWARD_HOOK = None
+
 
 class ImageMSEU8(torch.autograd.Function):
     """mean((out - (gt_u8-127.5)/127.5)^2) with d/dout produced in the same pass (R13)."""
@@ -115,16 +119,23 @@ def make_optimizer(model: torch.nn.Module, total_steps: int, lr: float = 1e-2):
 
 def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     """One iteration in the reference's order (training.py:50-76). Returns the (device) loss.
-    `bucket` (parallel.GradBucket) turns on data parallelism: backward writes the gradients into one flat
-    buffer, which is all-reduced once (grid range early and asynchronously) before the optimizer."""
+    `bucket` (parallel.GradBucket) turns on data parallelism: backward writes the gradients into one flat buffer whose
+    grid range is exchanged early and asynchronously; the optimizer decides how:
+      * parallel.ShardedAdamW - reduce-scatter, AdamW on the own shard, all-gather of the parameters (ZeRO-1);
+      * optim.AdamW           - all-reduce in pieces, every rank updates everything (1/world inside the kernel);
+      * anything else         - one blocking all-reduce + mean, then opt.step()."""
     from . import functional
     from .optim import AdamW
+    from .parallel import ShardedAdamW
+    sharded = isinstance(opt, ShardedAdamW)
+    if sharded:
+        bucket = opt.bucket
     out = model(model_input)["model_out"]
     loss = image_mse_u8(out, gt["img"])
     if bucket is not None:
         bucket.detach_grads()                       # == zero_grad(set_to_none=True)
         functional.GRAD_SINK = bucket.sink()        # backward writes straight into the flat buffer
-        functional.GRIDS_READY_HOOK = bucket.start_early   # grid grads all-reduce underneath the dW GEMMs
+        functional.GRIDS_READY_HOOK = opt.start_early if sharded else bucket.start_early   # grid grads exchanged underneath the dW GEMMs
     else:
         opt.zero_grad()
     try:
@@ -132,7 +143,11 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     finally:
         functional.GRAD_SINK = None
         functional.GRIDS_READY_HOOK = None
-    if bucket is not None and isinstance(opt, AdamW):
+    if AFTER_BACKWARD_HOOK is not None:
+        AFTER_BACKWARD_HOOK()
+    if sharded:
+        opt.step()
+    elif bucket is not None and isinstance(opt, AdamW):
         # SUM all-reduce in pieces (the grid pieces are already in flight); AdamW updates each piece as its collective
         # completes, 1/world applied inside the kernel
         opt.step(grad_scale=1.0 / bucket.world_size(), schedule=bucket.step_schedule())
@@ -142,6 +157,27 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
         opt.step()
     sched.step()
     return loss.detach()
+
+
+def make_dp(model: torch.nn.Module, total_steps: int, mode: str = "sharded", algo: str = "reduce_scatter", lr: float = 1e-2,
+            early: bool = True):
+    """Data-parallel optimizer set-up: (opt, sched, bucket).  mode "sharded" = ZeRO-1 (parallel.ShardedAdamW), "replicated" =
+    all-reduce + full AdamW on every rank (optim.AdamW with the chunked schedule).  Hyper-parameters: training.py:13-14."""
+    from . import parallel
+    from .optim import AdamW
+    params = parallel.unique_parameters(model)
+    grids = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings] if early else None
+    if mode == "sharded":
+        world = parallel.GradBucket.world_size()
+        bucket = parallel.GradBucket(params, early=grids, pad_to=parallel.ShardedAdamW.alignment(world))
+        opt = parallel.ShardedAdamW(bucket, lr=lr, weight_decay=0.001, algo=algo)
+    elif mode == "replicated":
+        bucket = parallel.GradBucket(params, early=grids)
+        opt = AdamW(params, lr=lr, weight_decay=0.001)
+    else:
+        raise ValueError("mode must be 'sharded' or 'replicated'")
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=total_steps, eta_min=1e-5)
+    return opt, sched, bucket
 
 
 def train_psnr(loss: torch.Tensor) -> float:

@@ -1,18 +1,29 @@
-"""Pixel-batch data parallelism: one process per GPU, every rank draws its
-own i.i.d. pixel batch, parameters are replicated, and after backward ONE all-reduce
-(RCCL over xGMI; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests) sums a single
-flat fp32 gradient buffer, which is then scaled by 1/world.  Weak scaling: the per-GPU
-batch stays N = 1 245 184, the global batch is world * N.
+"""Pixel-batch data parallelism: one process per GPU, every rank draws its own i.i.d. pixel batch,
+parameters are replicated, and after backward the flat fp32 gradient (543 MB for nvp_s) is summed across ranks over
+RCCL / xGMI (backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).  Weak scaling: the per-GPU batch stays
+N = 1 245 184, the global batch is world * N.
 
-The flat buffer is persistent: `GradBucket` points every parameter's `.grad` at a view of
-one contiguous tensor, so the collective really is a single call on 543 MB (nvp_s) and no
-per-step flatten/unflatten copy exists.  autograd accumulates in place into those views
-(`zero_grad(set_to_none=False)` semantics are provided by `GradBucket.zero_()`).
+Two exchange schemes share the flat buffers of `GradBucket`:
+
+* replicated (`GradBucket.step_schedule` + `optim.AdamW(schedule=...)`): all-reduce, every rank runs the whole AdamW.
+  The grid range (99.9 % of the bytes) is reduced early, asynchronously and in pieces underneath the dW GEMMs, and AdamW
+  updates piece i while piece i+1 is on the wire.
+* sharded (`ShardedAdamW`, ZeRO-1): the same pieces are REDUCE-SCATTERED (each rank receives the sum of 1/world of every
+  piece), each rank runs AdamW on its shard only (optimizer traffic and state / world), and the updated parameters are
+  ALL-GATHERED in place into a flat parameter buffer the module's parameters are views of.  Same bytes on the wire as an
+  all-reduce (which is a reduce-scatter + all-gather), but the all-gather of piece i overlaps the update of piece i+1 and
+  the 3.8 GB optimizer pass shrinks to 3.8 / world GB.  xGMI is point-to-point (7 links per GPU): besides RCCL's own
+  reduce-scatter the one-hop direct form is available (`algo="all_to_all"`): every rank sends shard j of its piece
+  straight to rank j over their private link and sums the world received shards locally.
+
+The flat buffers are persistent: `GradBucket` points every parameter's `.grad` at a view of one contiguous tensor, so
+a collective is a single call on a slice of it and no per-step flatten/unflatten copy exists.
 """
 from __future__ import annotations
 
+import math
 import os
-from typing import Iterable, List, Optional
+from typing import Callable, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -20,7 +31,7 @@ import torch.distributed as dist
 
 def _force() -> bool:
     """NVP_DP_FORCE_COLLECTIVES=1: run the collective code paths even with ONE rank (a single-GPU box can then exercise
-    the real RCCL calls - init, barrier, chunked asynchronous all-reduces on slices of the flat buffer, waits)."""
+    the real RCCL calls - init, barrier, chunked asynchronous collectives on slices of the flat buffer, waits)."""
     return os.environ.get("NVP_DP_FORCE_COLLECTIVES", "0") == "1"
 
 
@@ -55,16 +66,19 @@ class GradBucket:
     """All gradients of a module as views into one flat fp32 buffer + the per-step all-reduce."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], early: Optional[Iterable[torch.nn.Parameter]] = None,
-                 chunk_elems: int = 32 * 1024 * 1024):
+                 chunk_elems: int = 32 * 1024 * 1024, pad_to: int = 1):
         """`early`: parameters whose gradients are complete before the rest of backward has run (NVP's four
-        grids: 99.9 % of the bytes).  If they occupy one contiguous range of the flat buffer, their all-reduce
-        can be started early and asynchronously (`start_early`) and overlaps the remaining backward kernels."""
+        grids: 99.9 % of the bytes).  If they occupy one contiguous range of the flat buffer, their exchange
+        can be started early and asynchronously (`start_early`) and overlaps the remaining backward kernels.
+        `pad_to`: the flat buffer's length is rounded up to a multiple of this (zeros; ShardedAdamW needs equal shards)."""
         self.params = list(params)
         if not self.params:
             raise ValueError("no parameters")
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self.padded = (self.numel + pad_to - 1) // pad_to * pad_to
+        self._flat_all = torch.zeros(self.padded, device=dev, dtype=torch.float32)
+        self.flat = self._flat_all[:self.numel]
         self.views = []
         off = 0
         for p in self.params:
@@ -76,6 +90,7 @@ class GradBucket:
         self.attach()
         self._early_range = None
         self._early_work = None          # list of (lo, hi, work) once start_early() has run
+        self._sink_armed = False         # sink() handed the views to backward for the step in progress
         self.chunk_elems = int(chunk_elems)          # the early range is reduced in pieces of <= this many elements (128 MB)
         self._offsets = []
         o = 0
@@ -105,8 +120,10 @@ class GradBucket:
     def start_early(self) -> None:
         """Asynchronous all-reduces of the early range, piece by piece (call once its gradients are enqueued on the
         current stream; torch.distributed orders the collectives after that work).  Pieces let the optimizer update
-        the parameters of piece i while piece i+1 is still on the wire (`step_schedule`).  No-op without a group."""
-        if self._early_range is None or self._early_work is not None:
+        the parameters of piece i while piece i+1 is still on the wire (`step_schedule`).  Only runs when backward is
+        writing into the bucket (`sink()` armed for this step): otherwise the memory it would reduce is stale.
+        No-op without a group."""
+        if self._early_range is None or self._early_work is not None or not self._sink_armed:
             return
         if _multi():
             self._early_work = [(a, b, dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, async_op=True))
@@ -127,15 +144,41 @@ class GradBucket:
                 out.append((p, a - o, b - o))
         return out
 
+    def _repair(self) -> Optional[tuple]:
+        """Some `.grad` is not the bucket view any more (autograd cloned instead of adopting the tensor backward returned,
+        or something replaced it).  Make the bucket authoritative again WITHOUT double counting:
+
+        * the range an early collective already ran on was written by backward through the sink (start_early refuses to run
+          otherwise), so after joining, the bucket memory of that range IS the cross-rank sum; a clone autograd may have
+          taken meanwhile can hold half-reduced data (it was copied on the compute stream while the collective rewrote the
+          memory) and is simply dropped - it must neither be copied back nor reduced again;
+        * everything else is copied from `.grad` into the bucket and still has to be reduced.
+        Returns the flat range that is already reduced (or None)."""
+        done = None
+        if self._early_work is not None:
+            self._join_early()
+            done = self._early_range
+        for p, v, o in zip(self.params, self.views, self._offsets):
+            inside = done is not None and done[0] <= o and o + p.numel() <= done[1]
+            if inside:
+                continue                               # bucket memory is the reduced gradient
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+        self.attach()
+        return done
+
     def step_schedule(self) -> Optional[list]:
         """For an optimizer that can update sub-ranges (nvp_amd.optim.AdamW.step(schedule=...)): reduce what is not
         in flight yet, and return [(wait, [(param, a, b), ...]), ...] in completion order - wait() makes the
         current stream wait for that piece's collective.  Gradients stay SUMS (the caller passes 1/world as
         grad_scale).  Returns None for a single process (nothing to wait for)."""
+        self._sink_armed = False
         if not _multi():
             return None
         if not self.consistent():
-            self.all_reduce(scale=False)            # repair path: everything reduced synchronously
+            self.all_reduce(scale=False)            # repair path: everything reduced (exactly once) synchronously
             return None
         sched = []
         if self._early_work is None:
@@ -164,6 +207,7 @@ class GradBucket:
     def sink(self) -> dict:
         """{param.data_ptr(): bucket view} for nvp_amd.functional.GRAD_SINK: backward then writes each
         gradient directly into the flat buffer (every element exactly once - no zero-fill needed)."""
+        self._sink_armed = True
         return {p.data_ptr(): v for p, v in zip(self.params, self.views)}
 
     def detach_grads(self) -> None:
@@ -185,30 +229,31 @@ class GradBucket:
     def all_reduce(self, scale: bool = True) -> None:
         """SUM all-reduce of the flat gradient.  scale=False leaves the sum (the caller folds 1/world into
         the optimizer kernel: nvp_amd.optim.AdamW.step(grad_scale=...))."""
+        self._sink_armed = False
+        done = None
         if not self.consistent():
-            # a grad tensor was replaced (e.g. zero_grad(set_to_none=True)): copy back into the bucket.
-            # An early all-reduce that already ran on stale bucket memory is joined and discarded: the
-            # copy below restores the local gradients and the full all-reduce redoes the sum.
-            self._join_early()
-            for p, v in zip(self.params, self.views):
-                if p.grad is None:
-                    v.zero_()
-                elif p.grad.data_ptr() != v.data_ptr():
-                    v.copy_(p.grad)
-            self.attach()
+            done = self._repair()
         if _multi():
             if self._early_work is not None:
                 # the big range is already in flight (overlapping the dW GEMMs): reduce the rest, then join
-                lo, hi = self._early_range
-                if lo > 0:
-                    dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM)
-                if hi < self.numel:
-                    dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM)
+                done = self._early_range
+                self._reduce_outside(done)
                 self._join_early()
+            elif done is not None:
+                self._reduce_outside(done)            # repaired: the early range is already summed, reduce only the rest
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)       # one collective over the whole gradient
             if scale:
                 self.flat.mul_(1.0 / dist.get_world_size())
+        else:
+            self._join_early()
+
+    def _reduce_outside(self, rng: tuple) -> None:
+        lo, hi = rng
+        if lo > 0:
+            dist.all_reduce(self.flat[:lo], op=dist.ReduceOp.SUM)
+        if hi < self.numel:
+            dist.all_reduce(self.flat[hi:], op=dist.ReduceOp.SUM)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
@@ -216,3 +261,142 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
     if _multi():
         for p in unique_parameters(module):
             dist.broadcast(p.data, src=src)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ZeRO-1: reduce-scatter -> AdamW on the own shard -> all-gather of the parameters
+# ------------------------------------------------------------------------------------------------------------
+def _hip_adamw_update(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale) -> None:
+    """AdamW on four flat fp32 device slices of equal length in one launch of nvp_adamw_step (no CPU path)."""
+    from . import _lib
+    lib = _lib.load()
+    seg = _lib.AdamwSeg(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), p.numel())
+    arr = (_lib.AdamwSeg * 1)(seg)
+    _lib.check(lib.nvp_adamw_step(arr, 1, float(lr), float(b1), float(b2), float(eps), float(wd), int(step), float(grad_scale),
+                                  _lib.stream_ptr()), "nvp_adamw_step")
+
+
+class ShardedAdamW(torch.optim.Optimizer):
+    """The reference's AdamW (training.py:13) with the state and the update sharded over the data-parallel ranks.
+
+    * `bucket` must have been built with pad_to=ShardedAdamW.alignment(world): every piece then splits into `world`
+      equal, 256-B aligned shards.
+    * The module's parameters are re-homed: `p.data` becomes a view of one flat parameter buffer (values preserved), so
+      that the updated shards can be all-gathered in place.
+    * `param_groups[0]['lr']` is what CosineAnnealingLR drives, exactly as with torch.optim.AdamW; `state` is sharded
+      (`exp_avg`, `exp_avg_sq` of this rank's 1/world of the flat parameter vector) and `step` is one global counter.
+    * step(): for every piece in completion order: wait for its reduce-scatter, update the own shard (gradient SUM times
+      1/world inside the kernel), start the asynchronous all-gather of that piece's parameters; all gathers are joined on
+      the current stream before step() returns (stream-ordered waits, no host sync).
+    `update` is the flat-slice AdamW kernel launcher (default: nvp_adamw_step on the HIP device).  The world-2 gloo test
+    passes a CPU restatement of torch.optim.AdamW's rule instead - tests own their checker, the product has no CPU path."""
+
+    @staticmethod
+    def alignment(world: int) -> int:
+        return 64 * max(world, 1)
+
+    def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 algo: str = "reduce_scatter", update: Optional[Callable] = None):
+        if algo not in ("reduce_scatter", "all_to_all"):
+            raise ValueError("algo must be 'reduce_scatter' or 'all_to_all'")
+        super().__init__(bucket.params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.bucket = bucket
+        self.algo = algo
+        self.update = update or _hip_adamw_update
+        self.world = dist.get_world_size() if _multi() else 1
+        self.rank = dist.get_rank() if _multi() else 0
+        unit = self.alignment(self.world)
+        if bucket.padded % unit:
+            raise ValueError(f"GradBucket must be padded to a multiple of {unit} elements (pad_to=ShardedAdamW.alignment(world))")
+        dev = bucket.flat.device
+        # ---- flat parameter buffer; the parameters become views of it
+        self.pflat = torch.zeros(bucket.padded, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(bucket.params, bucket._offsets):
+                self.pflat[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.pflat[o:o + p.numel()].view_as(p)
+        # ---- pieces: the early range in chunks whose boundaries are multiples of `unit`, then one remainder piece
+        self.pieces = []
+        e_hi = 0
+        if bucket._early_range is not None and bucket._early_range[0] == 0:
+            e_hi = bucket._early_range[1] // unit * unit
+            step = max(unit, bucket.chunk_elems // unit * unit)
+            self.pieces = [(a, min(a + step, e_hi)) for a in range(0, e_hi, step)]
+        self.n_early = len(self.pieces)
+        if e_hi < bucket.padded:
+            self.pieces.append((e_hi, bucket.padded))
+        # ---- this rank's shard of every piece, and where it lives in the (sharded) moment buffers
+        self.shards, off = [], 0
+        for a, b in self.pieces:
+            s = (b - a) // self.world
+            self.shards.append((a + self.rank * s, a + (self.rank + 1) * s, off))
+            off += s
+        self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.steps_done = 0
+        self._scratch = torch.empty(bucket.padded, device=dev, dtype=torch.float32) if (algo == "all_to_all" and self.world > 1) else None
+        self._early_work = None
+
+    # -- exchange of one piece: after wait(), flat[own shard] holds the cross-rank SUM of that shard
+    def _reduce_piece(self, i: int):
+        a, b = self.pieces[i]
+        lo, hi, _ = self.shards[i]
+        g = self.bucket._flat_all
+        if self.world == 1 and not _force():
+            return lambda: None
+        if self.algo == "reduce_scatter":
+            w = dist.reduce_scatter_tensor(g[lo:hi], g[a:b], op=dist.ReduceOp.SUM, async_op=True)    # in place: output = input + rank * count
+            return w.wait
+        recv = self._scratch[a:b]
+        w = dist.all_to_all_single(recv, g[a:b], async_op=True)       # shard j of my piece -> rank j, one hop over our private link
+
+        def fin():
+            w.wait()
+            torch.sum(recv.view(self.world, hi - lo), dim=0, out=g[lo:hi])          # ranks summed in rank order: deterministic
+        return fin
+
+    def start_early(self) -> None:
+        """Start the exchange of the early (grid) pieces; call once their gradients are enqueued (GRIDS_READY_HOOK)."""
+        if self._early_work is None and self.bucket._sink_armed:
+            self._early_work = [self._reduce_piece(i) for i in range(self.n_early)]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError("ShardedAdamW.step does not take a closure")
+        b = self.bucket
+        b._sink_armed = False
+        if not b.consistent():
+            # a gradient did not land in the bucket.  Pieces already exchanged were written through the sink and are valid
+            # (see GradBucket._repair); the rest is copied back before it is exchanged.
+            started = self.n_early if self._early_work is not None else 0
+            done_hi = self.pieces[started - 1][1] if started else 0
+            for p, v, o in zip(b.params, b.views, b._offsets):
+                if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                    continue
+                keep = min(max(done_hi - o, 0), p.numel())       # leading elements inside an exchanged piece: bucket memory stands
+                if keep == p.numel():
+                    continue
+                if p.grad is None:
+                    v.reshape(-1)[keep:].zero_()
+                else:
+                    v.reshape(-1)[keep:].copy_(p.grad.reshape(-1)[keep:])
+            b.attach()
+        waits = list(self._early_work or [])
+        self._early_work = None
+        waits += [self._reduce_piece(i) for i in range(len(waits), len(self.pieces))]
+        group = self.param_groups[0]
+        b1, b2 = group["betas"]
+        self.steps_done += 1
+        gathers = []
+        for i, wait in enumerate(waits):
+            wait()
+            lo, hi, off = self.shards[i]
+            self.update(self.pflat[lo:hi], b._flat_all[lo:hi], self.exp_avg[off:off + hi - lo], self.exp_avg_sq[off:off + hi - lo],
+                        group["lr"], b1, b2, group["eps"], group["weight_decay"], self.steps_done, 1.0 / self.world)
+            if self.world > 1 or _force():
+                a, e = self.pieces[i]
+                gathers.append(dist.all_gather_into_tensor(self.pflat[a:e], self.pflat[lo:hi], async_op=True))   # in place
+        for w in gathers:
+            w.wait()
+        return None

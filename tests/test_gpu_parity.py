@@ -378,6 +378,39 @@ def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
         assert torch.equal(a, b) and torch.equal(b, c)
 
 
+@pytest.mark.parametrize("F,n,border", [(2, 200000, "wrap"), (4, 70000, "wrap"), (2, 3000, "wrap"), (2, 257, "clamp"), (2, 50000, "clamp")])
+def test_lds_staged_gather_is_bit_identical_to_the_global_gather(F, n, border):
+    """NVP_COORDS_SORTED_BY_Y routes the xy / yt planes through the LDS-staged kernel (encode_fwd_lds.hip): RGB must equal the
+    un-hinted evaluation bit for bit - dense batches (every level staged), sparse ones (fine levels fall back to global
+    loads because a 256-pixel run spans many grid rows), runs ending at y == 1 (the wrap-around rows fall back), both borders."""
+    from nvp_amd.modules import NVP
+    cfg = small_cfg(F=F)
+    for k in ("2d_encoding_xy", "2d_encoding_xt", "2d_encoding_yt"):
+        cfg[k]["border"] = border
+    torch.manual_seed(F + n)
+    model = NVP(out_features=3, encoding_config=cfg).to(dev())
+    with torch.no_grad():
+        for p in (model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings):
+            p.normal_(0, 0.3)
+    gen = torch.Generator().manual_seed(n)
+    W = 1920
+    col = torch.randint(0, W, (n,), generator=gen)
+    coords = torch.stack((torch.rand(n, generator=gen), torch.rand(n, generator=gen), col.float() / (W - 1)), dim=1)
+    coords[:7, 2] = 1.0                                       # y == 1: pos lands in the last row, the i+1 corner wraps / clamps
+    coords[7:9, 1] = 1.0                                      # x == 1 on the xy plane: column res wraps into the next row
+    coords = coords[torch.argsort(coords[:, 2], stable=True)].unsqueeze(0).to(dev())
+    steps = torch.rand((1, n), generator=gen).to(dev())
+    with torch.no_grad():
+        a = model({"all_coords": coords, "temporal_steps": steps})["model_out"]
+        b = model({"all_coords": coords, "temporal_steps": steps, "sorted_by_y": True})["model_out"]
+    assert torch.equal(a, b)
+    # and against the oracle on a subset (the hinted path)
+    idx = torch.randint(0, n, (2048,), generator=gen)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith("wrapper.net")}
+    ref = O.nvp_forward(coords[:, idx.to(dev())].cpu(), steps[:, idx.to(dev())].cpu(), sd, cfg)
+    assert float((b[:, idx.to(dev())].cpu() - ref).abs().max()) <= RGB_TOL
+
+
 def test_nvp_empty_batch():
     cfg, sd, model = _nvp_pair(2)
     out = model({"all_coords": torch.zeros((1, 0, 3), device=dev()), "temporal_steps": torch.zeros((1, 0), device=dev())})

@@ -70,13 +70,17 @@ def _worker(rank, world, port, q):
     assert b2._early_range == (0, sum(p.numel() for p in early))        # the grids are the first, contiguous params
     for k, p in enumerate(params):
         p.grad.fill_(float((rank + 1) * (k + 1)))
+    b2.start_early()                         # backward is not writing into the bucket (no sink()): must refuse to run on stale memory
+    assert b2._early_work is None
+    b2.sink()                                # what train_step does before backward: the bucket views ARE the gradient storage
     b2.start_early()                         # grids in flight ...
+    assert b2._early_work is not None and len(b2._early_work) >= 1
     b2.start_early()                         # (idempotent)
     b2.all_reduce_mean()                     # ... MLP range reduced, early work joined, everything scaled
     for k, p in enumerate(params):
         want_k = sum((r + 1) * (k + 1) for r in range(world)) / world
         assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), k
-    # early range reduced on stale memory (grads replaced afterwards) must still give the right answer
+    # without the sink an "early" call is a no-op and replaced grads are copied back and reduced exactly once
     for p in params:
         p.grad.zero_()
     b2.start_early()
@@ -86,12 +90,43 @@ def _worker(rank, world, port, q):
     for k, p in enumerate(params):
         want_k = sum((r + 1) * (k + 2) for r in range(world)) / world
         assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), k
+    # ADVICE r1 (parallel.py repair path): backward wrote through the sink, the early collective is already rewriting the
+    # bucket, and autograd CLONED instead of adopting the views - the clones of the early range may hold half-reduced
+    # garbage.  The early range must come from the bucket memory (reduced exactly once), the rest from the copies.
+    for k, v in enumerate(b2.views):
+        v.fill_(float((rank + 1) * (k + 5)))          # what the kernels wrote
+    b2.sink()
+    b2.start_early()
+    early_ids = {id(p) for p in early}
+    for k, p in enumerate(params):
+        if id(p) in early_ids:
+            p.grad = torch.full_like(p, 1e30)         # a clone taken while the collective was in flight: garbage
+        else:
+            p.grad = torch.full_like(p, float((rank + 1) * (k + 5)))     # a valid clone of a range no collective has touched
+    assert not b2.consistent()
+    b2.all_reduce_mean()
+    assert b2.consistent()
+    for k, p in enumerate(params):
+        want_k = sum((r + 1) * (k + 5) for r in range(world)) / world
+        assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), (k, float(p.grad.flatten()[0]), want_k)
+    # the same scenario through step_schedule (the optimizer path): falls back to the repair, nothing reduced twice
+    for k, v in enumerate(b2.views):
+        v.fill_(float((rank + 1) * (k + 6)))
+    b2.sink()
+    b2.start_early()
+    for k, p in enumerate(params):
+        p.grad = torch.full_like(p, 1e30 if id(p) in early_ids else float((rank + 1) * (k + 6)))
+    assert b2.step_schedule() is None
+    for k, p in enumerate(params):
+        want_k = float(sum((r + 1) * (k + 6) for r in range(world)))       # step_schedule leaves SUMS
+        assert torch.allclose(p.grad, torch.full_like(p.grad, want_k)), k
     # chunked early reduce + step schedule: pieces cross parameter boundaries, every element is scheduled exactly once,
     # and after all waits the buffer holds the SUM (the optimizer applies 1/world)
     b3 = parallel.GradBucket(params, early=early, chunk_elems=1000)
     assert len(b3.early_chunks()) > 4 and b3.early_chunks()[0][0] == 0 and b3.early_chunks()[-1][1] == b3._early_range[1]
     for k, p in enumerate(params):
         p.grad.fill_(float((rank + 1) * (k + 3)))
+    b3.sink()
     b3.start_early()
     sched = b3.step_schedule()
     seen = {id(p): torch.zeros(p.numel(), dtype=torch.int32) for p in params}
@@ -142,3 +177,126 @@ def test_single_process_bucket_is_a_noop_collective():
     lin.weight.grad.fill_(2.0)
     b.all_reduce_mean()                 # no process group: must not touch the values
     assert float(b.flat.sum()) == 2.0 * 6
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ZeRO-1 (parallel.ShardedAdamW): reduce-scatter -> AdamW on the own shard -> all-gather of the parameters
+# ------------------------------------------------------------------------------------------------------------
+def _cpu_adamw_update(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale):
+    """torch.optim.AdamW's update rule (training.py:13) on flat slices - the CHECKER for the sharded plumbing (the product's
+    update is the HIP kernel nvp_adamw_step; element-wise, so slicing cannot change a single bit)."""
+    import math
+    gs = g * grad_scale
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(gs, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gs, gs, value=1 - b2)
+    denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - b1 ** step))
+
+
+def _sharded_worker(rank, world, port, q, algo):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    from nvp_amd import parallel
+    from nvp_amd.modules import NVP
+    parallel.init_distributed(backend="gloo")
+    cfg = small_cfg(F=2, T=4, X=5, Y=5, n_levels=4)
+
+    def build():
+        torch.manual_seed(7)
+        return NVP(out_features=3, encoding_config=cfg)
+
+    def fake_grads(views, it):                       # what backward would write through the sink: rank- and step-dependent
+        g = torch.Generator().manual_seed(1000 * it + rank)
+        for v in views:
+            v.copy_(torch.randn(v.shape, generator=g) * 10.0 ** float(torch.randint(-6, 1, (1,), generator=g)))
+
+    # ---- replicated reference: all-reduce (SUM), every rank applies the whole update with grad_scale = 1/world
+    m_rep = build()
+    p_rep = parallel.unique_parameters(m_rep)
+    grids = [m_rep.keyframes_xy.params, m_rep.keyframes_yt.params, m_rep.keyframes_xt.params, m_rep.sparse_grid.embeddings]
+    b_rep = parallel.GradBucket(p_rep, early=grids, chunk_elems=3000)
+    flat_p = torch.cat([p.detach().reshape(-1) for p in p_rep]).clone()
+    m1, v1 = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+    # ---- sharded
+    m_sh = build()
+    p_sh = parallel.unique_parameters(m_sh)
+    grids_sh = [m_sh.keyframes_xy.params, m_sh.keyframes_yt.params, m_sh.keyframes_xt.params, m_sh.sparse_grid.embeddings]
+    b_sh = parallel.GradBucket(p_sh, early=grids_sh, chunk_elems=3000, pad_to=parallel.ShardedAdamW.alignment(world))
+    opt = parallel.ShardedAdamW(b_sh, lr=1e-2, weight_decay=1e-3, algo=algo, update=_cpu_adamw_update)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=4, eta_min=1e-5)
+    assert len(opt.pieces) >= 3 and opt.n_early >= 2 and opt.pieces[-1][1] == b_sh.padded
+    assert all((b - a) % (64 * world) == 0 for a, b in opt.pieces)
+    assert opt.exp_avg.numel() * world == b_sh.padded                      # optimizer state is 1/world of the flat vector
+    assert all(p.data_ptr() == opt.pflat[o:o + 1].data_ptr() for p, o in zip(p_sh, b_sh._offsets))    # parameters re-homed, values kept
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in p_sh]), flat_p)
+    lr_now = 1e-2
+    for it in range(1, 5):
+        # replicated
+        fake_grads(b_rep.views, it)
+        b_rep.sink(); b_rep.start_early()
+        assert b_rep.consistent()
+        for wait, _ in b_rep.step_schedule():
+            wait()
+        _cpu_adamw_update(flat_p, b_rep.flat, m1, v1, lr_now, 0.9, 0.999, 1e-8, 1e-3, it, 1.0 / world)
+        # sharded: same local gradients
+        fake_grads(b_sh.views, it)
+        b_sh.sink()
+        opt.start_early()                             # GRIDS_READY_HOOK: the early pieces' reduce-scatter is in flight
+        if it == 3:                                   # the MLP range lost its views (autograd cloned): repaired, exchanged once
+            for p in p_sh[4:]:
+                p.grad = p.grad.clone()
+            assert not b_sh.consistent()
+        assert abs(opt.param_groups[0]["lr"] - lr_now) < 1e-15
+        opt.step()
+        sched.step()
+        lr_now = opt.param_groups[0]["lr"]
+        got = torch.cat([p.detach().reshape(-1) for p in p_sh])
+        assert torch.equal(got, flat_p), f"step {it}: sharded parameters differ from the replicated AdamW path (max {float((got - flat_p).abs().max())})"
+    # replicas identical
+    chk = opt.pflat.double().sum().reshape(1)
+    gathered = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(gathered, chk)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    # the moments of my shard equal the replicated moments of the same elements
+    for (lo, hi, off) in opt.shards:
+        n_real = max(0, min(hi, b_sh.numel) - lo)
+        assert torch.equal(opt.exp_avg[off:off + n_real], m1[lo:lo + n_real]) and torch.equal(opt.exp_avg_sq[off:off + n_real], v1[lo:lo + n_real])
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+@pytest.mark.parametrize("algo", ["reduce_scatter", "all_to_all"])
+def test_sharded_adamw_matches_replicated_world2(algo):
+    """reduce-scatter -> sharded AdamW -> all-gather keeps every replica BIT-identical to the all-reduce + full-AdamW path
+    (world 2: a + b is order-independent), over 4 steps with a cosine schedule, incl. a step whose MLP gradients lost their
+    bucket views; both exchange algorithms (RCCL-style reduce_scatter, one-hop all_to_all + local sum)."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, algo)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, "ok"), (1, "ok")]
+
+
+def test_sharded_adamw_single_process_has_no_cpu_update():
+    """Without a process group ShardedAdamW is a plain flat AdamW in pieces; its default update is the HIP kernel and
+    refuses CPU tensors (no CPU path in the product)."""
+    from nvp_amd import parallel
+    lin = torch.nn.Linear(5, 3)
+    b = parallel.GradBucket(parallel.unique_parameters(lin), pad_to=parallel.ShardedAdamW.alignment(1))
+    opt = parallel.ShardedAdamW(b, lr=1e-2)
+    lin.weight.grad.fill_(1.0)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        opt.step()
+    w0 = lin.weight.detach().clone()
+    opt2 = parallel.ShardedAdamW(b, lr=1e-2, weight_decay=0.0, update=_cpu_adamw_update)
+    lin.weight.grad.fill_(1.0); lin.bias.grad.fill_(0.0)
+    opt2.step()
+    assert torch.allclose(lin.weight, w0 - 1e-2, atol=1e-6)             # first Adam step: -lr * sign(g)
