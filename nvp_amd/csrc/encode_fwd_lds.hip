@@ -91,11 +91,36 @@ __global__ __launch_bounds__(kRun) void encode_fwd_lds_kernel(const float* __res
                 if (!range(l, c_lo, len)) continue;
                 const float* __restrict__ src = params + ((int64_t)lv.offset[l] + c_lo) * F;
                 float* __restrict__ dst = stage + P.slot[l];
-                for (int i = threadIdx.x; i < len; i += kRun) {
-                    float v[F];
-                    load_cell<F>(v, src + (int64_t)i * F);
+                // eight loads in flight per thread before the first LDS write (a load -> write loop serialises on the memory
+                // latency: 17 round trips for the widest level)
+                if (len <= 2 * kRun) {                           // coarse levels: at most two cells per thread
+                    float v[2][F];
+                    const int i = threadIdx.x;
+                    load_cell<F>(v[0], src + (int64_t)min(i, len - 1) * F);
+                    load_cell<F>(v[1], src + (int64_t)min(i + kRun, len - 1) * F);
 #pragma unroll
-                    for (int f = 0; f < F; ++f) dst[i * F + f] = v[f];
+                    for (int u = 0; u < 2; ++u)
+                        if (i + u * kRun < len) {
+#pragma unroll
+                            for (int f = 0; f < F; ++f) dst[(i + u * kRun) * F + f] = v[u][f];
+                        }
+                    continue;
+                }
+                for (int i0 = threadIdx.x; i0 < len; i0 += 8 * kRun) {
+                    float v[8][F];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * kRun;
+                        load_cell<F>(v[u], src + (int64_t)min(i, len - 1) * F);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * kRun;
+                        if (i < len) {
+#pragma unroll
+                            for (int f = 0; f < F; ++f) dst[i * F + f] = v[u][f];
+                        }
+                    }
                 }
             }
             __syncthreads();

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
 
 }  // namespace
 
-// called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on, the latent has <= 128 rows and NVP_MLP_RING != 0
+// called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on, the latent has <= 128 rows and NVP_MLP_RING_BWD != 0
 int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
                            const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);

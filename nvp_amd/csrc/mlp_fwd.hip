@@ -155,8 +155,10 @@ extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_pa
     if (!zt || !steps || !p || !packed_fwd || !rgb || n < 0 || d < 1) return NVP_ERR_BADARG;
     if (n == 0) return 0;
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
-        // NVP_MLP_RING=0 (environment, read once): per-wave weight streaming (mlp_fwd_b3.hip) instead of the workgroup-shared LDS ring
-        static const bool ring = [] { const char* e = getenv("NVP_MLP_RING"); return !(e && e[0] == '0'); }();
+        // NVP_MLP_RING_FWD=1 (environment, read once): workgroup-shared LDS weight ring (mlp_fwd_b3r.hip) instead of per-wave weight
+        // streaming.  Bit-identical results; measured 1.88-1.95 ms vs 1.77-1.85 ms on MI355X (the per-k-step barrier costs more
+        // than the 4x lower vector-memory traffic buys in this kernel), so it is OFF by default - kept as the A/B evidence.
+        static const bool ring = [] { const char* e = getenv("NVP_MLP_RING_FWD"); return e && e[0] == '1'; }();
         if (ring) return nvp_mlp_fwd_b3r_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
         return nvp_mlp_fwd_b3_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
     }

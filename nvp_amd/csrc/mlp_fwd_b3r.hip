@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
 
 }  // namespace
 
-// called by nvp_mlp_fwd (mlp_fwd.hip) when NVP_FWD_B3 is on, the latent has <= 256 rows and NVP_MLP_RING != 0
+// called by nvp_mlp_fwd (mlp_fwd.hip) when NVP_FWD_B3 is on, the latent has <= 256 rows and NVP_MLP_RING_FWD=1
 int nvp_mlp_fwd_b3r_launch(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
                            float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);

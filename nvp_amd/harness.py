@@ -248,6 +248,62 @@ def eval_psnr(model, video: DeviceVideo, frames=None, n_slice: int = 100, s_inte
     return (sum(psnrs) / len(psnrs)) if (plain and psnrs) else None
 
 
+def eval_slices(total_pixels: int, want: int = 100) -> int:
+    """The reference evaluates a frame in Nslice = 100 slices of int(total/100) pixels (eval.py:233-239) and leaves a
+    remainder unrendered; UVG-HD and 4K frame sizes divide by 100.  For other sizes pick the largest slice count <= want
+    that divides the frame, so that every pixel is rendered."""
+    for k in range(min(want, total_pixels), 0, -1):
+        if total_pixels % k == 0:
+            return k
+    return 1
+
+
+def load_video(path: str, frames: int, height: int = 0, width: int = 0) -> torch.Tensor:
+    """uint8 [T, H, W, 3] on the host, the reference's loader restated (dataio.py:33-66):
+      * `*.npy`            - np.load, first `frames` frames;
+      * a directory        - sorted(glob('*.png'))[:frames] through PIL (what the reference's README extracts UVG into);
+      * `*.yuv`            - raw planar 8-bit 4:2:0 (how UVG is distributed), needs height / width; converted with the
+                             BT.709 limited-range matrix and nearest chroma up-sampling (an ffmpeg-free approximation of
+                             the reference's `ffmpeg -i x.yuv f%05d.png` step; use the PNG route for exact parity)."""
+    import glob
+    import os
+    import numpy as np
+    if path.endswith(".npy"):
+        v = np.load(path, mmap_mode="r")[:frames]
+        return torch.from_numpy(np.ascontiguousarray(v)).to(torch.uint8)
+    if os.path.isdir(path):
+        from PIL import Image
+        files = sorted(glob.glob(os.path.join(path, "*.png")))[:frames]
+        if not files:
+            raise FileNotFoundError(f"no *.png frames under {path}")
+        first = np.array(Image.open(files[0]).convert("RGB"))
+        out = np.zeros((len(files),) + first.shape, dtype=np.uint8)
+        for i, f in enumerate(files):
+            out[i] = np.array(Image.open(f).convert("RGB"))
+        return torch.from_numpy(out)
+    if path.endswith(".yuv"):
+        if height <= 0 or width <= 0:
+            raise ValueError("raw .yuv needs --height and --width")
+        fsz = height * width * 3 // 2
+        n = min(frames, os.path.getsize(path) // fsz)
+        out = np.zeros((n, height, width, 3), dtype=np.uint8)
+        with open(path, "rb") as fh:
+            for i in range(n):
+                buf = np.frombuffer(fh.read(fsz), dtype=np.uint8)
+                y = buf[:height * width].reshape(height, width).astype(np.float32)
+                u = buf[height * width:height * width * 5 // 4].reshape(height // 2, width // 2).astype(np.float32)
+                v = buf[height * width * 5 // 4:].reshape(height // 2, width // 2).astype(np.float32)
+                u = np.repeat(np.repeat(u, 2, 0), 2, 1) - 128.0
+                v = np.repeat(np.repeat(v, 2, 0), 2, 1) - 128.0
+                yy = (y - 16.0) * (255.0 / 219.0)
+                r = yy + 1.5748 * v * (255.0 / 224.0)
+                g = yy - (0.1873 * u + 0.4681 * v) * (255.0 / 224.0)
+                b = yy + 1.8556 * u * (255.0 / 224.0)
+                out[i] = np.clip(np.stack((r, g, b), -1) + 0.5, 0, 255).astype(np.uint8)
+        return torch.from_numpy(out)
+    raise ValueError(f"unsupported video source {path!r}: expected .npy, a PNG directory or .yuv")
+
+
 def procedural_video(T: int, H: int, W: int, device, seed: int = 0) -> torch.Tensor:
     """Deterministic smooth moving pattern (stand-in for UVG frames, which are not shipped)."""
     g = torch.Generator().manual_seed(seed)

@@ -5,6 +5,15 @@ tensorboard / checkpoint / argparse plumbing.
 
     python -m nvp_amd.train --video procedural --frames 600 --height 1080 --width 1920 --seconds 90
     python -m nvp_amd.train --video /path/to/video.npy --steps 4000         # uint8 [T,H,W,3]
+    python -m nvp_amd.train --video /data/UVG/Jockey --frames 600 --seconds 90 --log jockey_90s.jsonl      # directory of PNG frames
+    python -m nvp_amd.train --video Jockey_1920x1080_120fps_420_8bit_YUV.yuv --height 1080 --width 1920 --frames 600 --seconds 90
+
+Time-to-quality recipe (BASELINE.json north_star: the reference's 5-minute UVG-HD PSNR, 34.57 dB average over the seven
+UVG clips at 0.901 bpp on a V100, README.md:92-100, in <= 90 s on one MI355X): run the third line on a real clip; every
+--report-every steps a JSON line {step, seconds (training time only), train_psnr, eval_psnr, mpx_per_s} is printed (and
+appended to --log), and the summary line carries the fp32 and the 8-bit-grid PSNR (what the README table reports) and
+the bpp.  UVG frames are not shipped with this repo and cannot be fetched here: the committed 90-second log
+(profiles/*train_90s*) is on the PROCEDURAL clip and says nothing about that target beyond the step rate.
 
 What it reproduces from the reference: model = NVP(config_nvp_s|l with t_resolution = #frames),
 N = 1 245 184 samples per step drawn as dataio.py:104-120, loss/PSNR as training.py:47-61,
@@ -44,7 +53,8 @@ def config(size: str, t_res: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["s", "l"], default="s")
-    ap.add_argument("--video", default="procedural", help="'procedural' or a .npy file with uint8 [T,H,W,3]")
+    ap.add_argument("--video", default="procedural", help="'procedural', a .npy file with uint8 [T,H,W,3], a directory of PNG frames, or a raw 4:2:0 .yuv")
+    ap.add_argument("--log", default="", help="append the JSON report lines to this file")
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
@@ -63,12 +73,20 @@ def main():
         video = harness.procedural_video(args.frames, args.height, args.width, dev, seed=args.seed)
         source = "procedural moving pattern (UVG frames are not shipped)"
     else:
-        video = torch.from_numpy(np.load(args.video)[:args.frames]).to(dev)
+        video = harness.load_video(args.video, args.frames, args.height, args.width).to(dev)
         source = args.video
     T, H, W = (int(v) for v in video.shape[:3])
     model = NVP(out_features=3, encoding_config=config(args.config, T)).to(dev)
     data = harness.DeviceVideo(video, seed=args.seed)
     frames = [int(round(i * (T - 1) / max(args.eval_frames - 1, 1))) for i in range(args.eval_frames)]
+    n_slice = harness.eval_slices(H * W)
+
+    def emit(rec):
+        line = json.dumps(rec)
+        print(line, flush=True)
+        if args.log:
+            with open(args.log, "a") as f:
+                f.write(line + "\n")
 
     total = args.steps
     if total <= 0:
@@ -92,26 +110,26 @@ def main():
         if (step + 1) % args.report_every == 0 or step + 1 == total:
             torch.cuda.synchronize()
             train_s += time.perf_counter() - seg
-            print(json.dumps({"step": step + 1, "seconds": round(train_s, 2), "train_psnr": round(harness.train_psnr(loss), 3),
-                              "eval_psnr": round(harness.eval_psnr(model, data, frames), 3),
-                              "mpx_per_s": round((step + 1) * data.n / train_s / 1e6, 2)}), flush=True)
+            emit({"step": step + 1, "seconds": round(train_s, 2), "train_psnr": round(harness.train_psnr(loss), 3),
+                  "eval_psnr": round(harness.eval_psnr(model, data, frames, n_slice=n_slice), 3),
+                  "mpx_per_s": round((step + 1) * data.n / train_s / 1e6, 2)})
             torch.cuda.synchronize()
             seg = time.perf_counter()
     encode_s = train_s
 
-    psnr_fp32 = harness.eval_psnr(model, data, frames)
+    psnr_fp32 = harness.eval_psnr(model, data, frames, n_slice=n_slice)
     with torch.no_grad():                                   # eval.py:163-179: rebind 8-bit de-quantised grids
         cfg = config(args.config, T)
         for name, key in (("keyframes_xy", "2d_encoding_xy"), ("keyframes_xt", "2d_encoding_xt"), ("keyframes_yt", "2d_encoding_yt")):
             enc = getattr(model, name)
             enc.params = quantize.quantize_keyframes(enc.params.detach(), cfg[key])
         model.sparse_grid.embeddings = quantize.quantize_sparse_grid(model.sparse_grid.embeddings.detach())
-    psnr_q8 = harness.eval_psnr(model, data, frames)
-    print(json.dumps({"summary": True, "video": source, "frames": T, "height": H, "width": W, "config": "nvp_" + args.config,
+    psnr_q8 = harness.eval_psnr(model, data, frames, n_slice=n_slice)
+    emit({"summary": True, "video": source, "frames": T, "height": H, "width": W, "config": "nvp_" + args.config,
                       "steps": total, "encode_seconds": round(encode_s, 2), "eval_frames": frames,
                       "psnr_fp32": round(psnr_fp32, 3), "psnr_8bit_grids": round(psnr_q8, 3),
                       "bpp_8bit": round(quantize.quantized_bpp(model, T, H, W), 4),
-                      "mpx_per_s": round(total * data.n / encode_s / 1e6, 2)}), flush=True)
+                      "mpx_per_s": round(total * data.n / encode_s / 1e6, 2)})
 
 
 if __name__ == "__main__":

@@ -75,4 +75,11 @@ def report(test: str, **vals):
     import json
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_report.jsonl"), "a") as f:
-        f.write(json.dumps({"test": test, **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in vals.items()}}) + "\n")
+        def plain(v):
+            if isinstance(v, (list, tuple)):
+                return [plain(x) for x in v]
+            try:
+                return float(v) if not isinstance(v, str) else v
+            except (TypeError, ValueError):
+                return str(v)
+        f.write(json.dumps({"test": test, **{k: plain(v) for k, v in vals.items()}}) + "\n")

@@ -379,10 +379,13 @@ def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
 
 
 @pytest.mark.parametrize("F,n,border", [(2, 200000, "wrap"), (4, 70000, "wrap"), (2, 3000, "wrap"), (2, 257, "clamp"), (2, 50000, "clamp")])
-def test_lds_staged_gather_is_bit_identical_to_the_global_gather(F, n, border):
-    """NVP_COORDS_SORTED_BY_Y routes the xy / yt planes through the LDS-staged kernel (encode_fwd_lds.hip): RGB must equal the
-    un-hinted evaluation bit for bit - dense batches (every level staged), sparse ones (fine levels fall back to global
-    loads because a 256-pixel run spans many grid rows), runs ending at y == 1 (the wrap-around rows fall back), both borders."""
+def test_sorted_hint_forward_is_bit_identical(F, n, border):
+    """The sorted_by_y hint must never change a bit of the forward result - whichever gather serves it: by default the global
+    gather (hint only matters to the scatter); with NVP_ENCODE_LDS=1 in the environment the xy / yt planes of hinted batches go
+    through the LDS-staged kernel (encode_fwd_lds.hip): dense batches (every level staged), sparse ones (fine levels fall back
+    to global loads because a 256-pixel run spans many grid rows), runs ending at y == 1 (wrap-around rows fall back), both
+    borders.  tools/ab_ring.sh runs the two kernel families in separate processes and compares RGB and every gradient bit for
+    bit; test_kernel_variants_are_bit_identical below does the same from pytest."""
     from nvp_amd.modules import NVP
     cfg = small_cfg(F=F)
     for k in ("2d_encoding_xy", "2d_encoding_xt", "2d_encoding_yt"):
@@ -766,3 +769,24 @@ def test_sorted_hint_is_checked_on_request(monkeypatch):
         model(mi)["model_out"].sum().backward()
     srt = coords[0][torch.argsort(coords[0][:, 2])].unsqueeze(0)
     model({"all_coords": srt, "temporal_steps": mi["temporal_steps"], "sorted_by_y": True})["model_out"].sum().backward()
+
+
+def test_kernel_variants_are_bit_identical(tmp_path):
+    """The alternative kernels kept behind environment switches (read once per process by libnvp_hip.so) - the LDS-staged gather
+    (NVP_ENCODE_LDS=1), the workgroup-shared weight ring of the forward chain (NVP_MLP_RING_FWD=1) and the per-wave backward
+    chain (NVP_MLP_RING_BWD=0) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
+    accumulator, same index arithmetic; only where operands are staged differs)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for k, env in enumerate(({"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # the defaults
+                             {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0"})):        # every alternative
+        out = str(tmp_path / f"v{k}.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300,
+                       env={**os.environ, **env})
+        outs.append(np.load(out))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 19
+    for k in a.files:
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"{k} differs between kernel variants (max {np.abs(a[k] - b[k]).max()})"

@@ -284,3 +284,25 @@ def test_compat_install_shadows_the_reference_import_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_video_loaders_and_eval_slices(tmp_path):
+    """Row H: the loader restates dataio.py:33-66 (.npy, sorted PNG directory truncated to the frame count) plus raw 4:2:0 .yuv."""
+    from nvp_amd import harness
+    from PIL import Image
+    g = np.random.default_rng(0)
+    vid = g.integers(0, 256, (5, 12, 16, 3), dtype=np.uint8)
+    np.save(tmp_path / "v.npy", vid)
+    assert torch.equal(harness.load_video(str(tmp_path / "v.npy"), 4), torch.from_numpy(vid[:4]))
+    d = tmp_path / "frames"
+    d.mkdir()
+    for i in range(5):
+        Image.fromarray(vid[i]).save(d / f"f{i:05d}.png")
+    assert torch.equal(harness.load_video(str(d), 3), torch.from_numpy(vid[:3]))
+    # gray 4:2:0 frame: Y = 126 (limited range mid-gray), U = V = 128 -> R = G = B = round((126 - 16) * 255 / 219) = 128
+    yuv = np.concatenate([np.full(12 * 16, 126, np.uint8), np.full(6 * 8 * 2, 128, np.uint8)])
+    (tmp_path / "g.yuv").write_bytes(np.tile(yuv, 2).tobytes())
+    out = harness.load_video(str(tmp_path / "g.yuv"), 2, height=12, width=16)
+    assert out.shape == (2, 12, 16, 3) and int(out.min()) == int(out.max()) == 128
+    assert harness.eval_slices(1920 * 1080) == 100 and harness.eval_slices(3840 * 2160) == 100      # eval.py:233: Nslice = 100
+    assert harness.eval_slices(64 * 64) == 64 and (97 * 89) % harness.eval_slices(97 * 89) == 0
