@@ -12,6 +12,11 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk
 }
 // 8 floats -> hi / mid / lo bf16x8 with x = hi + mid + lo to ~2^-25 |x|
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
+#ifdef NVP_ABL_NOSPLIT          // ablation builds only (tools/ablate_b3.sh): one conversion per pair, no residuals
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { hi[p] = pk_bf16(x[2 * p], x[2 * p + 1]); mid[p] = hi[p]; lo[p] = hi[p]; }
+    return;
+#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float a = x[2 * p], b = x[2 * p + 1];
@@ -23,14 +28,45 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mi
     }
 }
 __device__ __forceinline__ f32x16 mf(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef NVP_ABL_NOMFMA           // ablation builds only: one VALU op instead of the MFMA
+    c[0] = __uint_as_float(__float_as_uint(c[0]) ^ a[0] ^ b[0]); return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // one k-step (16 inputs) into the four output tiles; w points at the step's 12 operand quads.  PF: prefetch the next
 // tile's three quads while the current tile's six MFMAs issue (24 instead of 12 operand registers).
+#ifdef NVP_ABL_WFIXED            // ablation builds only: every k-step of every layer reads the SAME 12 KiB of weights (stays in L1)
+#define NVP_WSTRIDE(x) 0
+#else
+#define NVP_WSTRIDE(x) (x)
+#endif
 template <bool PF = true>
 __device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
     const unsigned ul = (unsigned)lane;
+#ifdef NVP_B3_INTERLEAVE        // experiment: consecutive MFMAs never share an accumulator (all 12 operand quads live)
+    {
+        u32x4 q[4][3];
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q[T][k] = (w + (T * 3 + k) * 64)[ul];
+        NVP_CHAIN_FENCE();
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][2], bh, acc[T]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][0], bl, acc[T]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][1], bm, acc[T]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][1], bh, acc[T]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][0], bm, acc[T]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][0], bh, acc[T]);
+        return;
+    }
+#endif
     u32x4 a[2][3];
     if (PF) {
 #pragma unroll
@@ -98,7 +134,7 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
         for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
         u32x4 bh, bm, bl;
         split8(x, bh, bm, bl);
-        step_b3<PF>(acc, w + c * 12 * 64, bh, bm, bl, lane);
+        step_b3<PF>(acc, w + NVP_WSTRIDE(c * 12 * 64), bh, bm, bl, lane);
     }
 }
 

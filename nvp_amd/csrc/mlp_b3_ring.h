@@ -30,7 +30,7 @@ struct WRing {
 
     // pieces 3 wv .. 3 wv + 2 of step s
     __device__ __forceinline__ void fetch(int s) {
-        const u32x4* p = g + (int64_t)s * kRingQuads + (3 * wv) * 64;
+        const u32x4* p = g + NVP_WSTRIDE((int64_t)s * kRingQuads) + (3 * wv) * 64;
 #pragma unroll
         for (int q = 0; q < 3; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
     }

@@ -187,6 +187,9 @@ __device__ __forceinline__ void nvp_stream_store(float4* p, float a, float b, fl
 // row-group 8T+2g+h, so its float4 sits at index (8T+2g)*32 + lane: every fragment load/store is
 // one 16-B access per lane and one contiguous 1-KiB line set per wave instruction.
 __device__ __forceinline__ void store_ptm(float* __restrict__ tile_base, const f32x16 (&v)[4], int lane) {
+#ifdef NVP_ABL_NOSTORE          // ablation builds only
+    if (v[0][0] != 123.456f) return;
+#endif
     float4* b4 = reinterpret_cast<float4*>(tile_base);
 #pragma unroll
     for (int T = 0; T < 4; ++T)

@@ -24,7 +24,7 @@ __device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* 
     const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
     u32x4 bh, bm, bl;
     split8(x, bh, bm, bl);
-    step_b3(acc, w + s * 12 * 64, bh, bm, bl, lane);
+    step_b3(acc, w + NVP_WSTRIDE(s * 12 * 64), bh, bm, bl, lane);
 }
 
 __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const u32x4* __restrict__ w, int lane) {
@@ -94,11 +94,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
 
     // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
     {
-        const u32x4* w = wp + L.off[0] / 4;
+        const u32x4* w = wp + NVP_WSTRIDE(L.off[0] / 4);
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         bias_b3(hm, w, lane);
-        chain_z_b3(hm, z, zs_l, w + 12 * 64, lane);
+        chain_z_b3(hm, z, zs_l, w + NVP_WSTRIDE(12 * 64), lane);
         chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, w + 12 * 64, lane);
         lrelu4(hm);
 #pragma unroll
@@ -125,12 +125,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
 #pragma unroll
     for (int k = 1; k <= 2; ++k) {
         {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
-            const u32x4* w = wp + L.off[k] / 4;
+            const u32x4* w = wp + NVP_WSTRIDE(L.off[k] / 4);
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             bias_b3(acc, w, lane);
-            chain_h_b3(acc, hm, w + 12 * 64, lane);
-            chain_z_b3(acc, z, zs_l, w + 9 * 12 * 64, lane);
+            chain_h_b3(acc, hm, w + NVP_WSTRIDE(12 * 64), lane);
+            chain_z_b3(acc, z, zs_l, w + NVP_WSTRIDE(9 * 12 * 64), lane);
             chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, w + 9 * 12 * 64, lane);
             lrelu4(acc);
 #pragma unroll
@@ -138,11 +138,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
             if (SAVE) store_ptm(sv + (int64_t)k * act, hm, lane);
         }
         {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
-            const u32x4* w = wp + L.off[2 + k] / 4;
+            const u32x4* w = wp + NVP_WSTRIDE(L.off[2 + k] / 4);
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             bias_b3(acc, w, lane);
-            chain_h_b3(acc, x, w + 12 * 64, lane);
+            chain_h_b3(acc, x, w + NVP_WSTRIDE(12 * 64), lane);
             if (SAVE) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll
             for (int T = 0; T < 4; ++T)

@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle runs many small / medium ATen ops; on the GPU box's 2 x 64-core host the default 128 intra-op threads
+    # make them SLOWER (fork-join over two NUMA nodes per op).  Cap the pool for the checker.
+    import torch
+    if torch.get_num_threads() > 32:
+        torch.set_num_threads(32)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -304,8 +304,10 @@ def test_nvp_forward_backward_vs_oracle(F, n):
     sd_ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     ref = O.nvp_forward(coords, steps, sd_ref, cfg)
     O.image_mse(ref, gt).backward()
-    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}          # float64 yardstick (test_gpu_real_configs.py)
-    O.image_mse(O.nvp_forward(coords, steps, sd64, cfg), gt.double()).backward()
+    use64 = n >= 2048                             # float64 yardstick (test_gpu_real_configs.py) on the two large cases; the
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()} if use64 else None      # small ones compare with the fp32 oracle
+    if use64:
+        O.image_mse(O.nvp_forward(coords, steps, sd64, cfg), gt.double()).backward()
 
     out = model({"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())})["model_out"]
     assert out.shape == (1, n, 3)
@@ -314,12 +316,16 @@ def test_nvp_forward_backward_vs_oracle(F, n):
     ((out - gt.to(dev())) ** 2).mean().backward()
     for k in sd:
         got = _grad_of(model, k).cpu().numpy()
-        want, exact = sd_ref[k].grad.numpy(), sd64[k].grad.numpy()
+        want = sd_ref[k].grad.numpy()
         assert got.shape == want.shape
-        e_hip, e_ora = relerr_max(got, exact), relerr_max(want, exact)
-        report("nvp_fwd_bwd", F=F, n=n, tensor=k, max_hip_vs_f64=e_hip, max_oracle_vs_f64=e_ora, max_hip_vs_oracle=relerr_max(got, want))
-        # as close to the exact gradient as the reference's fp32 arithmetic is (x2), floor ~3x the measured error
-        assert e_hip <= max(2.0 * e_ora, 3e-6), f"grad {k}: {e_hip:.3e} vs float64 (fp32 oracle: {e_ora:.3e})"
+        if use64:
+            exact = sd64[k].grad.numpy()
+            e_hip, e_ora = relerr_max(got, exact), relerr_max(want, exact)
+            report("nvp_fwd_bwd", F=F, n=n, tensor=k, max_hip_vs_f64=e_hip, max_oracle_vs_f64=e_ora, max_hip_vs_oracle=relerr_max(got, want))
+            # as close to the exact gradient as the reference's fp32 arithmetic is (x2), floor ~2x the largest measured error (1.7e-6)
+            assert e_hip <= max(2.0 * e_ora, 3e-6), f"grad {k}: {e_hip:.3e} vs float64 (fp32 oracle: {e_ora:.3e})"
+        else:
+            assert relerr_max(got, want) < GRAD_TOL_MAX, f"grad {k}: {relerr_max(got, want):.3e} vs the fp32 oracle"
         if k.endswith(".params") or k.endswith("embeddings"):
             # dense-grad contract: a cell no pixel touches is EXACTLY zero, a touched cell is not lost
             z_want, z_got = want == 0, got == 0
@@ -575,27 +581,63 @@ def _psnr_trajectories(seed, steps_total, n_levels=16, log=None):
     return pa, pb, pg, eval_ref(ref_a), eval_ref(ref_b), ev_g
 
 
-@pytest.mark.parametrize("seed,n_levels", [(3, 16), (4, 12), (5, 12)])
-def test_psnr_at_equal_steps_matches_oracle(seed, n_levels):
-    """north_star: PSNR within +-0.02 dB at equal step count.  100 steps (NVP_PSNR_STEPS), three seeds.
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_psnr_at_equal_steps_matches_oracle(seed):
+    """north_star: PSNR within +-0.02 dB at equal step count - 100 steps (NVP_PSNR_STEPS), three seeds, identical batches, the
+    product's own AdamW kernel; STRICT bound on every step, plus the full-frame evaluation PSNR of the final parameters.
 
-    Two fp32 trainings of this model separate over a long horizon whatever computes them (sine layers with w0 = 30 amplify
-    rounding differences): the oracle started <= 1 ulp away from itself drifts by the same order.  So: the first 30 steps are
-    held to the strict 0.02 dB; over the whole horizon the HIP-vs-oracle gap must stay inside max(0.02 dB, 2 x the
-    oracle-vs-1-ulp-oracle envelope measured on the same batches in this very test).  Signed final differences are reported
-    (gpurun_out/parity_report.jsonl) - DESIGN.md section 5 discusses their sign."""
+    Each run also trains the oracle started <= 1 ulp away from itself: two fp32 trainings of this model drift apart whatever
+    computes them (sine layers with w0 = 30 amplify rounding differences), and the HIP-vs-oracle gap must not exceed twice that
+    envelope either (measured on MI355X: gap 0.007-0.008 dB, envelope 0.006-0.011 dB, signed final differences +0.003 / -0.007 dB:
+    no systematic sign - gpurun_out/parity_report.jsonl).  12 of the 16 keyframe levels (0.36 M cells per
+    plane instead of 4.6 M) keep the three CPU trainings of the checker affordable; the 16-level model is covered by
+    test_psnr_at_equal_steps_full_levels."""
     steps_total = int(os.environ.get("NVP_PSNR_STEPS", "100"))
-    pa, pb, pg, ev_a, ev_b, ev_g = _psnr_trajectories(seed, steps_total, n_levels, log=os.environ.get("NVP_PSNR_LOG"))
+    pa, pb, pg, ev_a, ev_b, ev_g = _psnr_trajectories(seed, steps_total, 12, log=os.environ.get("NVP_PSNR_LOG"))
     import math
     assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
     gap = [abs(a - g) for a, g in zip(pa, pg)]
     env = [abs(a - b) for a, b in zip(pa, pb)]
-    report("psnr_equal_steps", seed=seed, n_levels=n_levels, steps=steps_total, gap30=max(gap[:30]), gap=max(gap), envelope=max(env),
+    report("psnr_equal_steps", seed=seed, n_levels=12, steps=steps_total, gap30=max(gap[:30]), gap=max(gap), envelope=max(env),
            final_hip_minus_oracle=pg[-1] - pa[-1], final_1ulp_minus_oracle=pb[-1] - pa[-1],
            eval_hip_minus_oracle=ev_g - ev_a, eval_1ulp_minus_oracle=ev_b - ev_a, final_psnr=pa[-1])
-    assert max(gap[:30]) <= 0.02, f"train-PSNR gap over the first 30 steps {max(gap[:30]):.4f} dB"
-    assert max(gap) <= max(0.02, 2.0 * max(env)), f"train-PSNR gap {max(gap):.4f} dB vs 1-ulp envelope {max(env):.4f} dB"
-    assert abs(ev_g - ev_a) <= max(0.02, 2.0 * abs(ev_b - ev_a)), f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
+    assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB over {steps_total} steps (1-ulp envelope {max(env):.4f} dB)"
+    assert max(gap) <= max(0.01, 2.0 * max(env)), f"train-PSNR gap {max(gap):.4f} dB vs 1-ulp envelope {max(env):.4f} dB"
+    assert abs(ev_g - ev_a) <= 0.02, f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
+
+
+def test_psnr_at_equal_steps_full_levels():
+    """The same check on the full 16-level keyframes (config_nvp_s values, BASELINE.json configs[0]) over 50 steps, without the
+    1-ulp twin (each CPU step of the checker updates 27.8 M parameters)."""
+    import math
+    from nvp_amd import harness
+    from nvp_amd.modules import NVP
+    T, H, W, n, steps_total, seed = 16, 64, 64, 8192, int(os.environ.get("NVP_PSNR_STEPS_FULL", "50")), 3
+    cfg = small_cfg(F=2, T=T, X=20, Y=20)
+    sd = O.init_state(cfg, seed=seed)
+    model = NVP(out_features=3, encoding_config=cfg)
+    _load_state_into(model, sd)
+    model = model.to(dev())
+    video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=1)
+    flat = video.reshape(T, H * W, 3)
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt_r = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)
+    sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=steps_total, eta_min=1e-5)
+    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)
+    gen = torch.Generator().manual_seed(0)
+    gap = []
+    for it in range(steps_total):
+        ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)
+        gt_u8 = flat[ti, pi].unsqueeze(0)
+        loss_r = O.image_mse(O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg), O.normalise_gt(gt_u8))
+        opt_r.zero_grad(); loss_r.backward(); opt_r.step(); sch_r.step()
+        mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
+        loss_g = harness.image_mse_u8(model(mi)["model_out"], gt_u8.to(dev()))
+        opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
+        gap.append(abs(10 * math.log10(4 / float(loss_r)) - 10 * math.log10(4 / float(loss_g))))
+    report("psnr_equal_steps_full", steps=steps_total, gap=max(gap), final_gap=gap[-1], final_psnr=10 * math.log10(4 / float(loss_r)))
+    assert 10 * math.log10(4 / float(loss_g)) > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
+    assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"
 
 
 @pytest.mark.gpu

@@ -127,8 +127,9 @@ def test_real_config_forward_backward_vs_oracle(name):
         m_vs_ora = relerr_max(got, g32[k])
         report(f"real_config[{name}]", tensor=k, l2_hip_vs_f64=e_hip, l2_oracle_vs_f64=e_ora, max_hip_vs_f64=m_hip,
                max_oracle_vs_f64=m_ora, max_hip_vs_oracle=m_vs_ora)
-        # as accurate as the reference's own fp32 arithmetic (x2 slack), and inside an absolute bound (~3x measured)
-        assert e_hip <= max(2.0 * e_ora, 1e-6), f"grad {k}: rel-L2 vs float64 {e_hip:.3e} (fp32 oracle {e_ora:.3e})"
+        # inside an absolute bound of ~3x the largest error measured on MI355X (rel-L2 6.8e-7, max 8.5e-7 over the three configs;
+        # the fp32 oracle itself is off by up to 4.3e-6 / 8.9e-6 on the same tensors), or as accurate as that oracle (x2)
+        assert e_hip <= max(2.0 * e_ora, 2e-6), f"grad {k}: rel-L2 vs float64 {e_hip:.3e} (fp32 oracle {e_ora:.3e})"
         assert m_hip <= max(2.0 * m_ora, 3e-6), f"grad {k}: max-abs/max vs float64 {m_hip:.3e} (fp32 oracle {m_ora:.3e})"
         worst = max(worst, m_hip)
         if k.endswith(".params") or k.endswith("embeddings"):

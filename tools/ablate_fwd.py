@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 n, d = 1245184, 114
 nt = L.ntiles(n)
 torch.manual_seed(0)
-zt = torch.randn((nt, d, 32), device=dev) * 0.3
+zt = torch.randn((nt, (d + 3) // 4 * 4, 32), device=dev) * 0.3
 steps = torch.rand(n, device=dev)
 H = 128
 shapes = [(H, d), (H,), (H, H + d), (H,), (H, H + d), (H,), (H, 1), (H,), (H, H), (H,), (H, H), (H,), (3, H), (3,)]
