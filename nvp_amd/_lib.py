@@ -14,7 +14,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnvp_hip.so")
+# NVP_HIP_LIB: load another build of the same library (A/B runs of kernel variants built by tools/build_variant.sh)
+LIB_PATH = os.environ.get("NVP_HIP_LIB") or os.path.join(_HERE, "csrc", "libnvp_hip.so")
 
 NVP_MAX_LEVELS = 16
 COORDS_SORTED_BY_Y = 1

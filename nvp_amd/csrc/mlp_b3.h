@@ -125,8 +125,13 @@ __device__ __forceinline__ void bias_b3(f32x16 (&acc)[4], const u32x4* __restric
 }
 
 // 8 k-steps over the previous layer's D registers
+template <bool PF>
+__device__ __forceinline__ void chain_h_b3_swp(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane);
 template <bool PF = true>
 __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane) {
+#if NVP_B3_SWP
+    if (PF) { chain_h_b3_swp<PF>(acc, hin, w, lane); return; }
+#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
@@ -152,6 +157,78 @@ __device__ __forceinline__ void chain_h2_b3(f32x16 (&acc_a)[4], const u32x4* __r
         split8(x, bh, bm, bl);
         step_b3<PF>(acc_a, wa + c * 12 * 64, bh, bm, bl, lane);
         step_b3<PF>(acc_b, wb + c * 12 * 64, bh, bm, bl, lane);
+    }
+}
+
+// ---- software-pipelined operand split (NVP_B3_SWP) ------------------------------------------------------------------
+// A wave issues in order: with the split of k-step c placed in front of its 24 MFMAs, the wave's ~45 split instructions
+// and its MFMAs never overlap (only the PARTNER wave's MFMAs can run underneath), and the ablations show the VALU pipe is
+// as loaded as the matrix pipe.  Here the split of k-step c+1 is cut into four pair-splits and each is woven between the
+// six MFMAs of one output tile of k-step c (sched_group_barrier: 1 MFMA, 2 VALU, ...): the VALU instructions issue in the
+// shadow of the wave's own MFMAs (<= 5 issue slots are free per 32-cycle MFMA).
+#ifndef NVP_B3_SWP
+#define NVP_B3_SWP 0
+#endif
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16(sa, sb);
+}
+
+// one k-step into four output tiles with the NEXT k-step's operand split woven in: xn = the next step's eight inputs
+// (ignored when !more); nh/nm/nl receive its parts
+__device__ __forceinline__ void step_b3_swp(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl,
+                                            const float (&xn)[8], bool more, u32x4& nh, u32x4& nm, u32x4& nl, int lane) {
+    const unsigned ul = (unsigned)lane;
+    u32x4 a[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        if (T < 3) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+        }
+        NVP_CHAIN_FENCE();
+        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
+        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
+        acc[T] = mf(ah, bl, acc[T]);
+        acc[T] = mf(am, bm, acc[T]);
+        acc[T] = mf(am, bh, acc[T]);
+        acc[T] = mf(ah, bm, acc[T]);
+        acc[T] = mf(ah, bh, acc[T]);
+        if (more) {
+            unsigned h_, m_, l_;
+            split2(xn[2 * T], xn[2 * T + 1], h_, m_, l_);
+            nh[T] = h_; nm[T] = m_; nl[T] = l_;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU in its shadow
+            }
+        }
+    }
+}
+
+template <bool PF = true>
+__device__ __forceinline__ void chain_h_b3_swp(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane) {
+    u32x4 bh, bm, bl;
+    {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = hin[0][q];
+        split8(x, bh, bm, bl);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float xn[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xn[q] = hin[((c + 1) & 7) >> 1][8 * ((c + 1) & 1) + q];
+        u32x4 nh = bh, nm = bm, nl = bl;
+        step_b3_swp(acc, w + NVP_WSTRIDE(c * 12 * 64), bh, bm, bl, xn, c + 1 < 8, nh, nm, nl, lane);
+        bh = nh; bm = nm; bl = nl;
     }
 }
 

@@ -65,8 +65,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
                                                                     int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifndef NVP_FWD_SYNC
+#define NVP_FWD_SYNC 0          // experiment: s_barrier at every layer start keeps the workgroup's four waves in phase (their weight loads then hit in L1)
+#endif
+#if NVP_FWD_SYNC
+#define NVP_LAYER_SYNC() asm volatile("s_barrier" ::: "memory")
+    int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
+    const bool active = tile < ntiles;
+    if (!active) tile = ntiles - 1;                   // walks the barriers; its (duplicate) results are not stored
+#else
+#define NVP_LAYER_SYNC()
     const int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
     if (tile >= ntiles) return;                       // wave-uniform
+    const bool active = true;
+#endif
     nvp_stagger_start();
     const int j = lane & 31, h = lane >> 5;
     const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
@@ -88,13 +100,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
-    float* sv = SAVE ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
+    float* sv = (SAVE && active) ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
 
     f32x16 hm[4], x[4], acc[4];
 
     // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
     {
         const u32x4* w = wp + NVP_WSTRIDE(L.off[0] / 4);
+        NVP_LAYER_SYNC();
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         bias_b3(hm, w, lane);
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
         lrelu4(hm);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
-        if (SAVE) store_ptm(sv + 0 * act, hm, lane);
+        if (SAVE && active) store_ptm(sv + 0 * act, hm, lane);
     }
     // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
     {
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     for (int k = 1; k <= 2; ++k) {
         {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
             const u32x4* w = wp + NVP_WSTRIDE(L.off[k] / 4);
+            NVP_LAYER_SYNC();
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             bias_b3(acc, w, lane);
@@ -135,15 +149,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
             lrelu4(acc);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
-            if (SAVE) store_ptm(sv + (int64_t)k * act, hm, lane);
+            if (SAVE && active) store_ptm(sv + (int64_t)k * act, hm, lane);
         }
         {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
             const u32x4* w = wp + NVP_WSTRIDE(L.off[2 + k] / 4);
+            NVP_LAYER_SYNC();
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             bias_b3(acc, w, lane);
             chain_h_b3(acc, x, w + NVP_WSTRIDE(12 * 64), lane);
-            if (SAVE) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
+            if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
         o0 += __shfl_xor(o0, 32);
         o1 += __shfl_xor(o1, 32);
         o2 += __shfl_xor(o2, 32);
-        if (h == 0 && px < n) {
+        if (active && h == 0 && px < n) {
             rgb[px * 3 + 0] = o0 + p.last_b[0];
             rgb[px * 3 + 1] = o1 + p.last_b[1];
             rgb[px * 3 + 2] = o2 + p.last_b[2];
