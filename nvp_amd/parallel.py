@@ -334,7 +334,7 @@ class ShardedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
         self.steps_done = 0
-        self._scratch = torch.empty(bucket.padded, device=dev, dtype=torch.float32) if (algo == "all_to_all" and self.world > 1) else None
+        self._scratch = torch.empty(bucket.padded, device=dev, dtype=torch.float32) if (algo == "all_to_all" and (self.world > 1 or _force())) else None
         self._early_work = None
 
     # -- exchange of one piece: after wait(), flat[own shard] holds the cross-rank SUM of that shard
