@@ -8,7 +8,7 @@ WRITE_SIZE is used as reported (uncalibrated in the guide)."""
 import collections, csv, json, os, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = {"mlp_fwd_kernel": "nvp_mlp_fwd", "mlp_fwd_b3_kernel": "nvp_mlp_fwd", "mlp_bwd_b3_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dx_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_kernel": "nvp_mlp_bwd_dx",
+KEYS = {"mlp_fwd_kernel": "nvp_mlp_fwd", "mlp_fwd_b3_kernel": "nvp_mlp_fwd", "mlp_fwd_b3r_kernel": "nvp_mlp_fwd", "mlp_bwd_b3_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_b3r_kernel": "nvp_mlp_bwd_dx", "encode_fwd_lds_kernel": "nvp_encode_fwd", "mlp_bwd_dx_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_kernel": "nvp_mlp_bwd_dx",
         "mlp_dw_kernel": "nvp_mlp_bwd_dw", "dw_reduce_kernel": "nvp_mlp_bwd_dw", "dw_records_kernel": "nvp_mlp_bwd_dw", "encode_fwd_kernel": "nvp_encode_fwd",
         "band_kernel": "nvp_encode_bwd", "permute_kernel": "nvp_encode_bwd", "sparse_band_kernel": "nvp_encode_bwd",
         "sparse_keys_kernel": "nvp_encode_bwd", "slab_reduce_kernel": "nvp_encode_bwd", "rowstart_kernel": "nvp_encode_bwd", "keys_kernel": "nvp_encode_bwd"}
