@@ -141,6 +141,8 @@ def main():
         if rank == 0 and args.gpus > 1:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("NVP_DIST_BACKEND") == "gloo":
+        local = 0                              # smoke test: every rank on the one GPU of the box
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()

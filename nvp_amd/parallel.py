@@ -46,7 +46,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or _force()) and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # NVP_DIST_BACKEND=gloo: smoke-test the multi-rank code paths with several ranks on ONE GPU (RCCL refuses that)
+            backend = os.environ.get("NVP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
