@@ -54,7 +54,11 @@ struct WRing {
     // end of k-step s: everyone has read slot s, slot s+1 is complete.  NOT __syncthreads(): its workgroup-scope release
     // fence makes hipcc wait for vmcnt(0) - i.e. for the weight fetch issued two steps ahead and for every stream store in
     // flight - at every k-step.  Only LDS traffic has to be settled here.
+#ifdef NVP_ABL_NOBARRIER         // ablation builds only: results are wrong, the timing prices the lock step
+    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
     __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 };
 
 // one k-step into four output tiles, A operands from the ring slot `w` (LDS); the reads of tile T+1 are issued ahead of
@@ -161,7 +165,11 @@ struct HRing {
         if (hs + 2 < chain_end) fetch(hs + 2);
         return lds + (hs & 1) * kHalfQuads;
     }
+#ifdef NVP_ABL_NOBARRIER
+    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
     __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 };
 
 // one k-step (two half-steps of the ring) into four output tiles.  LEAN: one tile's three operand quads live at a time

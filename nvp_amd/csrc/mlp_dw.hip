@@ -23,6 +23,8 @@
 //    the records are summed per pixel chunk into the same partials.
 //
 // Bound: matrix pipe + the operand-split VALU work + ~6 KB/px of HBM reads (219 648 FLOP/px for nvp_s); they add.
+#include <cstdlib>
+#include <initializer_list>
 #include "mlp_b3.h"
 
 #ifndef NVP_DW_B3
@@ -42,6 +44,11 @@ struct DwJob {
     int64_t w_off;        // offset of W[0][col0] inside a partial
     int ld;               // leading dimension of W
     int64_t bias_off;     // >= 0: this job also produces the bias gradient
+    // second B tile of a MERGED job (NB == 2 kernels: the two 128-column halves [h_{k-1} ; z] of one modulator layer share
+    // the dp_k tile in LDS, so dp_k is staged once instead of twice - the dW stage is HBM-bound on its operand streams)
+    const float* bb;
+    int bb_rows, bb_row0, nn_cols;
+    int64_t ww_off;
 };
 
 struct DwArgs {
@@ -70,51 +77,66 @@ constexpr int kTileFloats = 128 * kRowStride;          // 4608 floats = 18 KiB
 __device__ __forceinline__ f32x16 nvp_abl_fake_mfma(float a, float b, f32x16 c) { c[0] = __fmaf_rn(a, b, c[0]); return c; }
 #endif
 
+template <int NB>
 struct Stage {
-    float4 a[4];
+    float4 a[4 / NB];
     float4 b[4];
     float4 b2[4];
 };
 
-template <bool XF>
-__device__ __forceinline__ void load_stage(Stage& s, const DwJob& J, int64_t t, int tid) {
+// 256 * NB threads stage one pixel tile: the A tile is spread over all of them (4 / NB float4 each), thread group g = tid >> 8
+// stages B tile g (4 float4 per thread)
+template <bool XF, int NB>
+__device__ __forceinline__ void load_stage(Stage<NB>& s, const DwJob& J, int64_t t, int tid) {
+    const int g = NB == 2 ? (tid >> 8) : 0, ft = tid & 255;
+    const float* bsrc = g ? J.bb : J.b;
+    const int brows = g ? J.bb_rows : J.b_rows, brow0 = g ? J.bb_row0 : J.b_row0;
     const float4* A4 = reinterpret_cast<const float4*>(J.a) + t * 1024;
-    const float4* B4 = reinterpret_cast<const float4*>(J.b) + (t * (J.b_rows >> 2) + (J.b_row0 >> 2)) * 32;
+    const float4* B4 = reinterpret_cast<const float4*>(bsrc) + (t * (brows >> 2) + (brow0 >> 2)) * 32;
     const float4* Q4 = reinterpret_cast<const float4*>(J.b2) + (t * (J.b_rows >> 2) + (J.b_row0 >> 2)) * 32;
     // rows past the end of the B stream (latent: 116 of 128) must read as zero: clamp the address here and
     // select on the DATA in write_stage - a conditional load would become a branch with a vmcnt(0) wait
     // per element, and a select right here would wait for the prefetch immediately
-    const int nvalid = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32);
+    const int nvalid = min(1024, ((brows - brow0) >> 2) * 32);
 #ifdef NVP_ABL_DW_NOLOAD          // ablation builds only
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { s.a[k] = make_float4(1e-3f, 2e-3f, 3e-3f, (float)t); s.b[k] = make_float4(1e-3f, 2e-3f, 3e-3f, (float)tid); s.b2[k] = s.b[k]; }
+    for (int k = 0; k < 4; ++k) { s.b[k] = make_float4(1e-3f, 2e-3f, 3e-3f, (float)tid); s.b2[k] = s.b[k]; }
+#pragma unroll
+    for (int k = 0; k < 4 / NB; ++k) s.a[k] = make_float4(1e-3f, 2e-3f, 3e-3f, (float)t);
     return;
 #endif
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int f = k * 256 + tid;
-        s.a[k] = A4[f];
-        s.b[k] = B4[min(f, nvalid - 1)];          // zeroed (if past the end) when it is written to LDS
-    }
+    for (int k = 0; k < 4 / NB; ++k) s.a[k] = A4[k * (256 * NB) + tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.b[k] = B4[min(k * 256 + ft, nvalid - 1)];          // zeroed (if past the end) when it is written to LDS
     if (XF && J.mode == 1) {                      // wave-uniform (kernarg) branch: only x_k = sin(q_k) h_k jobs read q_k
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s.b2[k] = Q4[min(k * 256 + tid, nvalid - 1)];
+        for (int k = 0; k < 4; ++k) s.b2[k] = Q4[min(k * 256 + ft, nvalid - 1)];
     }
 }
 
-// `t` is the tile the stage holds (mode 2 needs its temporal steps)
-template <bool XF>
-__device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb, const Stage& s, const DwJob& J,
+// `t` is the tile the stage holds (mode 2 needs its temporal steps); lb = the B tile of this thread's group
+template <bool XF, int NB>
+__device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb0, const Stage<NB>& s, const DwJob& J,
                                             const DwArgs& A, const float* __restrict__ tab, int64_t t, int64_t n, int tid) {
 #ifdef NVP_ABL_DW_NOWRITE         // ablation builds only
     if (t != 0x7fffffff) return;
 #endif
-    const int nvalid = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32);
+    const int g = NB == 2 ? (tid >> 8) : 0, ft = tid & 255;
+    float* __restrict__ lb = lb0 + g * kTileFloats;
+    const int brows = g ? J.bb_rows : J.b_rows, brow0 = g ? J.bb_row0 : J.b_row0;
+    const int nvalid = min(1024, ((brows - brow0) >> 2) * 32);
     float sp = 0.f;
     if (XF && J.mode == 2) sp = A.steps[min(t * 32 + (tid & 31), n - 1)];       // wave-uniform branch; px = f & 31 = tid & 31
 #pragma unroll
+    for (int k = 0; k < 4 / NB; ++k) {
+        const int f = k * (256 * NB) + tid;
+        const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
+        la[o] = s.a[k].x; la[o + kRowStride] = s.a[k].y; la[o + 2 * kRowStride] = s.a[k].z; la[o + 3 * kRowStride] = s.a[k].w;
+    }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int f = k * 256 + tid;
+        const int f = k * 256 + ft;
         const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
         const bool ok = f < nvalid;
         float bv[4] = {s.b[k].x, s.b[k].y, s.b[k].z, s.b[k].w};
@@ -127,7 +149,6 @@ __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[e] = nvp_sin(30.0f * __fmaf_rn(sp, tab[row + e], tab[NVP_H + row + e])) * bv[e];
         }
-        la[o] = s.a[k].x; la[o + kRowStride] = s.a[k].y; la[o + 2 * kRowStride] = s.a[k].z; la[o + 3 * kRowStride] = s.a[k].w;
         lb[o] = ok ? bv[0] : 0.f; lb[o + kRowStride] = ok ? bv[1] : 0.f;
         lb[o + 2 * kRowStride] = ok ? bv[2] : 0.f; lb[o + 3 * kRowStride] = ok ? bv[3] : 0.f;
         __builtin_amdgcn_sched_barrier(0);       // one float4 at a time: keeps the sincos temporaries of 16 values from piling up
@@ -154,12 +175,13 @@ __device__ __forceinline__ void read_frag(float (&f)[16], const float* __restric
 #ifndef NVP_DW_BUFS
 #define NVP_DW_BUFS 2        // LDS tile buffers: 2 = double-buffered (one barrier per tile, 2 workgroups/CU), 1 = single (two barriers, 3-4 workgroups/CU)
 #endif
-template <int KIND>
-__global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // [2 buffers][A tile | B tile]
+template <int KIND, int NB>
+__global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1) ? 3 : 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [2 buffers][A tile | B tile (| second B tile)]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);              // provably wave-uniform
+    const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform
+    const int w = wall & 3, wb = wall >> 2;                              // wave within its 128 x 128 block, B tile of the block
     const int i = lane & 31, h = lane >> 5;
     // XCD-aware block mapping.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
     // observed; only speed depends on it).  The jobs of one pixel chunk share streams (z is read by three
@@ -183,14 +205,15 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
     const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
     const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
     float* part = partials + (int64_t)chunk * A.total;
-    constexpr int BUFS = (KIND == 0 && NVP_DW_BUFS == 1) ? 1 : 2;     // only the plain variant fits 3 waves/SIMD
+    constexpr int BUFS = (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1) ? 1 : 2;     // only the plain variant fits 3 waves/SIMD
+    constexpr int kBufFloats = (1 + NB) * kTileFloats;                // one buffer: A tile + NB B tiles
     constexpr bool XF = KIND != 0;
     const DwJob J = A.job[job];
     const int wr = w >> 1, wc = w & 1;                // regular jobs: wave owns rows 64wr.., columns 64wc..
 
     // SIREN layer 0's weight and bias (mode 2 rebuilds x_0 from them) live in LDS behind the tile buffers:
     // a global load at the point of use would put a vmcnt(0) wait into the pipelined loop
-    float* tab = lds + 4 * kTileFloats;
+    float* tab = lds + 2 * kBufFloats;
     if (XF && tid < NVP_H) { tab[tid] = A.sir0_wp[tid]; tab[NVP_H + tid] = A.sir0_bp[tid]; }
     if (XF) __syncthreads();
 
@@ -200,32 +223,32 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
     float bsum0 = 0.f, bsum1 = 0.f;                   // bias sums
-    const bool want_bias = (J.bias_off >= 0) && (wc == 0);
+    const bool want_bias = (J.bias_off >= 0) && (wc == 0) && (wb == 0);
 
     // Global loads run TWO tiles ahead of the MFMAs (one tile in LDS, the next two in registers st/st2):
     // under load the HBM round trip exceeds one tile's 4096 MFMA cycles.
 #ifndef NVP_DW_DEPTH
 #define NVP_DW_DEPTH 1
 #endif
-    Stage st, st2;
+    Stage<NB> st, st2;
     if (t0 < t1) {
-        load_stage<XF>(st, J, t0, tid);
-        write_stage<XF>(lds, lds + kTileFloats, st, J, A, tab, t0, n, tid);
+        load_stage<XF, NB>(st, J, t0, tid);
+        write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t0, n, tid);
     }
 #if NVP_DW_DEPTH == 2
-    if (t0 + 1 < t1) load_stage<XF>(st, J, t0 + 1, tid);
+    if (t0 + 1 < t1) load_stage<XF, NB>(st, J, t0 + 1, tid);
 #endif
     __syncthreads();
     int cur = 0;
     for (int64_t t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
 #if NVP_DW_DEPTH == 2
-        if (t + 2 < t1) load_stage<XF>(st2, J, t + 2, tid);
+        if (t + 2 < t1) load_stage<XF, NB>(st2, J, t + 2, tid);
 #else
-        if (more) load_stage<XF>(st, J, t + 1, tid);
+        if (more) load_stage<XF, NB>(st, J, t + 1, tid);
 #endif
-        const float* la = lds + (BUFS == 2 ? cur : 0) * 2 * kTileFloats;
-        const float* lb = la + kTileFloats;
+        const float* la = lds + (BUFS == 2 ? cur : 0) * kBufFloats;
+        const float* lb = la + (1 + wb) * kTileFloats;
 #if NVP_DW_B3
         {
             // bf16 x 3 split MFMA (mlp_b3.h): a lane's 16 pixels of a row are two k-steps of 8 (the SAME pixels on both
@@ -300,9 +323,9 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
 #endif
         if (BUFS == 1) {
             __syncthreads();                        // everyone finished reading the single buffer
-            if (more) write_stage<XF>(lds, lds + kTileFloats, st, J, A, tab, t + 1, n, tid);
+            if (more) write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t + 1, n, tid);
         } else {
-            if (more) write_stage<XF>(lds + (cur ^ 1) * 2 * kTileFloats, lds + (cur ^ 1) * 2 * kTileFloats + kTileFloats, st, J, A, tab, t + 1, n, tid);
+            if (more) write_stage<XF, NB>(lds + (cur ^ 1) * kBufFloats, lds + (cur ^ 1) * kBufFloats + kTileFloats, st, J, A, tab, t + 1, n, tid);
         }
 #if NVP_DW_DEPTH == 2
         st = st2;
@@ -313,16 +336,18 @@ __global__ __launch_bounds__(256, (KIND == 0 && NVP_DW_BUFS == 1) ? 3 : 2) void 
 
     {
         // D[row = out][col = in]: lane holds column i of each tile, rows 8g+4h+e
+        const int ncols = wb ? J.nn_cols : J.n_cols;
+        const int64_t woff = wb ? J.ww_off : J.w_off;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int col = 64 * wc + 32 * c + i;
-            if (col < J.n_cols) {
+            if (col < ncols) {
 #pragma unroll
                 for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = 64 * wr + 32 * r2 + nvp_frag_row(r, h);
-                        part[J.w_off + (int64_t)row * J.ld + col] = acc[r2][c][r];
+                        part[woff + (int64_t)row * J.ld + col] = acc[r2][c][r];
                     }
             }
         }
@@ -405,52 +430,59 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
     if (rows > 256) return NVP_ERR_UNSUPPORTED;
 
-    DwArgs A;
-    int nj = 0;
+    // NVP_DW_MERGE=1 (environment, read once): the two 128-column blocks [h_{k-1} | z] of modulator layers 1 and 2 become ONE
+    // 512-thread job each, so dp_1 / dp_2 are staged once instead of twice (-14 % operand bytes).  Bit-identical; measured
+    // SLOWER in the step (2.225 vs 2.152 ms): one 8-wave workgroup with 108 KiB of LDS per CU loses more than the saved reads
+    // (which the XCD-local L2 partly served anyway) give back.  OFF by default; kept as the A/B evidence.
+    static const bool merge_on = [] { const char* e = getenv("NVP_DW_MERGE"); return e && e[0] == '1'; }();
+    const bool merge = merge_on && d <= 128;          // one latent column block: [h ; z] = exactly two B tiles
+    DwArgs P0, P2, P1;                                // plain single-tile jobs, merged two-tile jobs, transform jobs
+    int n0 = 0, n2 = 0, n1 = 0;
+    auto plain = [&](DwJob& J, int k, const float* b, int b_rows, int b_row0, int n_cols, int64_t w_off, int ld, int64_t bias_off) {
+        J.a = dy + (int64_t)k * act; J.b = b; J.b2 = b; J.mode = 0; J.b_rows = b_rows; J.b_row0 = b_row0;
+        J.n_cols = n_cols; J.w_off = w_off; J.ld = ld; J.bias_off = bias_off;
+        J.bb = b; J.bb_rows = b_rows; J.bb_row0 = b_row0; J.nn_cols = 0; J.ww_off = w_off;
+    };
     // modulator layers: A = dp_k; B = [h_{k-1} ; z]
     for (int k = 0; k < 3; ++k) {
         const int ld = (k == 0) ? d : NVP_H + d;
+        if (k > 0 && merge) {
+            // one job: dp_k x [h_{k-1} | z]: the dp_k tile is staged ONCE for both 128-column halves
+            DwJob& J = P2.job[n2++];
+            plain(J, k, saved + (int64_t)(k - 1) * act, NVP_H, 0, NVP_H, P.mod_w[k], ld, P.mod_b[k]);
+            J.bb = zt; J.bb_rows = rows; J.bb_row0 = 0; J.nn_cols = d; J.ww_off = P.mod_w[k] + NVP_H;
+            continue;
+        }
         bool bias_done = false;
         if (k > 0) {
-            DwJob& J = A.job[nj++];
-            J.a = dy + (int64_t)k * act; J.b = saved + (int64_t)(k - 1) * act; J.b2 = J.b; J.mode = 0; J.b_rows = NVP_H; J.b_row0 = 0;
-            J.n_cols = NVP_H; J.w_off = P.mod_w[k]; J.ld = ld; J.bias_off = P.mod_b[k];
+            plain(P0.job[n0++], k, saved + (int64_t)(k - 1) * act, NVP_H, 0, NVP_H, P.mod_w[k], ld, P.mod_b[k]);
             bias_done = true;
         }
         for (int c0 = 0; c0 < d; c0 += 128) {
-            DwJob& J = A.job[nj++];
-            J.a = dy + (int64_t)k * act; J.b = zt; J.b2 = zt; J.mode = 0; J.b_rows = rows; J.b_row0 = c0;
-            J.n_cols = (d - c0 < 128) ? d - c0 : 128;
-            J.w_off = P.mod_w[k] + (k == 0 ? 0 : NVP_H) + c0; J.ld = ld;
-            J.bias_off = bias_done ? -1 : P.mod_b[k];
+            plain(P0.job[n0++], k, zt, rows, c0, (d - c0 < 128) ? d - c0 : 128, P.mod_w[k] + (k == 0 ? 0 : NVP_H) + c0, ld,
+                  bias_done ? -1 : P.mod_b[k]);
             bias_done = true;
         }
     }
     // SIREN layers 1, 2: A = dq_k; B = x_{k-1} = sin(q_{k-1}) h_{k-1}, rebuilt from the saved h (and q) streams
     for (int k = 1; k <= 2; ++k) {
-        DwJob& J = A.job[nj++];
-        J.a = dy + (int64_t)(3 + k) * act; J.b = saved + (int64_t)(k - 1) * act; J.b_rows = NVP_H; J.b_row0 = 0;
-        if (k == 1) { J.b2 = J.b; J.mode = 2; } else { J.b2 = saved + 3 * act; J.mode = 1; }
-        J.n_cols = NVP_H; J.w_off = P.sir_w[k]; J.ld = NVP_H; J.bias_off = P.sir_b[k];
+        DwJob& J = P1.job[n1++];
+        plain(J, 3 + k, saved + (int64_t)(k - 1) * act, NVP_H, 0, NVP_H, P.sir_w[k], NVP_H, P.sir_b[k]);
+        if (k == 1) { J.mode = 2; } else { J.b2 = saved + 3 * act; J.mode = 1; }
     }
-    A.n_jobs = nj;
-    A.steps = steps; A.sir0_wp = p->sir_w[0]; A.sir0_bp = p->sir_b[0];
-    A.total = P.total;
+    for (DwArgs* Q : {&P0, &P2, &P1}) { Q->steps = steps; Q->sir0_wp = p->sir_w[0]; Q->sir0_bp = p->sir_b[0]; Q->total = P.total; }
+    P0.n_jobs = n0; P2.n_jobs = n2; P1.n_jobs = n1;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
-    // two GEMM launches: plain jobs (modulator layers), transform jobs (SIREN layers 1-2); plus the record sums
-    DwArgs P0 = A, P1 = A;
-    int n0 = 0, n1 = 0;
-    for (int jx = 0; jx < A.n_jobs; ++jx) {
-        if (A.job[jx].mode == 0) P0.job[n0++] = A.job[jx];
-        else P1.job[n1++] = A.job[jx];
-    }
-    P0.n_jobs = n0; P1.n_jobs = n1;
+    // GEMM launches: plain jobs, merged jobs (512 threads, three LDS tiles per buffer), transform jobs; plus the record sums
     const size_t lds_bytes = (2 * 2 * kTileFloats + 2 * NVP_H) * sizeof(float);
     const size_t lds_bytes0 = (NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats * sizeof(float);
-    hipLaunchKernelGGL(mlp_dw_kernel<0>, dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    const size_t lds_bytes2 = 2 * 3 * kTileFloats * sizeof(float);          // 108 KiB: one 8-wave workgroup per CU
+    if (n0) hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(mlp_dw_kernel<1>, dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    if (n2) hipLaunchKernelGGL((mlp_dw_kernel<0, 2>), dim3(n_chunks * n2), dim3(512), lds_bytes2, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    NVP_LAUNCH_CHECK();
+    hipLaunchKernelGGL((mlp_dw_kernel<1, 1>), dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     hipLaunchKernelGGL(dw_records_kernel, dim3(n_chunks, (kRecFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy + 3 * act, partials,
                        ntiles, tiles_per_chunk, P.total, P.last_w, P.last_b, P.sir_w[0], P.sir_b[0]);
