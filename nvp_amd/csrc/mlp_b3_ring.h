@@ -55,10 +55,71 @@ struct WRing {
     // fence makes hipcc wait for vmcnt(0) - i.e. for the weight fetch issued two steps ahead and for every stream store in
     // flight - at every k-step.  Only LDS traffic has to be settled here.
 #ifdef NVP_ABL_NOBARRIER         // ablation builds only: results are wrong, the timing prices the lock step
-    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ void end(int) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #else
-    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+    __device__ __forceinline__ void end(int) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
+};
+
+// ---- flag-synchronised ring (NVP_RING_FLAGS) ---------------------------------------------------------------------------
+// The barrier ring lock-steps the workgroup: every k-step costs the slowest of four waves, each of which shares its SIMD with a
+// wave of the other workgroup (measured: removing the barriers - wrong results - takes the forward from 1.93 to 1.55 ms).
+// Here the slots carry two LDS counters instead: `filled` (+1 by each of the four producers after its quarter is written) and
+// `drained` (+1 by each consumer after its reads).  A consumer polls filled[slot] >= 4 (generation + 1) before reading, a
+// producer polls drained[slot] >= 4 generation before overwriting; with R slots and a publish distance of D = R - 2 steps the
+// waves may drift two k-steps apart before anyone waits.  LDS executes one wave's operations in order, so a counter update
+// issued after the data accesses is seen after them; the signalling and polling are inline asm so that hipcc neither
+// reorders memory operations across them nor attaches a vmcnt(0) to them.
+template <int R>
+struct WRingF {
+    static constexpr int D = R - 2;
+    u32x4* lds;                // R slots of kRingQuads, followed by 2 R counters
+    const u32x4* g;
+    int total;
+    int wv, lane;
+    u32x4 sg[3];
+
+    __device__ __forceinline__ unsigned cnt_addr(int which, int slot) const {      // LDS byte address of a counter
+        return (unsigned)reinterpret_cast<uintptr_t>(lds + R * kRingQuads) + 4u * (unsigned)(which * R + slot);
+    }
+    __device__ __forceinline__ void wait_ge(unsigned addr, unsigned target) const {
+        unsigned v;
+        do {
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        } while (__builtin_amdgcn_readfirstlane(v) < target);
+    }
+    __device__ __forceinline__ void signal(unsigned addr) const {
+        if (lane == 0) { const unsigned one = 1u; asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(one) : "memory"); }
+        else asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void fetch(int s) {
+        const u32x4* p = g + NVP_WSTRIDE((int64_t)s * kRingQuads) + (3 * wv) * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
+    }
+    __device__ __forceinline__ void publish(int p) {
+        const int slot = p % R;
+        wait_ge(cnt_addr(1, slot), 4u * (unsigned)(p / R));            // every consumer is done with the slot's previous step
+        u32x4* d = lds + slot * kRingQuads + (3 * wv) * 64;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
+        signal(cnt_addr(0, slot));
+    }
+    __device__ __forceinline__ void prologue() {
+        unsigned* c = reinterpret_cast<unsigned*>(lds + R * kRingQuads);
+        if (wv == 0 && lane < 2 * R) c[lane] = 0u;
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < D && i < total; ++i) { fetch(i); publish(i); }
+        if (D < total) fetch(D);
+    }
+    __device__ __forceinline__ const u32x4* begin(int s) {
+        if (s + D < total) publish(s + D);
+        if (s + D + 1 < total) fetch(s + D + 1);
+        wait_ge(cnt_addr(0, s % R), 4u * (unsigned)(s / R + 1));       // all four quarters of step s are in the slot
+        return lds + (s % R) * kRingQuads;
+    }
+    __device__ __forceinline__ void end(int s) { signal(cnt_addr(1, s % R)); }
 };
 
 // one k-step into four output tiles, A operands from the ring slot `w` (LDS); the reads of tile T+1 are issued ahead of
@@ -101,8 +162,8 @@ __device__ __forceinline__ void bias_b3_ring(f32x16 (&acc)[4], const u32x4* __re
 // 8 k-steps over the previous layer's D registers; `s` is the running k-step index of the kernel.  `pre` (optional) runs
 // at the start of the LAST k-step: the caller prefetches what the following chain needs (its first latent rows) there,
 // one k-step ahead, instead of keeping those registers alive through the whole chain.
-template <typename Pre>
-__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], WRing& R, int& s, int lane, Pre pre) {
+template <typename Ring, typename Pre>
+__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], Ring& R, int& s, int lane, Pre pre) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const u32x4* w = R.begin(s);
@@ -113,12 +174,13 @@ __device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (
         u32x4 bh, bm, bl;
         split8(x, bh, bm, bl);
         step_b3_ring(acc, w, bh, bm, bl, lane);
-        R.end();
+        R.end(s);
         ++s;
     }
 }
 
-__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], WRing& R, int& s, int lane) {
+template <typename Ring>
+__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], Ring& R, int& s, int lane) {
     chain_h_b3_ring(acc, hin, R, s, lane, [] {});
 }
 

@@ -6,9 +6,20 @@
 // lane and step - which frees the 64 KiB of LDS the per-wave latent tiles used, so two workgroups still share a CU).
 #include "mlp_b3_ring.h"
 
+#ifndef NVP_RING_FLAGS
+#define NVP_RING_FLAGS 0        // 1: flag-synchronised ring of kRingSlots slots (WRingF) instead of the two-slot barrier ring
+#endif
+
 namespace {
 
 constexpr int kWaves = 4;
+#if NVP_RING_FLAGS
+constexpr int kRingSlots = 4;
+typedef WRingF<kRingSlots> Ring;
+#else
+constexpr int kRingSlots = 2;
+typedef WRing Ring;
+#endif
 
 // B operands of latent k-step s (rows 16 s + 8 h .. + 7 of pixel j), fetched one step ahead
 struct ZFeed {
@@ -25,7 +36,7 @@ struct ZFeed {
 };
 
 // `ns` latent k-steps; Z holds step 0's rows on entry (fetched one k-step earlier by the caller)
-__device__ __forceinline__ void chain_z_b3_ring(f32x16 (&acc)[4], ZFeed& Z, int ns, WRing& R, int& s, int lane) {
+__device__ __forceinline__ void chain_z_b3_ring(f32x16 (&acc)[4], ZFeed& Z, int ns, Ring& R, int& s, int lane) {
 #pragma unroll 1
     for (int u = 0; u < ns; ++u) {
         const u32x4* w = R.begin(s);
@@ -34,7 +45,7 @@ __device__ __forceinline__ void chain_z_b3_ring(f32x16 (&acc)[4], ZFeed& Z, int 
         u32x4 bh, bm, bl;
         split8(x, bh, bm, bl);
         step_b3_ring(acc, w, bh, bm, bl, lane);
-        R.end();
+        R.end(s);
         ++s;
     }
 }
@@ -44,7 +55,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
                                                                      nvp_mlp_params p, const unsigned* __restrict__ packed,
                                                                      float* __restrict__ rgb, float* __restrict__ saved,
                                                                      int64_t n, int64_t ntiles, int d) {
-    __shared__ __attribute__((aligned(16))) u32x4 ring[2 * kRingQuads];          // 24 KiB
+    __shared__ __attribute__((aligned(16))) u32x4 ring[kRingSlots * kRingQuads + 4];          // 24 KiB (+ the flag ring's counters)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
     float* sv = (SAVE && active) ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
 
-    WRing R;
+    Ring R;
     R.lds = ring; R.g = reinterpret_cast<const u32x4*>(packed); R.total = (int)(L.off[5] / kB3StepU32); R.wv = wv; R.lane = lane;
     ZFeed Z;
     Z.zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4; Z.rg_end = nvp_rows4(d) / 4; Z.j = j; Z.h = h;
@@ -74,7 +85,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
     {
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
-        { const u32x4* w = R.begin(ks); bias_b3_ring(hm, w, lane); R.end(); ++ks; }
+        { const u32x4* w = R.begin(ks); bias_b3_ring(hm, w, lane); R.end(ks); ++ks; }
         chain_z_b3_ring(hm, Z, L.zs, R, ks, lane);
         lrelu4(hm);
 #pragma unroll
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
         {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, lane); R.end(); ++ks; }
+            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, lane); R.end(ks); ++ks; }
             chain_h_b3_ring(acc, hm, R, ks, lane, [&] { Z.fetch(0); });
             chain_z_b3_ring(acc, Z, L.zs, R, ks, lane);
             lrelu4(acc);
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
         {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, lane); R.end(); ++ks; }
+            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, lane); R.end(ks); ++ks; }
             chain_h_b3_ring(acc, x, R, ks, lane);
             if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll
