@@ -7,18 +7,22 @@
 
 A "step" is one full optimisation iteration of the reference's loop (training.py:42-76) over
 one batch of N = 1 245 184 synthetic (t, x, y) samples of a 1920x1080x600 video
-(BASELINE.json configs[1], config_nvp_s): on-device sampler + gt gather, NVP forward
-(grid gathers -> MFMA MLP), fused MSE, backward (MFMA dX chain, split-K dW GEMMs, grid
-scatter-add), for N>1 ONE all-reduce of the flat 543 MB gradient over RCCL, AdamW + cosine.
-Nothing is skipped inside the timed region.  Each rank keeps the full per-GPU batch (weak
-scaling); value = world * N pixels / max-over-ranks step time.
+(BASELINE.json configs[1], config_nvp_s; --config l / 4k: configs[2] / configs[3]): on-device
+sampler + gt gather, NVP forward (grid gathers -> MFMA MLP), fused MSE, backward (MFMA dX chain,
+split-K dW GEMMs, grid scatter-add), for N>1 the exchange of the flat 543 MB gradient over RCCL
+(--dp: reduce-scatter + sharded AdamW + parameter all-gather, its one-hop all_to_all form, or
+chunked all-reduce + full AdamW; "auto" measures the three on untimed steps and keeps the fastest),
+AdamW + cosine.  Nothing is skipped inside the timed region.  Each rank keeps the full per-GPU
+batch (weak scaling); value = world * N pixels / max-over-ranks step time.
 
 Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   "roofline":     dominant kernel's algorithmic FLOP (or bytes) per launch / its HIP-event
                   duration inside the timed region, vs the gfx950 peak;
   "cpu_baseline": the oracle (pure-PyTorch CPU port of the reference path) timed on this
                   host's cores on a bounded sample of the same workload (N=1 run only);
-  "kernels":      mean ms of every hot-path kernel stage, "fwd_bwd_mpx_s": hot path only.
+  "kernels_ms":   mean ms of every hot-path kernel stage, "fwd_bwd_mpx_s": hot path only;
+  "dp" (N>1):     the exchange scheme, the autotune timings and, per rank, the HIP-event time between
+                  the end of backward and the end of the optimizer (exposed exchange + AdamW share).
 """
 import argparse
 import json
