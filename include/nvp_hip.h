@@ -43,6 +43,8 @@ extern "C" {
 #define NVP_ERR_UNSUPPORTED (-2)
 
 /* nvp_encode_fwd / nvp_encode_bwd flags */
+#define NVP_DZ_PLANES_READY 2      /* nvp_encode_bwd: the xy / yt planes' latent gradients already sit level-major in the workspace
+                                      (written by nvp_mlp_bwd_dx through nvp_encode_bwd_prepare's pointers); needs NVP_COORDS_SORTED_BY_Y */
 #define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: the scatter skips one radix sort,
                                       the gather stages the xy / yt grid rows of a pixel run in LDS */
 
@@ -143,6 +145,18 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
  * permutation-invariant, so a sampler may deliver its batch that way; results are identical). */
 int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
                                        const nvp_levels* lv_xt, const nvp_sparse_shape* sh);
+/* Hand-over of the latent gradient in the scatter's own layout (y-sorted batches only).  For a batch sorted by y the scatter's
+ * sorted order of the xy and yt planes IS the batch order, so its permute pass would merely transpose those planes' columns of
+ * dz into level-major [level][pixel][F] arrays.  nvp_encode_bwd_prepare zeroes the max|dz| slots on `stream` and returns device
+ * pointers into `workspace`; pass them to nvp_mlp_bwd_dx (which then writes those two planes there instead of into dz_rows) and
+ * set NVP_DZ_PLANES_READY | NVP_COORDS_SORTED_BY_Y for nvp_encode_bwd on the SAME workspace.  Gradients are bit-identical. */
+typedef struct nvp_scatter_lm {
+    float* dzs[2];          /* xy, yt: [n_levels][n][F] */
+    uint32_t* dzmax;        /* 256 slots, bit patterns of max|dz| */
+} nvp_scatter_lm;
+int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                           const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, nvp_scatter_lm* out, void* stream);
+int32_t nvp_dz_lm_supported(int32_t latent_dim);   /* does nvp_mlp_bwd_dx honour `lm` for this latent width in this build? */
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
@@ -181,7 +195,8 @@ int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_params* p, co
  *         into `g` (overwritten). */
 int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved,
                    const nvp_mlp_params* p, const float* packed_bwd,
-                   float* dy, float* dz_rows, int64_t n, int32_t latent_dim, void* stream);
+                   float* dy, float* dz_rows, const nvp_scatter_lm* lm /* NULL or nvp_encode_bwd_prepare's output */,
+                   int64_t n, int32_t latent_dim, void* stream);
 int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
                    const float* dy, const nvp_mlp_params* p, float* partials, int32_t n_chunks,
                    const nvp_mlp_grads* g, int64_t n, int32_t latent_dim, void* stream);

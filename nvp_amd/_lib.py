@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("NVP_HIP_LIB") or os.path.join(_HERE, "csrc", "libnvp_
 
 NVP_MAX_LEVELS = 16
 COORDS_SORTED_BY_Y = 1
+DZ_PLANES_READY = 2
 GRID_POS_FMA, GRID_INTERP_FMA, GRID_CLAMP = 1, 2, 4      # nvp_levels.flags (include/nvp_hip.h)
 HIDDEN = 128
 TILE = 32
@@ -51,6 +52,11 @@ class MlpParams(C.Structure):
 MlpGrads = MlpParams  # identical layout (const-ness only differs in C)
 
 
+class ScatterLm(C.Structure):
+    """struct nvp_scatter_lm - device pointers into the scatter workspace (nvp_encode_bwd_prepare)."""
+    _fields_ = [("dzs", C.c_void_p * 2), ("dzmax", C.c_void_p)]
+
+
 class AdamwSeg(C.Structure):
     """struct nvp_adamw_seg - one tensor of an AdamW step."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64)]
@@ -75,7 +81,10 @@ SIGNATURES = {
     "nvp_mlp_pack_fwd": [C.POINTER(MlpParams), _p, _i32, _vp],
     "nvp_mlp_pack_bwd": [C.POINTER(MlpParams), _p, _i32, _vp],
     "nvp_mlp_fwd": [_p, _p, C.POINTER(MlpParams), _p, _p, _p, _i64, _i32, _vp],
-    "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _i64, _i32, _vp],
+    "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(ScatterLm), _i64, _i32, _vp],
+    "nvp_encode_bwd_prepare": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64,
+                               C.POINTER(ScatterLm), _vp],
+    "nvp_dz_lm_supported": [_i32],
     "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
     "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
@@ -90,7 +99,7 @@ SIGNATURES = {
 _RESTYPES = {
     "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64,
     "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
-    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32,
+    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32,
 }
 
 _lib: Optional[C.CDLL] = None

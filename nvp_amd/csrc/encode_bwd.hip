@@ -152,13 +152,17 @@ int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape*
 }
 
 // ------------------------------------------------------------------------------------------
+// cs_xy / cs_yt (optional): the (dim0, dim1) coordinate pairs of the xy and yt planes in batch order - what the permute pass
+// would write for them when their sorted order is the identity (NVP_DZ_PLANES_READY)
 __global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ coords, float* __restrict__ ky, float* __restrict__ kx,
-                                                   int* __restrict__ iota, int64_t n) {
+                                                   int* __restrict__ iota, float2* __restrict__ cs_xy, float2* __restrict__ cs_yt, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    kx[i] = coords[i * 3 + 1];
-    ky[i] = coords[i * 3 + 2];
+    const float t = coords[i * 3], x = coords[i * 3 + 1], y = coords[i * 3 + 2];
+    kx[i] = x;
+    ky[i] = y;
     iota[i] = (int)i;
+    if (cs_xy) { cs_xy[i] = make_float2(x, y); cs_yt[i] = make_float2(t, y); }
 }
 
 struct PermArgs {
@@ -169,6 +173,7 @@ struct PermArgs {
     int c0[3], c1[3];         // coordinate columns feeding (dim0, dim1) of each plane
     int scol0, scols;         // the sparse grid's latent-gradient columns (only their max|.| is taken here)
     unsigned* sdzmax;
+    int plane0;               // first plane this launch handles (2 when the y-sorted planes arrive level-major already)
 };
 
 // A workgroup rewrites kPermPix<F> consecutive sorted positions of one plane.  A pixel's segment of this plane in the
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
     constexpr int NV = PermCfg<F>::NV, PIX = PermCfg<F>::PIX, STRIDE = PermCfg<F>::STRIDE;
     constexpr int PPP = 256 / NV;                      // pixels per pass
     extern __shared__ float tile[];                    // [PIX][STRIDE]
-    const int plane = blockIdx.y;
+    const int plane = blockIdx.y + A.plane0;
     const int64_t p0 = (int64_t)blockIdx.x * PIX;
     const int t = threadIdx.x;
     const int nl = A.nlev[plane];
@@ -515,17 +520,21 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     float* ky = (float*)(ws + W.keys_in[0]);
     float* kx = (float*)(ws + W.keys_in[1]);
     int* iota = (int*)(ws + W.iota);
-    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota, n);
-    size_t tmp = W.sort_tmp_bytes;
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
+    const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;        // xy / yt latent gradients already level-major in ws
+    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
+                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, n);
+    size_t tmp = W.sort_tmp_bytes;
     for (int k = 0; k < 2; ++k) {
         if (k == 0 && y_sorted) continue;          // the batch already arrives in ascending y: identity order
         hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[k]), (float*)(ws + W.keys_out[k]),
                                                  (const int*)iota, (int*)(ws + W.order[k]), (size_t)n, 0, 32, s);
         if (e != hipSuccess) return (int)e;
     }
-    hipError_t me = hipMemsetAsync(ws + W.dzmax, 0, kMaxSlots * 4, s);
-    if (me != hipSuccess) return (int)me;
+    if (!planes_ready) {          // otherwise nvp_encode_bwd_prepare zeroed the slots before the chain kernel fed them
+        hipError_t me = hipMemsetAsync(ws + W.dzmax, 0, kMaxSlots * 4, s);
+        if (me != hipSuccess) return (int)me;
+    }
 
     // planes in latent order: xy <- (x, y) sorted by y ; yt <- (t, y) sorted by y ; xt <- (t, x) sorted by x
     PermArgs PA;
@@ -545,7 +554,8 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         if (me2 != hipSuccess) return (int)me2;
     }
     if (PA.scols > 16 * F) return NVP_ERR_UNSUPPORTED;         // the sparse columns are scanned by the plane's own lanes
-    hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + PermCfg<F>::PIX - 1) / PermCfg<F>::PIX), 3), dim3(256),
+    PA.plane0 = planes_ready ? 2 : 0;
+    hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + PermCfg<F>::PIX - 1) / PermCfg<F>::PIX), 3 - PA.plane0), dim3(256),
                        (size_t)PermCfg<F>::PIX * PermCfg<F>::STRIDE * sizeof(float), s, coords, dz, dz_stride, PA, (unsigned*)(ws + W.dzmax), n);
 
     RowArgs RA;
@@ -626,6 +636,25 @@ int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const
     Ws W;
     if (carve(W, P, lv, sh, n)) return NVP_ERR_BADARG;
     return (int64_t)W.total;
+}
+
+int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                           const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, nvp_scatter_lm* out, void* stream) {
+    if (n < 1 || !levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh || !workspace || !out) return NVP_ERR_BADARG;
+    const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
+    Plan P;
+    make_plan(P, lv, n);
+    Ws W;
+    int rc = carve(W, P, lv, sh, n);
+    if (rc) return rc;
+    if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
+    char* ws = (char*)workspace;
+    hipError_t e = hipMemsetAsync(ws + W.dzmax, 0, kMaxSlots * 4, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    out->dzs[0] = (float*)(ws + W.dzs[0]);
+    out->dzs[1] = (float*)(ws + W.dzs[1]);
+    out->dzmax = (uint32_t*)(ws + W.dzmax);
+    return 0;
 }
 
 // dz: row-major latent gradient [>= n][dz_stride] (columns xy | yt | xt | sparse).

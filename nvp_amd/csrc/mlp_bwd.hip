@@ -333,20 +333,33 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_kernel(const float*
 }  // namespace
 
 int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                           const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream);      // mlp_bwd_b3r.hip
+                           const float* packed_bwd, float* dy, float* dz_rows, NvpDzLm lm, int64_t n, int32_t d, void* stream);      // mlp_bwd_b3r.hip
 int nvp_mlp_bwd_b3_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                          const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream);   // mlp_bwd_b3.hip
+                          const float* packed_bwd, float* dy, float* dz_rows, NvpDzLm lm, int64_t n, int32_t d, void* stream);   // mlp_bwd_b3.hip
+
+// 1 when nvp_mlp_bwd_dx honours `lm` for this latent width (bf16x3 chain kernels, F = 2 or 4): the host only hands the scatter's
+// level-major buffers over (and tells nvp_encode_bwd so) when this says yes
+extern "C" int32_t nvp_dz_lm_supported(int32_t d) {
+    const int F = d / 57;
+    return (NVP_BWD_B3 && nvp_bwd_b3_ok(d) && d == 57 * F && (F == 2 || F == 4)) ? 1 : 0;
+}
 
 extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                              const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
+                              const float* packed_bwd, float* dy, float* dz_rows, const nvp_scatter_lm* lm_host,
+                              int64_t n, int32_t d, void* stream) {
     if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
+    NvpDzLm lm = {{nullptr, nullptr}, nullptr};
+    if (lm_host && lm_host->dzs[0]) {
+        if (!nvp_dz_lm_supported(d) || !lm_host->dzs[1] || !lm_host->dzmax) return NVP_ERR_UNSUPPORTED;
+        lm.dzs[0] = lm_host->dzs[0]; lm.dzs[1] = lm_host->dzs[1]; lm.dzmax = lm_host->dzmax;
+    }
     if (n == 0) return 0;
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
         // NVP_MLP_RING_BWD=0 (environment, read once): per-wave weight streaming (mlp_bwd_b3.hip) instead of the workgroup-shared LDS
         // weight ring (mlp_bwd_b3r.hip, default for fused-dz latents).  Bit-identical results; measured 2.28-2.35 ms vs 2.43-2.46 ms.
         static const bool ring = [] { const char* e = getenv("NVP_MLP_RING_BWD"); return !(e && e[0] == '0'); }();
-        if (ring && nvp_bwd_b3_zt(d) == 4) return nvp_mlp_bwd_b3r_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
-        return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, n, d, stream);
+        if (ring && nvp_bwd_b3_zt(d) == 4) return nvp_mlp_bwd_b3r_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, lm, n, d, stream);
+        return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, lm, n, d, stream);
     }
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;

@@ -26,7 +26,7 @@ template <bool FUSE_DZ>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const unsigned* __restrict__ packed,
-                                                                    float* __restrict__ dy, float* __restrict__ dzr,
+                                                                    float* __restrict__ dy, float* __restrict__ dzr, NvpDzLm lm,
                                                                     int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform
@@ -287,14 +287,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
             chain_h_b3<NVP_BWD_B3_PF>(dzacc, dh, wp + nvp_bwd_b3_off(4, 4) / 4, lane);     // stream 4 (z0^T)
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
+            const int F = d / 57;                       // latent = 57 F columns (modules.py:42-45)
+            unsigned mx = 0u;
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int base = 32 * T + 8 * g + 4 * h;
-                    if (base < stride)
+                    if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3], mx))
                         *reinterpret_cast<float4*>(o + base) = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
                 }
+            nvp_dz_lm_finish(lm, mx, tile, lane);
         }
     }
 }
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
 //   dz = W2[:,128:]^T dp2 + W1[:,128:]^T dp1 + W0^T dp0, reading the three dp streams the chain kernel just wrote.
 template <int ZT>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3_kernel(const float* __restrict__ dy, const unsigned* __restrict__ packed,
-                                                                       float* __restrict__ dzr, int64_t ntiles, int d) {
+                                                                       float* __restrict__ dzr, NvpDzLm lm, int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile >= ntiles) return;
@@ -335,30 +338,34 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3_kernel(const flo
     }
     const int stride = nvp_dz_stride_dev(d);
     float* o = dzr + (tile * 32 + j) * stride;
+    const int F = d / 57;
+    const int64_t px = tile * 32 + j;
+    unsigned mx = 0u;
 #pragma unroll
     for (int T = 0; T < ZT; ++T)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int base = 32 * T + 8 * g + 4 * h;
-            if (base < stride)
+            if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3], mx))
                 *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
         }
+    nvp_dz_lm_finish(lm, mx, tile, lane);
 }
 
 }  // namespace
 
 // called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on and the latent has <= 128 rows
 int nvp_mlp_bwd_b3_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                          const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
+                          const float* packed_bwd, float* dy, float* dz_rows, NvpDzLm lm, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     const size_t lds = kWaves * kRecTileFloats * sizeof(float);
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_bwd);
     if (nvp_bwd_b3_zt(d) == 4) {
-        hipLaunchKernelGGL(mlp_bwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, lm, n, ntiles, d);
     } else {
-        hipLaunchKernelGGL(mlp_bwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, n, ntiles, d);
-        hipLaunchKernelGGL(mlp_bwd_dz_b3_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, pk, dz_rows, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, NvpDzLm{{nullptr, nullptr}, nullptr}, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_dz_b3_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, pk, dz_rows, lm, n, ntiles, d);
     }
     NVP_LAUNCH_CHECK();
     return 0;

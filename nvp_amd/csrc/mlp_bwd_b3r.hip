@@ -17,7 +17,7 @@ __device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ 
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const unsigned* __restrict__ packed,
-                                                                    float* __restrict__ dy, float* __restrict__ dzr,
+                                                                    float* __restrict__ dy, float* __restrict__ dzr, NvpDzLm lm,
                                                                     int64_t n, int64_t ntiles, int d) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -250,14 +250,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
             chain_h_b3_hring(dzacc, dh, R, hs, lane);     // stream 4 (z0^T)
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
+            const int F = d / 57;                       // latent = 57 F columns (modules.py:42-45)
+            unsigned mx = 0u;
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int base = 32 * T + 8 * g + 4 * h;
-                    if (base < stride)
+                    if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3], mx))
                         *reinterpret_cast<float4*>(o + base) = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
                 }
+            nvp_dz_lm_finish(lm, mx, tile, lane);
         }
     }
 }
@@ -267,12 +270,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
 
 // called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on, the latent has <= 128 rows and NVP_MLP_RING_BWD != 0
 int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
-                           const float* packed_bwd, float* dy, float* dz_rows, int64_t n, int32_t d, void* stream) {
+                           const float* packed_bwd, float* dy, float* dz_rows, NvpDzLm lm, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     const size_t lds = kWaves * kRecTileFloats * sizeof(float) + 2 * kHalfQuads * sizeof(u32x4);        // 67 584 + 12 288 B: two workgroups per CU
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_bwd);
-    hipLaunchKernelGGL(mlp_bwd_b3r_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, n, ntiles, d);
+    hipLaunchKernelGGL(mlp_bwd_b3r_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, lm, n, ntiles, d);
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -254,3 +254,43 @@ __device__ __forceinline__ void store_ptm16(float* __restrict__ tile_base, const
     for (int g = 0; g < 4; ++g)
         nvp_stream_store(&(b4 + (8 * T + 2 * g) * 32)[(unsigned)lane], v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
+
+
+// ---- latent gradient handed to the scatter in ITS layout (encode_bwd.hip) ---------------------------------------------------
+// For a y-sorted batch the scatter's sorted order of the xy and yt planes is the batch order itself, so its `permute` pass would
+// only transpose those planes' columns of the row-major latent gradient into level-major [level][pixel][F] arrays.  The chain
+// kernels write them there directly (and feed max|dz| for the fixed-point scale), `permute` then only handles the xt plane:
+// -2/3 of that pass and of its traffic.  Device pointers into the scatter workspace (nvp_encode_bwd_prepare); dzs[0] == nullptr: off.
+struct NvpDzLm {
+    float* dzs[2];
+    unsigned* dzmax;
+};
+
+// one float4 = latent rows base..base+3 of pixel px.  Returns true when the rows belong to plane 0 / 1 and were stored level-major.
+__device__ __forceinline__ bool nvp_dz_store_lm(const NvpDzLm& lm, int F, int base, int64_t px, int64_t n, float a, float b, float c, float d4, unsigned& m) {
+    if (lm.dzs[0] == nullptr) return false;
+    const int plane_rows = 16 * F;
+    if (base >= 2 * plane_rows) return false;
+    const int plane = base >= plane_rows ? 1 : 0;
+    const int rowin = base - plane * plane_rows;
+    if (px < n) {
+        float* dst = lm.dzs[plane];
+        if (F == 2) {
+            const int l0 = rowin >> 1;
+            *reinterpret_cast<float2*>(dst + ((int64_t)l0 * n + px) * 2) = make_float2(a, b);
+            *reinterpret_cast<float2*>(dst + ((int64_t)(l0 + 1) * n + px) * 2) = make_float2(c, d4);
+        } else {            // F == 4: the float4 is exactly one level
+            *reinterpret_cast<float4*>(dst + ((int64_t)(rowin >> 2) * n + px) * 4) = make_float4(a, b, c, d4);
+        }
+        m = max(m, max(max(__float_as_uint(fabsf(a)), __float_as_uint(fabsf(b))), max(__float_as_uint(fabsf(c)), __float_as_uint(fabsf(d4)))));
+    }
+    return true;
+}
+
+// after the stores: the wave's max|dz| (bit patterns: NaN / Inf win, see encode_bwd.hip) into one of the scatter's slots
+__device__ __forceinline__ void nvp_dz_lm_finish(const NvpDzLm& lm, unsigned m, int64_t tile, int lane) {
+    if (lm.dzs[0] == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0 && m > 0u) atomicMax(lm.dzmax + (int)(tile & 255), m);
+}

@@ -65,6 +65,11 @@ AUTO_SORT_MIN = int(os.environ.get("NVP_AUTO_SORT_MIN", "65536"))
 # and for tests; off by default because the sync would serialise the training loop.
 CHECK_SORTED = os.environ.get("NVP_CHECK_SORTED", "0") == "1"
 
+# For y-sorted batches the backward chain hands the xy / yt planes' latent gradients to the scatter in its own level-major
+# layout (nvp_encode_bwd_prepare / NVP_DZ_PLANES_READY): 2/3 of the scatter's permute pass disappear.  NVP_DZ_LEVEL_MAJOR=0 keeps
+# the row-major hand-over for every plane (bit-identical gradients either way).
+DZ_LEVEL_MAJOR = os.environ.get("NVP_DZ_LEVEL_MAJOR", "1") != "0"
+
 # Optional gradient sink (data parallelism): {param.data_ptr(): preallocated tensor}.  When a
 # parameter has an entry, backward writes its gradient straight into that tensor (a view of the
 # flat all-reduce bucket) and returns it, so no zero-fill / accumulate / flatten pass exists.
@@ -182,7 +187,7 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
 
 
 def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, saved: torch.Tensor,
-                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """dX chain (+ latent gradient), then the dW GEMMs.  `between(dz_rows)`, if given, runs after the
     dX kernels are enqueued and before the dW kernels: the fused NVP path uses it to enqueue the grid
     scatter (which only needs dz) first, so its gradients can be all-reduced underneath the dW GEMMs."""
@@ -196,8 +201,9 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
     dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
     drgb = _f32c(drgb)
+    # lm (optional, fused NVP path with y-sorted batches): the scatter's level-major buffers for the xy / yt planes
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
-                               L.ptr(dy), L.ptr(dz_rows), n, d, stream), "nvp_mlp_bwd_dx")
+                               L.ptr(dy), L.ptr(dz_rows), C.byref(lm) if lm is not None else None, n, d, stream), "nvp_mlp_bwd_dx")
     if between is not None:
         between(dz_rows)
     grads = [_grad_buffer(t) for t in mlp]
@@ -343,19 +349,28 @@ class NVPFused(torch.autograd.Function):
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
         d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t) for t in (kf_xy, kf_yt, kf_xt, emb))
 
+        # scatter workspace: allocated up front so that, for y-sorted batches, the backward chain can write the xy / yt planes'
+        # latent gradients straight into the scatter's level-major buffers (the permute pass then only handles the xt plane)
+        ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
+        if ws_bytes < 0:
+            raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
+        ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
+        flags, lm = ctx.flags, None
+        if DZ_LEVEL_MAJOR and (flags & L.COORDS_SORTED_BY_Y) and lib.nvp_dz_lm_supported(d):
+            lm = L.ScatterLm()
+            L.check(lib.nvp_encode_bwd_prepare(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
+                                               L.ptr(ws, torch.uint8), ws_bytes, C.byref(lm), L.stream_ptr()), "nvp_encode_bwd_prepare")
+            flags |= L.DZ_PLANES_READY
+
         def scatter(dz_rows):
-            ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
-            if ws_bytes < 0:
-                raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
-            ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
             L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1],
                           L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
                           C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
-                          L.ptr(ws, torch.uint8), ws_bytes, ctx.flags, L.stream_ptr()),
+                          L.ptr(ws, torch.uint8), ws_bytes, flags, L.stream_ptr()),
                     "nvp_encode_bwd")
             if GRIDS_READY_HOOK is not None:
                 GRIDS_READY_HOOK()            # e.g. start the (async) all-reduce of the grid gradients
 
         # order: dX chain -> grid scatter (needs only dz) -> dW GEMMs (independent of the scatter)
-        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter)
+        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm)
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, *grads)

@@ -819,14 +819,16 @@ def test_sorted_hint_is_checked_on_request(monkeypatch):
 def test_kernel_variants_are_bit_identical(tmp_path):
     """The alternative kernels kept behind environment switches (read once per process by libnvp_hip.so) - the LDS-staged gather
     (NVP_ENCODE_LDS=1), the workgroup-shared weight ring of the forward chain (NVP_MLP_RING_FWD=1), the per-wave backward
-    chain (NVP_MLP_RING_BWD=0) and the merged dW jobs (NVP_DW_MERGE=1) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
+    chain (NVP_MLP_RING_BWD=0), the merged dW jobs (NVP_DW_MERGE=1) and the row-major latent-gradient hand-over to the scatter
+    (NVP_DZ_LEVEL_MAJOR=0) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
     accumulator, same index arithmetic; only where operands are staged differs)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for k, env in enumerate(({"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # the defaults
-                             {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1"})):   # every alternative
+                             {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1",
+                              "NVP_DZ_LEVEL_MAJOR": "0"})):                                                              # every alternative
         out = str(tmp_path / f"v{k}.npz")
         subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300,
                        env={**os.environ, **env})

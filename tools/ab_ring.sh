@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 TAG=${1:-ab}
 for F in 2 4; do
   for n in 100000 4099; do
-    NVP_MLP_RING_FWD=0 NVP_MLP_RING_BWD=0 NVP_ENCODE_LDS=0 NVP_DW_MERGE=0 python tools/ab_dump.py /tmp/a_${F}_${n}.npz $F $n || exit 1
+    NVP_MLP_RING_FWD=0 NVP_MLP_RING_BWD=0 NVP_ENCODE_LDS=0 NVP_DW_MERGE=0 NVP_DZ_LEVEL_MAJOR=0 python tools/ab_dump.py /tmp/a_${F}_${n}.npz $F $n || exit 1
     NVP_MLP_RING_FWD=1 NVP_MLP_RING_BWD=1 NVP_ENCODE_LDS=1 NVP_DW_MERGE=1 python tools/ab_dump.py /tmp/b_${F}_${n}.npz $F $n || exit 1
     python - <<PY | tee -a gpurun_out/${TAG}_identity.txt
 import numpy as np
@@ -17,7 +17,7 @@ print("F=${F} n=${n}:", "BIT-IDENTICAL (%d tensors)" % len(a.files) if not bad e
 PY
   done
 done
-for V in "NVP_DW_MERGE=0" "NVP_DW_MERGE=1" "NVP_DW_MERGE=0" "NVP_DW_MERGE=1"; do
+for V in "NVP_DZ_LEVEL_MAJOR=0" "NVP_DZ_LEVEL_MAJOR=1" "NVP_DZ_LEVEL_MAJOR=0" "NVP_DZ_LEVEL_MAJOR=1"; do
   echo "== $V" | tee -a gpurun_out/${TAG}_bench.txt
   env $V python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' | python -c "
 import json,sys

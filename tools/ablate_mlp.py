@@ -38,7 +38,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "tools", "bin", "libmlp_*.so")))
     lib.nvp_mlp_pack_fwd(C.byref(ps), vp(pf), C.c_int32(d), C.c_void_p(stream))
     lib.nvp_mlp_pack_bwd(C.byref(ps), vp(pb), C.c_int32(d), C.c_void_p(stream))
     f = lambda: lib.nvp_mlp_fwd(vp(zt), vp(steps), C.byref(ps), vp(pf), vp(rgb), vp(saved), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
-    g = lambda: lib.nvp_mlp_bwd_dx(vp(drgb), vp(steps), vp(saved), C.byref(ps), vp(pb), vp(dy), vp(dz), C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
+    g = lambda: lib.nvp_mlp_bwd_dx(vp(drgb), vp(steps), vp(saved), C.byref(ps), vp(pb), vp(dy), vp(dz), None, C.c_int64(n), C.c_int32(d), C.c_void_p(stream))
     lib.nvp_dw_partial_floats.restype = C.c_int64
     if os.environ.get("NVP_LOOP_STAGE"):          # tools/power_probe.sh: loop one stage for a few seconds
         import time
