@@ -718,6 +718,12 @@ def test_device_sampler_matches_reference_sampler_formulas():
     c = mi["all_coords"][0]
     assert mi["all_coords"].shape == (1, n, 3) and mi["temporal_steps"].shape == (1, n) and g["img"].shape == (1, n, 3) and mi["sorted_by_y"]
     assert bool((c[1:, 2] >= c[:-1, 2]).all()) and float(c.min()) >= 0 and float(c.max()) <= 1
+    # prefetch (next batch drawn on a side stream) delivers the very same sequence of batches
+    plain, pre = harness.DeviceVideo(vd, n_samples=n, seed=9), harness.DeviceVideo(vd, n_samples=n, seed=9, prefetch=True)
+    for _ in range(4):
+        (ma, ga), (mb, gb) = plain.sample(), pre.sample()
+        torch.cuda.synchronize()
+        assert torch.equal(ma["all_coords"], mb["all_coords"]) and torch.equal(ma["temporal_steps"], mb["temporal_steps"]) and torch.equal(ga["img"], gb["img"])
     mi2, g2 = harness.DeviceVideo(vd, n_samples=n, seed=5, sort_by_y=False).sample()      # same draws, raw order
     key = lambda cc, ss: torch.sort(cc[:, 0] * 1e6 + cc[:, 1] * 1e3 + cc[:, 2] + ss * 1e-3).values
     assert torch.allclose(key(c, mi["temporal_steps"][0]), key(mi2["all_coords"][0], mi2["temporal_steps"][0]))
