@@ -1,145 +1,220 @@
-// bf16 x 3 split-MFMA helpers shared by mlp_fwd_b3.hip and mlp_bwd_b3.hip (see mlp_layout.h, "b3").
+// Split-operand MFMA helpers shared by the "b3" chain kernels (mlp_fwd_b3*.hip, mlp_bwd_b3*.hip) and mlp_dw.hip
+// (see mlp_layout.h, "b3").  Two operand splits, selected at build time (NVP_SPLIT_H2):
+//
+//  * fp16 x 2 (default).  x * s = hi + lo with hi = fp16(x s), lo = fp16(x s - hi): 22+ significant bits, representation
+//    error <= 2^-22 |x| (2^-24 rms).  s is a POWER OF TWO chosen so that the largest magnitude that shares the scale lands in
+//    [2^13, 2^14): per packed weight stream (pack_b3_scales_kernel), per PIXEL for activations (the pixel is the MFMA column
+//    = the lane, so the scale and its inverse are per-lane scalars).  Scaling by 2^e is exact, fp16 subnormal parts are kept
+//    (v_mfma_f32_32x32x16_f16 honours them: tools/probes/f16_mfma_probe.hip), so an element 2^-k below its pixel's maximum
+//    still carries an absolute error <= 2^-38 of that maximum.  THREE products - lo*hi, hi*lo, hi*hi, smallest first - are
+//    accumulated in fp32; the accumulator is multiplied by 2^-(e_w + e_px) afterwards (exact).  Dropped: lo*lo <= 2^-22.
+//  * bf16 x 3.  x = hi + mid + lo in bf16 (8 + 8 + 8 bits, fp32's exponent range: no scale), the SIX products >= 2^-24.
+//
+// Measured on K = 128 / 242 dot products (tools/split_accuracy.py, profiles/r02_probe_f16x2_split.txt): both splits end
+// BELOW the error of an fp32 fma chain (the fp32 accumulation dominates); fp16 x 2 needs half the matrix-pipe cycles, two
+// thirds of the weight bytes and about half the split instructions (v_fma_mix folds scale, residual and conversion).
 #pragma once
 #include "mlp_chain.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kP = kB3Parts;
+// the 16-bit parts of eight consecutive k of one operand: p[0] = hi, then (mid,) lo
+struct BOp { u32x4 p[kP]; };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32, round to nearest even
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, v);
 }
-// 8 floats -> hi / mid / lo bf16x8 with x = hi + mid + lo to ~2^-25 |x|
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
-#ifdef NVP_ABL_NOSPLIT          // ablation builds only (tools/ablate_b3.sh): one conversion per pair, no residuals
-#pragma unroll
-    for (int p = 0; p < 4; ++p) { hi[p] = pk_bf16(x[2 * p], x[2 * p + 1]); mid[p] = hi[p]; lo[p] = hi[p]; }
-    return;
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {       // v_cvt_pk_f16_f32, round to nearest even
+    f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// ---- per-pixel power-of-two scale (fp16 x 2) ----------------------------------------------------------------------------------
+// s = 2^e with m * s in [2^13, 2^14) for the pixel's largest magnitude m, u = 1 / s.  m must be >= 2^-113 (callers clamp:
+// 1.0 where a bias shares the scale, kTinyMax otherwise); m = +inf gives s = 2^-115, and the infinity itself still converts
+// to an fp16 infinity, so non-finite inputs poison the pixel's outputs as they do in fp32.
+struct PxScale { float s, u; };
+constexpr float kTinyMax = 8.8817841970012523e-16f;      // 2^-50: pixels whose inputs are all smaller keep 2^-63 absolute precision
+__device__ __forceinline__ PxScale px_scale(float m) {
+#if NVP_SPLIT_H2
+    const unsigned e = __float_as_uint(m) >> 23;
+    return {__uint_as_float((267u - e) << 23), __uint_as_float((e - 13u) << 23)};
+#else
+    return {1.0f, 1.0f};
 #endif
+}
+// largest magnitude among the 128 values of this lane's pixel held in four D-register tiles (both lane halves)
+__device__ __forceinline__ float px_absmax(const f32x16 (&v)[4]) {
+#if NVP_SPLIT_H2
+    float m = 0.f;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(v[T][r]), fabsf(v[T][r + 1])));      // v_max3_f32 |.|
+    return fmaxf(m, __shfl_xor(m, 32));
+#else
+    return 1.0f;
+#endif
+}
+
+// 8 floats -> hi / mid / lo bf16x8 with x = hi + mid + lo to ~2^-25 |x| (always available: mlp_dw.hip)
+__device__ __forceinline__ void split8_bf3(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const float a = x[2 * p], b = x[2 * p + 1];
-        const unsigned h = pk_bf16(a, b);
-        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const float a = x[2 * p], c = x[2 * p + 1];
+        const unsigned h = pk_bf16(a, c);
+        const float ra = a - __uint_as_float(h << 16), rb = c - __uint_as_float(h & 0xffff0000u);
         const unsigned m = pk_bf16(ra, rb);
         const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
         hi[p] = h; mid[p] = m; lo[p] = pk_bf16(sa, sb);
     }
 }
+__device__ __forceinline__ f32x16 mf_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// 8 floats -> parts.  fp16 x 2: of x * s.
+__device__ __forceinline__ void split8(const float (&x)[8], const float s, BOp& b) {
+#ifdef NVP_ABL_NOSPLIT          // ablation builds only (tools/ablate_b3.sh): one conversion per pair, no residuals
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int k = 0; k < kP; ++k) b.p[k][p] = NVP_SPLIT_H2 ? pk_f16(x[2 * p], x[2 * p + 1]) : pk_bf16(x[2 * p], x[2 * p + 1]);
+    return;
+#endif
+#if NVP_SPLIT_H2
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = x[2 * p], c = x[2 * p + 1];
+        const f16x2 h = {(_Float16)(a * s), (_Float16)(c * s)};
+        // residual x s - hi is exact in fp32 (hipcc: v_fma_mixlo/hi_f16 - scale, subtraction and conversion in one instruction)
+        const f16x2 l = {(_Float16)__builtin_fmaf(a, s, -(float)h.x), (_Float16)__builtin_fmaf(c, s, -(float)h.y)};
+        b.p[0][p] = __builtin_bit_cast(unsigned, h);
+        b.p[1][p] = __builtin_bit_cast(unsigned, l);
+    }
+#else
+    split8_bf3(x, b.p[0], b.p[1], b.p[2]);
+#endif
+}
+
 __device__ __forceinline__ f32x16 mf(u32x4 a, u32x4 b, f32x16 c) {
 #ifdef NVP_ABL_NOMFMA           // ablation builds only: one VALU op instead of the MFMA
     c[0] = __uint_as_float(__float_as_uint(c[0]) ^ a[0] ^ b[0]); return c;
 #endif
+#if NVP_SPLIT_H2
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
-// one k-step (16 inputs) into the four output tiles; w points at the step's 12 operand quads.  PF: prefetch the next
-// tile's three quads while the current tile's six MFMAs issue (24 instead of 12 operand registers).
-#ifdef NVP_ABL_WFIXED            // ablation builds only: every k-step of every layer reads the SAME 12 KiB of weights (stays in L1)
+// all significant part products of one (A tile, B) pair into one accumulator, smallest terms first
+__device__ __forceinline__ void mac_parts(f32x16& acc, const u32x4 (&a)[kP], const BOp& b) {
+#if NVP_SPLIT_H2
+    acc = mf(a[1], b.p[0], acc);
+    acc = mf(a[0], b.p[1], acc);
+    acc = mf(a[0], b.p[0], acc);
+#else
+    acc = mf(a[2], b.p[0], acc);
+    acc = mf(a[0], b.p[2], acc);
+    acc = mf(a[1], b.p[1], acc);
+    acc = mf(a[1], b.p[0], acc);
+    acc = mf(a[0], b.p[1], acc);
+    acc = mf(a[0], b.p[0], acc);
+#endif
+}
+
+// one k-step (16 inputs) into the four output tiles; w points at the step's 4 kP operand quads.  PF: prefetch the next
+// tile's quads while the current tile's MFMAs issue (2 kP instead of kP operand quads live).
+#ifdef NVP_ABL_WFIXED            // ablation builds only: every k-step of every layer reads the SAME block of weights (stays in L1)
 #define NVP_WSTRIDE(x) 0
 #else
 #define NVP_WSTRIDE(x) (x)
 #endif
 template <bool PF = true>
-__device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+__device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const BOp& b, int lane) {
     const unsigned ul = (unsigned)lane;
-#ifdef NVP_B3_INTERLEAVE        // experiment: consecutive MFMAs never share an accumulator (all 12 operand quads live)
-    {
-        u32x4 q[4][3];
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) q[T][k] = (w + (T * 3 + k) * 64)[ul];
-        NVP_CHAIN_FENCE();
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][2], bh, acc[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][0], bl, acc[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][1], bm, acc[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][1], bh, acc[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][0], bm, acc[T]);
-#pragma unroll
-        for (int T = 0; T < 4; ++T) acc[T] = mf(q[T][0], bh, acc[T]);
-        return;
-    }
-#endif
-    u32x4 a[2][3];
+    u32x4 a[2][kP];
     if (PF) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+        for (int q = 0; q < kP; ++q) a[0][q] = (w + q * 64)[ul];
     }
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
         if (PF) {
             if (T < 3) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+                for (int q = 0; q < kP; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * kP + q) * 64)[ul];
             }
         } else {
-            // register-lean order: lo first (one use), then mid, then hi; at most two operand quads are live
-            const u32x4 al = (w + (T * 3 + 2) * 64)[ul];
-            const u32x4 am = (w + (T * 3 + 1) * 64)[ul];
+            // register-lean order: one tile's operand quads live at a time
+#pragma unroll
+            for (int q = kP - 1; q >= 0; --q) a[0][q] = (w + (T * kP + q) * 64)[ul];
             NVP_CHAIN_FENCE();
-            acc[T] = mf(al, bh, acc[T]);
-            acc[T] = mf(am, bm, acc[T]);
-            const u32x4 ah = (w + (T * 3 + 0) * 64)[ul];
-            acc[T] = mf(am, bh, acc[T]);
+            mac_parts(acc[T], a[0], b);
             NVP_CHAIN_FENCE();
-            acc[T] = mf(ah, bl, acc[T]);
-            acc[T] = mf(ah, bm, acc[T]);
-            acc[T] = mf(ah, bh, acc[T]);
             continue;
         }
         NVP_CHAIN_FENCE();
-        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
-        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
-        acc[T] = mf(ah, bl, acc[T]);
-        acc[T] = mf(am, bm, acc[T]);
-        acc[T] = mf(am, bh, acc[T]);
-        acc[T] = mf(ah, bm, acc[T]);
-        acc[T] = mf(ah, bh, acc[T]);
+        mac_parts(acc[T], a[T & 1], b);
     }
 }
 
 // the same k-step for four consecutive tiles of a longer accumulator array
 template <bool PF = true>
-__device__ __forceinline__ void step_b3_at(f32x16* acc, const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
-    step_b3<PF>(*reinterpret_cast<f32x16(*)[4]>(acc), w, bh, bm, bl, lane);
+__device__ __forceinline__ void step_b3_at(f32x16* acc, const u32x4* __restrict__ w, const BOp& b, int lane) {
+    step_b3<PF>(*reinterpret_cast<f32x16(*)[4]>(acc), w, b, lane);
 }
 
-// bias step: B = e_0 (1.0 at k = 0, exact in bf16), A[.][0] = hi/mid/lo of the bias
-__device__ __forceinline__ void bias_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, int lane) {
+// the B operand of a bias step: e_0 times the pixel's scale (1.0 for bf16 x 3; a power of two, exact in fp16 down to 2^-24)
+__device__ __forceinline__ u32x4 bias_bop(float s, int lane) {
+#if NVP_SPLIT_H2
+    const unsigned one = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)s);
+#else
+    const unsigned one = 0x00003f80u;
+#endif
+    return u32x4{lane < 32 ? one : 0u, 0u, 0u, 0u};
+}
+// the bias products of one tile: A[.][0] = the parts of the (scaled) bias
+__device__ __forceinline__ void bias_mac(f32x16& acc, const u32x4 (&a)[kP], const u32x4 e0) {
+#pragma unroll
+    for (int q = kP - 1; q >= 0; --q) acc = mf(a[q], e0, acc);
+}
+// bias step: B = e_0 s
+__device__ __forceinline__ void bias_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, float s, int lane) {
     const unsigned ul = (unsigned)lane;
-    const u32x4 e0 = {lane < 32 ? 0x00003f80u : 0u, 0u, 0u, 0u};
+    const u32x4 e0 = bias_bop(s, lane);
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
-        const u32x4 ah = (w + (T * 3 + 0) * 64)[ul], am = (w + (T * 3 + 1) * 64)[ul], al = (w + (T * 3 + 2) * 64)[ul];
-        acc[T] = mf(al, e0, acc[T]);
-        acc[T] = mf(am, e0, acc[T]);
-        acc[T] = mf(ah, e0, acc[T]);
+        u32x4 a[kP];
+#pragma unroll
+        for (int q = 0; q < kP; ++q) a[q] = (w + (T * kP + q) * 64)[ul];
+        bias_mac(acc[T], a, e0);
     }
 }
 
-// 8 k-steps over the previous layer's D registers
-template <bool PF>
-__device__ __forceinline__ void chain_h_b3_swp(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane);
+// the eight inputs of chained k-step c: D registers 8 (c & 1) .. + 7 of tile c >> 1
+__device__ __forceinline__ void chain_in8(float (&x)[8], const f32x16 (&hin)[4], int c) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
+}
+
+// 8 k-steps over the previous layer's D registers, scaled by s
 template <bool PF = true>
-__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane) {
-#if NVP_B3_SWP
-    if (PF) { chain_h_b3_swp<PF>(acc, hin, w, lane); return; }
-#endif
+__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3<PF>(acc, w + NVP_WSTRIDE(c * 12 * 64), bh, bm, bl, lane);
+        chain_in8(x, hin, c);
+        BOp b;
+        split8(x, s, b);
+        step_b3<PF>(acc, w + NVP_WSTRIDE(c * kB3StepQuads), b, lane);
     }
 }
 
@@ -147,89 +222,42 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
 // operand split is done once and feeds both weight streams.
 template <bool PF = true>
 __device__ __forceinline__ void chain_h2_b3(f32x16 (&acc_a)[4], const u32x4* __restrict__ wa, f32x16 (&acc_b)[4], const u32x4* __restrict__ wb,
-                                            const f32x16 (&hin)[4], int lane) {
+                                            const f32x16 (&hin)[4], const float s, int lane) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3<PF>(acc_a, wa + c * 12 * 64, bh, bm, bl, lane);
-        step_b3<PF>(acc_b, wb + c * 12 * 64, bh, bm, bl, lane);
+        chain_in8(x, hin, c);
+        BOp b;
+        split8(x, s, b);
+        step_b3<PF>(acc_a, wa + c * kB3StepQuads, b, lane);
+        step_b3<PF>(acc_b, wb + c * kB3StepQuads, b, lane);
     }
 }
 
-// ---- software-pipelined operand split (NVP_B3_SWP) ------------------------------------------------------------------
-// A wave issues in order: with the split of k-step c placed in front of its 24 MFMAs, the wave's ~45 split instructions
-// and its MFMAs never overlap (only the PARTNER wave's MFMAs can run underneath), and the ablations show the VALU pipe is
-// as loaded as the matrix pipe.  Here the split of k-step c+1 is cut into four pair-splits and each is woven between the
-// six MFMAs of one output tile of k-step c (sched_group_barrier: 1 MFMA, 2 VALU, ...): the VALU instructions issue in the
-// shadow of the wave's own MFMAs (<= 5 issue slots are free per 32-cycle MFMA).
-#ifndef NVP_B3_SWP
-#define NVP_B3_SWP 0
+// acc *= f for the four tiles (un-scaling an accumulator, or bringing a parked one into a chain's scaled units); f = 1 folds away
+__device__ __forceinline__ void scale4(f32x16 (&v)[4], const float f) {
+#if NVP_SPLIT_H2
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[T][r] *= f;
 #endif
-__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-    h = pk_bf16(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    m = pk_bf16(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    l = pk_bf16(sa, sb);
 }
 
-// one k-step into four output tiles with the NEXT k-step's operand split woven in: xn = the next step's eight inputs
-// (ignored when !more); nh/nm/nl receive its parts
-__device__ __forceinline__ void step_b3_swp(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl,
-                                            const float (&xn)[8], bool more, u32x4& nh, u32x4& nm, u32x4& nl, int lane) {
-    const unsigned ul = (unsigned)lane;
-    u32x4 a[2][3];
+// LeakyReLU(0.01) of acc * f (modulation.py:112-121)
+__device__ __forceinline__ void lrelu4_scaled(f32x16 (&v)[4], const float f) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+    for (int T = 0; T < 4; ++T)
 #pragma unroll
-    for (int T = 0; T < 4; ++T) {
-        if (T < 3) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+        for (int r = 0; r < 16; ++r) {
+            const float t = NVP_SPLIT_H2 ? v[T][r] * f : v[T][r];
+            v[T][r] = t > 0.f ? t : t * 0.01f;
         }
-        NVP_CHAIN_FENCE();
-        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
-        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
-        acc[T] = mf(ah, bl, acc[T]);
-        acc[T] = mf(am, bm, acc[T]);
-        acc[T] = mf(am, bh, acc[T]);
-        acc[T] = mf(ah, bm, acc[T]);
-        acc[T] = mf(ah, bh, acc[T]);
-        if (more) {
-            unsigned h_, m_, l_;
-            split2(xn[2 * T], xn[2 * T + 1], h_, m_, l_);
-            nh[T] = h_; nm[T] = m_; nl[T] = l_;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU in its shadow
-            }
-        }
-    }
 }
 
-template <bool PF = true>
-__device__ __forceinline__ void chain_h_b3_swp(f32x16 (&acc)[4], const f32x16 (&hin)[4], const u32x4* __restrict__ w, int lane) {
-    u32x4 bh, bm, bl;
-    {
-        float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = hin[0][q];
-        split8(x, bh, bm, bl);
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float xn[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xn[q] = hin[((c + 1) & 7) >> 1][8 * ((c + 1) & 1) + q];
-        u32x4 nh = bh, nm = bm, nl = bl;
-        step_b3_swp(acc, w + NVP_WSTRIDE(c * 12 * 64), bh, bm, bl, xn, c + 1 < 8, nh, nm, nl, lane);
-        bh = nh; bm = nm; bl = nl;
-    }
+// per-pixel largest magnitude of a float4 (used while staging / streaming the latent)
+__device__ __forceinline__ float absmax_f4(float m, const float4 t) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
 }
 
 // the 16 values of table `t` for this lane's rows of tile T (see kB3TabFloats): four 16-B loads

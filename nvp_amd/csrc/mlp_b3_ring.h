@@ -1,4 +1,5 @@
-// Workgroup-shared weight operands for the bf16 x 3 split-MFMA chains (mlp_fwd_b3r.hip, mlp_bwd_b3r.hip).
+// Workgroup-shared weight operands for the split-operand MFMA chains (mlp_fwd_b3r.hip, mlp_bwd_b3r.hip).  Sizes below are
+// for the bf16 x 3 split (12 KiB per k-step); with the fp16 x 2 split (mlp_b3.h) a k-step is 8 KiB = 8 pieces of 1 KiB.
 //
 // Why.  In mlp_fwd_b3 / mlp_bwd_b3 every wave streams the complete packed weight set (12 KiB per 16-input k-step, 732 /
 // 672 KiB per 32-pixel tile) through its own vector-memory path: 29 GB of L2->L1->VGPR traffic per launch.  A CU's vector
@@ -6,8 +7,8 @@
 // SIMDs need for the k-step's 8 x 24 MFMAs.  The weight stream alone saturates the L1 return path, so the matrix pipe can
 // never be much more than half busy (measured: 42 % forward, 28 % backward; 3.2e7 VMEM wave-instructions per launch).
 //
-// What.  The four waves of a workgroup walk the layers in lock step and share each k-step's 12 KiB through LDS:
-//   * every wave fetches ONE QUARTER of the step (3 x 1 KiB, three 16-byte loads per lane) two steps ahead into registers,
+// What.  The four waves of a workgroup walk the layers in lock step and share each k-step through LDS:
+//   * every wave fetches ONE QUARTER of the step (kP x 1 KiB, kP 16-byte loads per lane) two steps ahead into registers,
 //   * writes it to the free slot of a two-slot ring one step ahead (ds_write_b128, lane-contiguous),
 //   * all four read their A operands from the current slot (ds_read_b128, lane-contiguous: conflict-free),
 //   * one s_barrier per k-step both publishes slot (s+1) and retires slot (s-1).
@@ -19,25 +20,25 @@
 #pragma once
 #include "mlp_b3.h"
 
-constexpr int kRingQuads = 12 * 64;            // u32x4 per k-step (12 KiB)
+constexpr int kRingQuads = kB3StepQuads;       // u32x4 per k-step (8 / 12 KiB)
 
 struct WRing {
     u32x4* lds;                // two slots of kRingQuads
     const u32x4* g;            // packed stream, k-step 0
     int total;                 // k-steps in the stream
     int wv, lane;
-    u32x4 sg[3];               // this wave's quarter of the step that is two ahead of the one being consumed
+    u32x4 sg[kP];              // this wave's quarter of the step that is two ahead of the one being consumed
 
-    // pieces 3 wv .. 3 wv + 2 of step s
+    // pieces kP wv .. kP wv + kP - 1 of step s
     __device__ __forceinline__ void fetch(int s) {
-        const u32x4* p = g + NVP_WSTRIDE((int64_t)s * kRingQuads) + (3 * wv) * 64;
+        const u32x4* p = g + NVP_WSTRIDE((int64_t)s * kRingQuads) + (kP * wv) * 64;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
+        for (int q = 0; q < kP; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
     }
     __device__ __forceinline__ void publish(int s) {
-        u32x4* d = lds + (s & 1) * kRingQuads + (3 * wv) * 64;
+        u32x4* d = lds + (s & 1) * kRingQuads + (kP * wv) * 64;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
+        for (int q = 0; q < kP; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
     }
     __device__ __forceinline__ void prologue() {
         fetch(0);
@@ -77,7 +78,7 @@ struct WRingF {
     const u32x4* g;
     int total;
     int wv, lane;
-    u32x4 sg[3];
+    u32x4 sg[kP];
 
     __device__ __forceinline__ unsigned cnt_addr(int which, int slot) const {      // LDS byte address of a counter
         return (unsigned)reinterpret_cast<uintptr_t>(lds + R * kRingQuads) + 4u * (unsigned)(which * R + slot);
@@ -93,16 +94,16 @@ struct WRingF {
         else asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void fetch(int s) {
-        const u32x4* p = g + NVP_WSTRIDE((int64_t)s * kRingQuads) + (3 * wv) * 64;
+        const u32x4* p = g + NVP_WSTRIDE((int64_t)s * kRingQuads) + (kP * wv) * 64;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
+        for (int q = 0; q < kP; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
     }
     __device__ __forceinline__ void publish(int p) {
         const int slot = p % R;
         wait_ge(cnt_addr(1, slot), 4u * (unsigned)(p / R));            // every consumer is done with the slot's previous step
-        u32x4* d = lds + slot * kRingQuads + (3 * wv) * 64;
+        u32x4* d = lds + slot * kRingQuads + (kP * wv) * 64;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
+        for (int q = 0; q < kP; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
         signal(cnt_addr(0, slot));
     }
     __device__ __forceinline__ void prologue() {
@@ -124,38 +125,32 @@ struct WRingF {
 
 // one k-step into four output tiles, A operands from the ring slot `w` (LDS); the reads of tile T+1 are issued ahead of
 // the MFMAs of tile T
-__device__ __forceinline__ void step_b3_ring(f32x16 (&acc)[4], const u32x4* __restrict__ w, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+__device__ __forceinline__ void step_b3_ring(f32x16 (&acc)[4], const u32x4* __restrict__ w, const BOp& b, int lane) {
     const unsigned ul = (unsigned)lane;
-    u32x4 a[2][3];
+    u32x4 a[2][kP];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+    for (int q = 0; q < kP; ++q) a[0][q] = (w + q * 64)[ul];
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
         if (T < 3) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * 3 + q) * 64)[ul];
+            for (int q = 0; q < kP; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * kP + q) * 64)[ul];
         }
         NVP_CHAIN_FENCE();
-        const u32x4 ah = a[T & 1][0], am = a[T & 1][1], al = a[T & 1][2];
-        acc[T] = mf(al, bh, acc[T]);              // smallest terms first
-        acc[T] = mf(ah, bl, acc[T]);
-        acc[T] = mf(am, bm, acc[T]);
-        acc[T] = mf(am, bh, acc[T]);
-        acc[T] = mf(ah, bm, acc[T]);
-        acc[T] = mf(ah, bh, acc[T]);
+        mac_parts(acc[T], a[T & 1], b);
     }
 }
 
-// bias step: B = e_0 (1.0 at k = 0, exact in bf16), A[.][0] = hi/mid/lo of the bias
-__device__ __forceinline__ void bias_b3_ring(f32x16 (&acc)[4], const u32x4* __restrict__ w, int lane) {
+// bias step: B = e_0 s (mlp_b3.h), A[.][0] = the parts of the bias
+__device__ __forceinline__ void bias_b3_ring(f32x16 (&acc)[4], const u32x4* __restrict__ w, float s, int lane) {
     const unsigned ul = (unsigned)lane;
-    const u32x4 e0 = {lane < 32 ? 0x00003f80u : 0u, 0u, 0u, 0u};
+    const u32x4 e0 = bias_bop(s, lane);
 #pragma unroll
     for (int T = 0; T < 4; ++T) {
-        const u32x4 ah = (w + (T * 3 + 0) * 64)[ul], am = (w + (T * 3 + 1) * 64)[ul], al = (w + (T * 3 + 2) * 64)[ul];
-        acc[T] = mf(al, e0, acc[T]);
-        acc[T] = mf(am, e0, acc[T]);
-        acc[T] = mf(ah, e0, acc[T]);
+        u32x4 a[kP];
+#pragma unroll
+        for (int q = 0; q < kP; ++q) a[q] = (w + (T * kP + q) * 64)[ul];
+        bias_mac(acc[T], a, e0);
     }
 }
 
@@ -163,53 +158,53 @@ __device__ __forceinline__ void bias_b3_ring(f32x16 (&acc)[4], const u32x4* __re
 // at the start of the LAST k-step: the caller prefetches what the following chain needs (its first latent rows) there,
 // one k-step ahead, instead of keeping those registers alive through the whole chain.
 template <typename Ring, typename Pre>
-__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], Ring& R, int& s, int lane, Pre pre) {
+__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float sc, Ring& R, int& s, int lane, Pre pre) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const u32x4* w = R.begin(s);
         if (c == 7) pre();
         float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3_ring(acc, w, bh, bm, bl, lane);
+        chain_in8(x, hin, c);
+        BOp b;
+        split8(x, sc, b);
+        step_b3_ring(acc, w, b, lane);
         R.end(s);
         ++s;
     }
 }
 
 template <typename Ring>
-__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], Ring& R, int& s, int lane) {
-    chain_h_b3_ring(acc, hin, R, s, lane, [] {});
+__device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float sc, Ring& R, int& s, int lane) {
+    chain_h_b3_ring(acc, hin, sc, R, s, lane, [] {});
 }
 
 // ---- half-step ring (mlp_bwd_b3r.hip) ------------------------------------------------------------------------------
 // The backward chain keeps a 16.9 KiB transpose / parking tile per wave in LDS, which leaves 12 KiB per workgroup when two
-// workgroups share a CU: the ring's slots then hold HALF a k-step (two output tiles x three parts = 6 KiB), one barrier
-// per half-step.  Six 1-KiB pieces per half-step over four waves: the wave pair {0,1} takes two pieces each on even
-// half-steps and one each on odd ones, the pair {2,3} the other way round (three pieces per wave and k-step).
-constexpr int kHalfQuads = 6 * 64;
+// workgroups share a CU: the ring's slots then hold HALF a k-step (two output tiles x kP parts: 4 KiB fp16 x 2, 6 KiB
+// bf16 x 3), one barrier per half-step.  fp16 x 2: four 1-KiB pieces per half-step, one per wave.  bf16 x 3: six pieces over
+// four waves - wave w moves pieces w and 4 + (w & 1).
+constexpr int kHalfPieces = 2 * kP;
+constexpr int kHalfQuads = kHalfPieces * 64;
 
 struct HRing {
     u32x4* lds;                // two slots of kHalfQuads
     const u32x4* g;            // packed stream in consumption order, half-step 0
     int chain_end;             // first half-step beyond the chain that is open
     int wv, lane;
-    u32x4 sg[2];
+    u32x4 sg[kHalfPieces > 4 ? 2 : 1];
 
-    // wave w moves pieces w and 4 + (w & 1): pieces 4 and 5 are moved twice (identical data to identical addresses), which
-    // keeps fetch / publish free of wave-dependent branches (a conditional second quad cost ~450 spill instructions: the
-    // branches split the chains' scheduling regions)
+    // bf16 x 3: pieces 4 and 5 are moved twice (identical data to identical addresses), which keeps fetch / publish free of
+    // wave-dependent branches (a conditional second quad cost ~450 spill instructions: the branches split the chains'
+    // scheduling regions)
     __device__ __forceinline__ void fetch(int hs) {
         const u32x4* p = g + (int64_t)hs * kHalfQuads;
         sg[0] = (p + wv * 64)[(unsigned)lane];
-        sg[1] = (p + (4 + (wv & 1)) * 64)[(unsigned)lane];
+        if (kHalfPieces > 4) sg[kHalfPieces > 4 ? 1 : 0] = (p + (4 + (wv & 1)) * 64)[(unsigned)lane];
     }
     __device__ __forceinline__ void publish(int hs) {
         u32x4* d = lds + (hs & 1) * kHalfQuads;
         (d + wv * 64)[(unsigned)lane] = sg[0];
-        (d + (4 + (wv & 1)) * 64)[(unsigned)lane] = sg[1];
+        if (kHalfPieces > 4) (d + (4 + (wv & 1)) * 64)[(unsigned)lane] = sg[kHalfPieces > 4 ? 1 : 0];
     }
     // Open a chain of `nh` half-steps starting at hs0: fill slot hs0, fetch hs0 + 1.  The ring is filled chain by chain (not
     // across chains) so that the staging registers are DEAD during the element-wise stages between the chains, where the
@@ -234,13 +229,13 @@ struct HRing {
 #endif
 };
 
-// one k-step (two half-steps of the ring) into four output tiles.  LEAN: one tile's three operand quads live at a time
+// one k-step (two half-steps of the ring) into four output tiles.  LEAN: one tile's operand quads live at a time
 // (the backward chain has two accumulator sets live in its shared pass and no registers to spare); otherwise the second
 // tile's quads are read ahead of the first tile's MFMAs.
 #ifndef NVP_HRING_LEAN
 #define NVP_HRING_LEAN 1
 #endif
-__device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& hs, const u32x4 bh, const u32x4 bm, const u32x4 bl, int lane) {
+__device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& hs, const BOp& b, int lane) {
     const unsigned ul = (unsigned)lane;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -249,35 +244,23 @@ __device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& h
 #pragma unroll
         for (int Tl = 0; Tl < 2; ++Tl) {
             const int T = 2 * half + Tl;
-            const u32x4 al = (w + (Tl * 3 + 2) * 64)[ul];
-            const u32x4 am = (w + (Tl * 3 + 1) * 64)[ul];
-            const u32x4 ah = (w + (Tl * 3 + 0) * 64)[ul];
+            u32x4 a[kP];
+#pragma unroll
+            for (int q = kP - 1; q >= 0; --q) a[q] = (w + (Tl * kP + q) * 64)[ul];
             NVP_CHAIN_FENCE();
-            acc[T] = mf(al, bh, acc[T]);              // smallest terms first
-            acc[T] = mf(ah, bl, acc[T]);
-            acc[T] = mf(am, bm, acc[T]);
-            acc[T] = mf(am, bh, acc[T]);
-            acc[T] = mf(ah, bm, acc[T]);
-            acc[T] = mf(ah, bh, acc[T]);
+            mac_parts(acc[T], a, b);
             NVP_CHAIN_FENCE();
         }
 #else
-        u32x4 a[2][3];
+        u32x4 a[2][kP];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[0][q] = (w + q * 64)[ul];
+        for (int Tl = 0; Tl < 2; ++Tl)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[1][q] = (w + (3 + q) * 64)[ul];
+            for (int q = 0; q < kP; ++q) a[Tl][q] = (w + (Tl * kP + q) * 64)[ul];
 #pragma unroll
         for (int Tl = 0; Tl < 2; ++Tl) {
-            const int T = 2 * half + Tl;
             NVP_CHAIN_FENCE();
-            const u32x4 ah = a[Tl][0], am = a[Tl][1], al = a[Tl][2];
-            acc[T] = mf(al, bh, acc[T]);              // smallest terms first
-            acc[T] = mf(ah, bl, acc[T]);
-            acc[T] = mf(am, bm, acc[T]);
-            acc[T] = mf(am, bh, acc[T]);
-            acc[T] = mf(ah, bm, acc[T]);
-            acc[T] = mf(ah, bh, acc[T]);
+            mac_parts(acc[2 * half + Tl], a[Tl], b);
         }
 #endif
         R.end();
@@ -285,31 +268,29 @@ __device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& h
     }
 }
 
-__device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 (&hin)[4], HRing& R, int& hs, int lane) {
+__device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane) {
     R.open(hs, 16);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3_hring(acc, R, hs, bh, bm, bl, lane);
+        chain_in8(x, hin, c);
+        BOp b;
+        split8(x, sc, b);
+        step_b3_hring(acc, R, hs, b, lane);
     }
 }
 
 // two transposed GEMMs over the SAME input registers, one operand split per k-step; the packed stream interleaves the two
 // weight streams k-step by k-step (a's step c, then b's step c)
-__device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&acc_b)[4], const f32x16 (&hin)[4], HRing& R, int& hs, int lane) {
+__device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&acc_b)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane) {
     R.open(hs, 32);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3_hring(acc_a, R, hs, bh, bm, bl, lane);
-        step_b3_hring(acc_b, R, hs, bh, bm, bl, lane);
+        chain_in8(x, hin, c);
+        BOp b;
+        split8(x, sc, b);
+        step_b3_hring(acc_a, R, hs, b, lane);
+        step_b3_hring(acc_b, R, hs, b, lane);
     }
 }

@@ -1,8 +1,10 @@
 // Backward dX chain + latent gradient + per-tile records (see mlp_bwd.hip, whose structure this kernel shares line
-// for line) with every transposed GEMM on **bf16 x 3 split MFMA** (mlp_b3.h): dq / dp are split into hi + mid + lo
-// bf16 on the fly, the transposed weights come pre-split from pack_bwd_b3_kernel, six products per k-step are
-// accumulated in fp32.  Used for latents of <= 256 rows when the library is built with NVP_BWD_B3=1 (latent gradient
-// fused up to 128 rows, separate mlp_bwd_dz_b3_kernel beyond).
+// for line) with every transposed GEMM on **split-operand 16-bit MFMA** (mlp_b3.h: fp16 x 2 scaled split, three products -
+// or bf16 x 3, six): dq / dp are split on the fly (fp16 x 2: scaled per pixel by a power of two from the pixel's largest
+// |dq| / |dp|; a parked latent-gradient accumulator is brought into the chain's scaled units before the chain and back
+// after it - both exact), the transposed weights come pre-split from pack_bwd_b3_kernel, products are accumulated in fp32.
+// Used for latents of <= 256 rows when the library is built with NVP_BWD_B3=1 (latent gradient fused up to 128 rows,
+// separate mlp_bwd_dz_b3_kernel beyond).
 #include "mlp_b3.h"
 
 #ifndef NVP_BWD_B3_SHARE
@@ -41,6 +43,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
     float* dyt = dy + tb;                  // dp0,dp1,dp2,(records),dq1,dq2
     const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
     const float* tab = reinterpret_cast<const float*>(packed + nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)));      // sir_w0 / sir_b0 / last_w in D-register order
+    const float* wsc = tab + kB3ScaleOff;              // 2^e of each weight stream, 2^-e at + 8 (mlp_layout.h)
 
     // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
     // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
@@ -134,9 +137,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         f32x16 acc[4];
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h_b3<NVP_BWD_B3_PF>(acc, dx, wp + nvp_bwd_b3_off(2 - k, 4) / 4, lane);   // streams 0 (sir2^T), 1 (sir1^T)
+        {
+            const PxScale pq = px_scale(fmaxf(px_absmax(dx), kTinyMax));
+            chain_h_b3<NVP_BWD_B3_PF>(acc, dx, pq.s, wp + nvp_bwd_b3_off(2 - k, 4) / 4, lane);   // streams 0 (sir2^T), 1 (sir1^T)
+            scale4(acc, pq.u * wsc[8 + 2 - k]);
+        }
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+        const PxScale pp = px_scale(fmaxf(px_absmax(dh), kTinyMax));       // dp_k feeds the dz and the dh chain
 #if NVP_BWD_B3_SHARE
         if (FUSE_DZ) {
             // dz += W_k[:, 128:]^T dp_k and dh_{k-1} = W_k[:, :128]^T dp_k in ONE pass over dp (one operand split per
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
                         const float4 t = park[(T * 4 + g) * 64 + lane];
                         dzacc[T][4 * g] = t.x; dzacc[T][4 * g + 1] = t.y; dzacc[T][4 * g + 2] = t.z; dzacc[T][4 * g + 3] = t.w;
                     }
+                    if (NVP_SPLIT_H2) dzacc[T] *= pp.s * wsc[4 + k];      // into this chain's scaled units (exact)
                 }
                 NVP_LOAD_FENCE();
 #pragma unroll
@@ -163,7 +172,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
             }
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            chain_h2_b3<NVP_BWD_B3_PF>(dzacc, wp + nvp_bwd_b3_off(4 + k, 4) / 4, acc, wp + nvp_bwd_b3_off(4 - k, 4) / 4, dh, lane);
+            chain_h2_b3<NVP_BWD_B3_PF>(dzacc, wp + nvp_bwd_b3_off(4 + k, 4) / 4, acc, wp + nvp_bwd_b3_off(4 - k, 4) / 4, dh, pp.s, lane);
+            scale4(acc, pp.u * wsc[8 + 4 - k]);
+            scale4(dzacc, pp.u * wsc[8 + 4 + k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
 #pragma unroll
@@ -197,8 +208,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
                         const float4 t = park[(T * 4 + g) * 64 + lane];
                         acc[T][4 * g] = t.x; acc[T][4 * g + 1] = t.y; acc[T][4 * g + 2] = t.z; acc[T][4 * g + 3] = t.w;
                     }
+                scale4(acc, pp.s * wsc[4 + k]);
             }
-            chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 + k, 4) / 4, lane);   // streams 6 (z2^T), 5 (z1^T)
+            chain_h_b3<NVP_BWD_B3_PF>(acc, dh, pp.s, wp + nvp_bwd_b3_off(4 + k, 4) / 4, lane);   // streams 6 (z2^T), 5 (z1^T)
+            scale4(acc, pp.u * wsc[8 + 4 + k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
@@ -213,7 +226,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         for (int T = 0; T < 4; ++T) nvp_pin(dh[T]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h_b3<NVP_BWD_B3_PF>(acc, dh, wp + nvp_bwd_b3_off(4 - k, 4) / 4, lane);   // streams 2 (mod2h^T), 3 (mod1h^T)
+        chain_h_b3<NVP_BWD_B3_PF>(acc, dh, pp.s, wp + nvp_bwd_b3_off(4 - k, 4) / 4, lane);   // streams 2 (mod2h^T), 3 (mod1h^T)
+        scale4(acc, pp.u * wsc[8 + 4 - k]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
     }
@@ -284,7 +298,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
         if (FUSE_DZ) {
             // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
             NVP_LOAD_FENCE();
-            chain_h_b3<NVP_BWD_B3_PF>(dzacc, dh, wp + nvp_bwd_b3_off(4, 4) / 4, lane);     // stream 4 (z0^T)
+            const PxScale pp = px_scale(fmaxf(px_absmax(dh), kTinyMax));
+            scale4(dzacc, pp.s * wsc[4]);
+            chain_h_b3<NVP_BWD_B3_PF>(dzacc, dh, pp.s, wp + nvp_bwd_b3_off(4, 4) / 4, lane);     // stream 4 (z0^T)
+            scale4(dzacc, pp.u * wsc[8 + 4]);
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
             const int F = d / 57;                       // latent = 57 F columns (modules.py:42-45)
@@ -315,6 +332,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3_kernel(const flo
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
     const float* dyt = dy + tile * (int64_t)NVP_H * 32;
     const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
+    const float* wsc = reinterpret_cast<const float*>(packed + nvp_bwd_b3_off(7, ZT)) + kB3ScaleOff;
     f32x16 dz[ZT];
 #pragma unroll
     for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
@@ -325,15 +343,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3_kernel(const flo
         for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + (int64_t)k * act, T, lane);
         NVP_LOAD_FENCE();
         const u32x4* w = wp + nvp_bwd_b3_off(4 + k, ZT) / 4;       // streams 6 (z2^T), 5 (z1^T), 4 (z0^T)
+        const PxScale pp = px_scale(fmaxf(px_absmax(b), kTinyMax));
+        if (NVP_SPLIT_H2) {                                         // the running sum into this layer's scaled units (exact)
+            const float f = pp.s * wsc[4 + k];
+#pragma unroll
+            for (int T = 0; T < ZT; ++T) dz[T] *= f;
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float x[8];
+            chain_in8(x, b, c);
+            BOp bo;
+            split8(x, pp.s, bo);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x[q] = b[c >> 1][8 * (c & 1) + q];
-            u32x4 bh, bm, bl;
-            split8(x, bh, bm, bl);
+            for (int T0 = 0; T0 < ZT; T0 += 4) step_b3_at<NVP_BWD_B3_PF>(dz + T0, w + (c * ZT + T0) * kB3TileQuads, bo, lane);
+        }
+        if (NVP_SPLIT_H2) {
+            const float f = pp.u * wsc[8 + 4 + k];
 #pragma unroll
-            for (int T0 = 0; T0 < ZT; T0 += 4) step_b3_at<NVP_BWD_B3_PF>(dz + T0, w + (c * ZT + T0) * 3 * 64, bh, bm, bl, lane);
+            for (int T = 0; T < ZT; ++T) dz[T] *= f;
         }
     }
     const int stride = nvp_dz_stride_dev(d);

@@ -1,7 +1,7 @@
 // Backward dX chain + latent gradient + per-tile records (mlp_bwd_b3.hip, latent <= 128 rows, fused latent gradient) with
 // WORKGROUP-SHARED weight operands: the A operands of every transposed GEMM come from a two-slot LDS ring that the four
 // waves of the workgroup fill cooperatively (mlp_b3_ring.h, half-step ring: the per-wave transpose / parking tiles leave
-// 12 KiB per workgroup with two workgroups per CU) instead of 12 KiB of per-wave global loads per k-step.  Arithmetic,
+// 12 KiB per workgroup with two workgroups per CU) instead of 8 / 12 KiB of per-wave global loads per k-step.  Arithmetic,
 // streams, records and the latent gradient are those of mlp_bwd_b3_kernel<true>, bit for bit (same MFMA order per
 // accumulator); the packed weights are read from the consumption-ordered copy behind the tables (mlp_layout.h).
 #include "mlp_b3_ring.h"
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
     const float* sv = saved + tb;          // h0,h1,h2,q1,q2 at +k*act
     float* dyt = dy + tb;                  // dp0,dp1,dp2,(records),dq1,dq2
     const float* tab = reinterpret_cast<const float*>(packed + nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d)));      // sir_w0 / sir_b0 / last_w in D-register order
+    const float* wsc = tab + kB3ScaleOff;              // 2^e of each weight stream, 2^-e at + 8 (mlp_layout.h)
 
     // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
     // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
@@ -132,9 +133,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
         f32x16 acc[4];
 #pragma unroll
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-        chain_h_b3_hring(acc, dx, R, hs, lane);        // streams 0 (sir2^T), 1 (sir1^T)
+        {
+            const PxScale pq = px_scale(fmaxf(px_absmax(dx), kTinyMax));
+            chain_h_b3_hring(acc, dx, pq.s, R, hs, lane);        // streams 0 (sir2^T), 1 (sir1^T)
+            scale4(acc, pq.u * wsc[8 + 2 - k]);
+        }
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
+        const PxScale pp = px_scale(fmaxf(px_absmax(dh), kTinyMax));       // dp_k feeds the dz and the dh chain
         if (true) {
             // dz += W_k[:, 128:]^T dp_k and dh_{k-1} = W_k[:, :128]^T dp_k in ONE pass over dp (one operand split per
             // k-step instead of two).  Both accumulators are live, so dx' waits in the wave's LDS tile meanwhile: the
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
                         const float4 t = park[(T * 4 + g) * 64 + lane];
                         dzacc[T][4 * g] = t.x; dzacc[T][4 * g + 1] = t.y; dzacc[T][4 * g + 2] = t.z; dzacc[T][4 * g + 3] = t.w;
                     }
+                    if (NVP_SPLIT_H2) dzacc[T] *= pp.s * wsc[4 + k];      // into this chain's scaled units (exact)
                 }
                 NVP_LOAD_FENCE();
 #pragma unroll
@@ -160,7 +167,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
             }
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            chain_h2_b3_hring(dzacc, acc, dh, R, hs, lane);          // streams 6/2 (z2^T, mod2h^T), 5/3 (z1^T, mod1h^T), interleaved per k-step
+            chain_h2_b3_hring(dzacc, acc, dh, pp.s, R, hs, lane);    // streams 6/2 (z2^T, mod2h^T), 5/3 (z1^T, mod1h^T), interleaved per k-step
+            scale4(acc, pp.u * wsc[8 + 4 - k]);
+            scale4(dzacc, pp.u * wsc[8 + 4 + k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
 #pragma unroll
@@ -247,7 +256,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
         if (true) {
             // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
             NVP_LOAD_FENCE();
-            chain_h_b3_hring(dzacc, dh, R, hs, lane);     // stream 4 (z0^T)
+            const PxScale pp = px_scale(fmaxf(px_absmax(dh), kTinyMax));
+            scale4(dzacc, pp.s * wsc[4]);
+            chain_h_b3_hring(dzacc, dh, pp.s, R, hs, lane);     // stream 4 (z0^T)
+            scale4(dzacc, pp.u * wsc[8 + 4]);
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
             const int F = d / 57;                       // latent = 57 F columns (modules.py:42-45)
@@ -273,7 +285,7 @@ int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* s
                            const float* packed_bwd, float* dy, float* dz_rows, NvpDzLm lm, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
-    const size_t lds = kWaves * kRecTileFloats * sizeof(float) + 2 * kHalfQuads * sizeof(u32x4);        // 67 584 + 12 288 B: two workgroups per CU
+    const size_t lds = kWaves * kRecTileFloats * sizeof(float) + 2 * kHalfQuads * sizeof(u32x4);        // 67 584 + 8 192 / 12 288 B: two workgroups per CU
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_bwd);
     hipLaunchKernelGGL(mlp_bwd_b3r_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, lm, n, ntiles, d);
     NVP_LAUNCH_CHECK();

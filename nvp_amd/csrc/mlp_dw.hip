@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const float x[8] = {fb[c][8 * s2], fb[c][8 * s2 + 1], fb[c][8 * s2 + 2], fb[c][8 * s2 + 3],
                                         fb[c][8 * s2 + 4], fb[c][8 * s2 + 5], fb[c][8 * s2 + 6], fb[c][8 * s2 + 7]};
-                    split8(x, pb[c][s2][0], pb[c][s2][1], pb[c][s2][2]);
+                    split8_bf3(x, pb[c][s2][0], pb[c][s2][1], pb[c][s2][2]);
                 }
 #pragma unroll
             for (int r2 = 0; r2 < 2; ++r2) {
@@ -278,15 +278,15 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const float x[8] = {fa[8 * s2], fa[8 * s2 + 1], fa[8 * s2 + 2], fa[8 * s2 + 3], fa[8 * s2 + 4], fa[8 * s2 + 5], fa[8 * s2 + 6], fa[8 * s2 + 7]};
                     u32x4 ah, am, al;
-                    split8(x, ah, am, al);
+                    split8_bf3(x, ah, am, al);
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        acc[r2][c] = mf(al, pb[c][s2][0], acc[r2][c]);
-                        acc[r2][c] = mf(ah, pb[c][s2][2], acc[r2][c]);
-                        acc[r2][c] = mf(am, pb[c][s2][1], acc[r2][c]);
-                        acc[r2][c] = mf(am, pb[c][s2][0], acc[r2][c]);
-                        acc[r2][c] = mf(ah, pb[c][s2][1], acc[r2][c]);
-                        acc[r2][c] = mf(ah, pb[c][s2][0], acc[r2][c]);
+                        acc[r2][c] = mf_bf16(al, pb[c][s2][0], acc[r2][c]);
+                        acc[r2][c] = mf_bf16(ah, pb[c][s2][2], acc[r2][c]);
+                        acc[r2][c] = mf_bf16(am, pb[c][s2][1], acc[r2][c]);
+                        acc[r2][c] = mf_bf16(am, pb[c][s2][0], acc[r2][c]);
+                        acc[r2][c] = mf_bf16(ah, pb[c][s2][1], acc[r2][c]);
+                        acc[r2][c] = mf_bf16(ah, pb[c][s2][0], acc[r2][c]);
                     }
                 }
             }

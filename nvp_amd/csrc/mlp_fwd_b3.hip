@@ -1,12 +1,13 @@
-// Forward of the modulator MLP + modulated SIREN (R8-R10) on **bf16 x 3 split MFMA**: same structure as
-// mlp_fwd.hip (one wave = one 32-pixel tile, pixel on the MFMA column axis, a layer's 64 D registers are the next
-// layer's B operand, latent tile in the wave's LDS region, five saved streams), but every GEMM runs on
-// v_mfma_f32_32x32x16_bf16: both operands are written as hi + mid + lo bf16 (weights once per step by
-// pack_fwd_b3_kernel, activations on the fly from the fp32 registers) and the six products >= 2^-24 are
-// accumulated in fp32.  The result carries an error BELOW that of an fp32 fma chain of the same length
-// (profiles/r01_probe_bf16x3_split_chain.txt) at 2.5x fewer matrix-pipe cycles.  Used for latents of <= 128 rows
-// when the library is built with NVP_FWD_B3=1 (up to 256 rows; beyond 144 rows the rest is read from the tensor); everything else (element-wise stages, saved streams, RGB layout)
-// is identical to the fp32 kernel.
+// Forward of the modulator MLP + modulated SIREN (R8-R10) on **split-operand 16-bit MFMA** (mlp_b3.h: fp16 x 2 scaled split,
+// three products - or bf16 x 3, six products): same structure as mlp_fwd.hip (one wave = one 32-pixel tile, pixel on the
+// MFMA column axis, a layer's 64 D registers are the next layer's B operand, latent tile in the wave's LDS region, five
+// saved streams), but every GEMM runs on v_mfma_f32_32x32x16_{f16,bf16}: weights are split once per step by
+// pack_fwd_b3_kernel, activations on the fly from the fp32 registers (fp16 x 2: scaled per PIXEL by a power of two taken
+// from the pixel's largest input, the accumulator is un-scaled before the activation), products accumulated in fp32.
+// The result carries an error BELOW that of an fp32 fma chain of the same length at 5x (fp16 x 2) / 2.5x (bf16 x 3)
+// fewer matrix-pipe cycles.  Used for latents of <= 256 rows when the library is built with NVP_FWD_B3=1 (beyond 144
+// rows the rest is read from the tensor); everything else (element-wise stages, saved streams, RGB layout) is identical
+// to the fp32 kernel.
 #include "mlp_b3.h"
 
 #ifndef NVP_B3_ZUNROLL
@@ -18,31 +19,56 @@ namespace {
 constexpr int kWaves = 4;
 // `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
 // step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
-__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const u32x4* __restrict__ w, int j, int h, int lane) {
+__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane) {
     const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
     const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
     const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-    u32x4 bh, bm, bl;
-    split8(x, bh, bm, bl);
-    step_b3(acc, w + NVP_WSTRIDE(s * 12 * 64), bh, bm, bl, lane);
+    BOp b;
+    split8(x, sc, b);
+    step_b3(acc, w + NVP_WSTRIDE(s * kB3StepQuads), b, lane);
 }
 
-__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const u32x4* __restrict__ w, int lane) {
+// sc: the pixel's operand scale (mlp_b3.h; 1 for bf16 x 3)
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane) {
     const int j = lane & 31, h = lane >> 5;
 #if NVP_B3_ZUNROLL
     if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, w, j, h, lane);
+        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane);
         return;
     }
 #endif
 #pragma unroll 1
-    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, w, j, h, lane);
+    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane);
+}
+
+// Stage this wave's latent tile into its LDS region (as stage_z, mlp_chain.h) and return the largest |z| this lane saw: every
+// float4 a lane moves belongs to pixel lane & 31 (the tile is [row-group][32 px] and 64 divides every chunk offset), so the
+// two lane halves' maxima combine to the pixel's.
+__device__ __forceinline__ float stage_z_absmax(float4* __restrict__ zl, const float4* __restrict__ z4, int n4, int lane) {
+    float m = 0.f;
+    for (int base = 0; base < n4; base += 16 * 64) {          // <= 2 passes (rows <= 256)
+        float4 tmp[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                        // 16 independent 1-KiB wave loads in flight
+            const int idx = base + k * 64 + lane;
+            tmp[k] = idx < n4 ? z4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = base + k * 64 + lane;
+            if (idx < n4) zl[idx] = tmp[k];
+            m = absmax_f4(m, tmp[k]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return m;
 }
 
 // k-steps [s0, s1) straight from the latent tensor (wide latents: rows the LDS tile does not hold); row-groups at or
 // beyond rg_end (the tensor's rows / 4) read as zero - the tile of the LAST pixels is followed by nothing
-__device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end,
+__device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end, const float sc,
                                             const u32x4* __restrict__ w, int lane) {
     const int j = lane & 31, h = lane >> 5;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -52,9 +78,9 @@ __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __re
         const float4 t0 = rg < rg_end ? zg[rg * 32 + j] : zero;
         const float4 t1 = rg + 1 < rg_end ? zg[(rg + 1) * 32 + j] : zero;
         const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3(acc, w + s * 12 * 64, bh, bm, bl, lane);
+        BOp b;
+        split8(x, sc, b);
+        step_b3(acc, w + s * kB3StepQuads, b, lane);
     }
 }
 
@@ -90,13 +116,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     float4* z = zlds + wv * zl4;
     const int z4 = (nvp_rows4(d) / 4) * 32;
     const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
-    stage_z(z, zg, min(z4, zl4), lane);
+    float mz = stage_z_absmax(z, zg, min(z4, zl4), lane);     // per-pixel max |z|: the latent's share of the operand scale
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (NVP_SPLIT_H2) {
+        for (int idx = zl4 + lane; idx < z4; idx += 64) mz = absmax_f4(mz, zg[idx]);      // wide latents: the rows the LDS tile does not hold
+        mz = fmaxf(mz, __shfl_xor(mz, 32));
+    }
     const int rg_end = nvp_rows4(d) / 4;
     const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
     const float* tab = reinterpret_cast<const float*>(packed + L.off[5]);      // sir_w0 / sir_b0 / last_w in D-register order
+    const float* winv = tab + kB3ScaleOff + 8;                                 // 2^-e of each weight stream (mlp_layout.h)
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
@@ -110,10 +141,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
         NVP_LAYER_SYNC();
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
-        bias_b3(hm, w, lane);
-        chain_z_b3(hm, z, zs_l, w + NVP_WSTRIDE(12 * 64), lane);
-        chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, w + 12 * 64, lane);
-        lrelu4(hm);
+        const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
+        bias_b3(hm, w, ps.s, lane);
+        chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+        chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
+        lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
         if (SAVE && active) store_ptm(sv + 0 * act, hm, lane);
@@ -142,11 +174,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
             NVP_LAYER_SYNC();
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            bias_b3(acc, w, lane);
-            chain_h_b3(acc, hm, w + NVP_WSTRIDE(12 * 64), lane);
-            chain_z_b3(acc, z, zs_l, w + NVP_WSTRIDE(9 * 12 * 64), lane);
-            chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, w + 9 * 12 * 64, lane);
-            lrelu4(acc);
+            const PxScale ps = px_scale(fmaxf(fmaxf(px_absmax(hm), mz), 1.0f));
+            bias_b3(acc, w, ps.s, lane);
+            chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+            chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
+            chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
+            lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
             if (SAVE && active) store_ptm(sv + (int64_t)k * act, hm, lane);
@@ -156,8 +189,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
             NVP_LAYER_SYNC();
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            bias_b3(acc, w, lane);
-            chain_h_b3(acc, x, w + NVP_WSTRIDE(12 * 64), lane);
+            const PxScale ps = px_scale(fmaxf(px_absmax(x), 1.0f));
+            bias_b3(acc, w, ps.s, lane);
+            chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+            scale4(acc, ps.u * winv[2 + k]);
             if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll
             for (int T = 0; T < 4; ++T)

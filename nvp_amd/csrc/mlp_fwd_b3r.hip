@@ -1,7 +1,7 @@
-// Forward of the modulator MLP + modulated SIREN (R8-R10) on bf16 x 3 split MFMA with WORKGROUP-SHARED weight operands
+// Forward of the modulator MLP + modulated SIREN (R8-R10) on split-operand MFMA (mlp_b3.h) with WORKGROUP-SHARED weight operands
 // (mlp_b3_ring.h): same arithmetic, same saved streams and the same RGB as mlp_fwd_b3.hip, bit for bit - the MFMA
 // sequence per accumulator is unchanged; what changes is where the A operands come from (a two-slot LDS ring filled
-// cooperatively by the workgroup's four waves instead of 12 KiB of per-wave global loads per k-step) and where the
+// cooperatively by the workgroup's four waves instead of 8 / 12 KiB of per-wave global loads per k-step) and where the
 // latent comes from (the B operands of the latent k-steps are read from the PTM4 tensor one step ahead - 2 x 16 B per
 // lane and step - which frees the 64 KiB of LDS the per-wave latent tiles used, so two workgroups still share a CU).
 #include "mlp_b3_ring.h"
@@ -36,15 +36,15 @@ struct ZFeed {
 };
 
 // `ns` latent k-steps; Z holds step 0's rows on entry (fetched one k-step earlier by the caller)
-__device__ __forceinline__ void chain_z_b3_ring(f32x16 (&acc)[4], ZFeed& Z, int ns, Ring& R, int& s, int lane) {
+__device__ __forceinline__ void chain_z_b3_ring(f32x16 (&acc)[4], ZFeed& Z, int ns, const float sc, Ring& R, int& s, int lane) {
 #pragma unroll 1
     for (int u = 0; u < ns; ++u) {
         const u32x4* w = R.begin(s);
         const float x[8] = {Z.t0.x, Z.t0.y, Z.t0.z, Z.t0.w, Z.t1.x, Z.t1.y, Z.t1.z, Z.t1.w};
         if (u + 1 < ns) Z.fetch(u + 1);
-        u32x4 bh, bm, bl;
-        split8(x, bh, bm, bl);
-        step_b3_ring(acc, w, bh, bm, bl, lane);
+        BOp b;
+        split8(x, sc, b);
+        step_b3_ring(acc, w, b, lane);
         R.end(s);
         ++s;
     }
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
                                                                      nvp_mlp_params p, const unsigned* __restrict__ packed,
                                                                      float* __restrict__ rgb, float* __restrict__ saved,
                                                                      int64_t n, int64_t ntiles, int d) {
-    __shared__ __attribute__((aligned(16))) u32x4 ring[kRingSlots * kRingQuads + 4];          // 24 KiB (+ the flag ring's counters)
+    __shared__ __attribute__((aligned(16))) u32x4 ring[kRingSlots * kRingQuads + 4];          // 16 / 24 KiB (+ the flag ring's counters)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
     const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
     const int z4 = (nvp_rows4(d) / 4) * 32;
     const float* tab = reinterpret_cast<const float*>(packed + L.off[5]);      // sir_w0 / sir_b0 / last_w in D-register order
+    const float* winv = tab + kB3ScaleOff + 8;                                 // 2^-e of each weight stream (mlp_layout.h)
     const int64_t px = tile * 32 + j;
     const float s = px < n ? steps[px] : 0.f;
     const int64_t act = ntiles * (int64_t)NVP_H * 32;
@@ -75,6 +76,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
     R.lds = ring; R.g = reinterpret_cast<const u32x4*>(packed); R.total = (int)(L.off[5] / kB3StepU32); R.wv = wv; R.lane = lane;
     ZFeed Z;
     Z.zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4; Z.rg_end = nvp_rows4(d) / 4; Z.j = j; Z.h = h;
+    float mz = 0.f;                                   // per-pixel max |z|: the latent's share of the operand scale (same value as mlp_fwd_b3's)
+    if (NVP_SPLIT_H2) {
+        for (int idx = lane; idx < z4; idx += 64) mz = absmax_f4(mz, Z.zg[idx]);
+        mz = fmaxf(mz, __shfl_xor(mz, 32));
+    }
     Z.fetch(0);
     R.prologue();
     int ks = 0;                                       // running k-step: the packed stream is in consumption order
@@ -85,9 +91,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
     {
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
-        { const u32x4* w = R.begin(ks); bias_b3_ring(hm, w, lane); R.end(ks); ++ks; }
-        chain_z_b3_ring(hm, Z, L.zs, R, ks, lane);
-        lrelu4(hm);
+        const PxScale ps = px_scale(fmaxf(mz, 1.0f));
+        { const u32x4* w = R.begin(ks); bias_b3_ring(hm, w, ps.s, lane); R.end(ks); ++ks; }
+        chain_z_b3_ring(hm, Z, L.zs, ps.s, R, ks, lane);
+        lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
         if (SAVE && active) store_ptm(sv + 0 * act, hm, lane);
@@ -114,10 +121,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
         {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, lane); R.end(ks); ++ks; }
-            chain_h_b3_ring(acc, hm, R, ks, lane, [&] { Z.fetch(0); });
-            chain_z_b3_ring(acc, Z, L.zs, R, ks, lane);
-            lrelu4(acc);
+            const PxScale ps = px_scale(fmaxf(fmaxf(px_absmax(hm), mz), 1.0f));
+            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, ps.s, lane); R.end(ks); ++ks; }
+            chain_h_b3_ring(acc, hm, ps.s, R, ks, lane, [&] { Z.fetch(0); });
+            chain_z_b3_ring(acc, Z, L.zs, ps.s, R, ks, lane);
+            lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
             if (SAVE && active) store_ptm(sv + (int64_t)k * act, hm, lane);
@@ -125,8 +133,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3r_kernel(const float
         {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, lane); R.end(ks); ++ks; }
-            chain_h_b3_ring(acc, x, R, ks, lane);
+            const PxScale ps = px_scale(fmaxf(px_absmax(x), 1.0f));
+            { const u32x4* w = R.begin(ks); bias_b3_ring(acc, w, ps.s, lane); R.end(ks); ++ks; }
+            chain_h_b3_ring(acc, x, ps.s, R, ks, lane);
+            scale4(acc, ps.u * winv[2 + k]);
             if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll
             for (int T = 0; T < 4; ++T)

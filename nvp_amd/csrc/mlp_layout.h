@@ -96,12 +96,19 @@ constexpr int kRecFloats = 644;
 constexpr int kRecRowStride = 33;     // LDS transpose tile [128 features][32 px], conflict-free both ways
 constexpr int kRecTileFloats = 128 * kRecRowStride;
 
-// ---- bf16 x 3 split forward ("b3", mlp_fwd_b3.hip) ---------------------------------------------------------
-// Every fp32 operand is written as hi + mid + lo bf16 (8 + 8 + 8 mantissa bits) and the six products >= 2^-24
-// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (profiles/r01_probe_bf16x3_split_chain.txt: 1.8x the
-// fp32 MFMA skeleton, error below that of an fp32 fma chain).  One k-step covers 16 inputs: lane (i, h) supplies
-// A[out 32T'+i][k = 8h + q], q = 0..7, as one 16-B register quad per part.  Packed stream, in u32x4 units:
-//        stream[((step*4 + T')*3 + part)*64 + lane]          part 0 hi, 1 mid, 2 lo
+// ---- split-operand forward ("b3" kernels, mlp_fwd_b3.hip) ---------------------------------------------------
+// Every fp32 operand is written as a sum of 16-bit parts and the significant part products are accumulated in fp32 by a
+// 16-bit MFMA (32x32x16: 16 inputs per k-step).  Two splits are built (NVP_SPLIT_H2, mlp_b3.h):
+//   * fp16 x 2 (default): x * 2^e = hi + lo in fp16 (11 + 11 significant bits; the power-of-two scale 2^e - per weight
+//     stream, per pixel for activations - keeps the parts inside fp16's range and is divided out of the accumulator),
+//     THREE products (lo*hi, hi*lo, hi*hi) on v_mfma_f32_32x32x16_f16, two operand quads per tile;
+//   * bf16 x 3: x = hi + mid + lo in bf16 (8 + 8 + 8 bits, no scale needed), SIX products >= 2^-24 on
+//     v_mfma_f32_32x32x16_bf16, three operand quads per tile (profiles/r01_probe_bf16x3_split_chain.txt).
+// Both carry an error below that of an fp32 fma chain of the same length (profiles/r02_probe_f16x2_split.txt); fp16 x 2
+// needs half the matrix cycles, two thirds of the weight bytes and half the split instructions.
+// One k-step covers 16 inputs: lane (i, h) supplies A[out 32T'+i][k = 8h + q], q = 0..7, as one 16-B register quad per
+// part.  Packed stream, in u32x4 units (P = kB3Parts):
+//        stream[((step*4 + T')*P + part)*64 + lane]          part 0 hi, then (mid,) lo
 // Steps of a layer: bias step (A[.][k=0] = b, B = e_0), then 8 steps per 128 chained inputs with
 //        in(c, h, q) = 32 (c>>1) + 8 (2 (c&1) + (q>>2)) + 4 h + (q&3)        (= the D registers 8(c&1)..+7 of tile c>>1)
 // then, for the modulator layers, ceil(rows/16) latent steps with in(s, h, q) = 16 s + 8 h + q (zero beyond D).
@@ -110,7 +117,13 @@ struct NvpFwdLayoutB3 {
     int steps[5];      // mod0, mod1, mod2, sir1, sir2
     int64_t off[6];    // u32 offsets, off[5] = total
 };
-constexpr int kB3StepU32 = 4 * 3 * 64 * 4;       // u32 per k-step (12 KiB)
+#ifndef NVP_SPLIT_H2
+#define NVP_SPLIT_H2 1       // 1: fp16 x 2 scaled split, three products; 0: bf16 x 3 split, six products
+#endif
+constexpr int kB3Parts = NVP_SPLIT_H2 ? 2 : 3;   // 16-bit parts per fp32 operand
+constexpr int kB3TileQuads = kB3Parts * 64;      // u32x4 per output tile of a k-step (one quad per lane and part)
+constexpr int kB3StepQuads = 4 * kB3TileQuads;   // u32x4 per k-step of a four-tile stream
+constexpr int kB3StepU32 = kB3StepQuads * 4;     // u32 per k-step (8 KiB fp16 x 2, 12 KiB bf16 x 3)
 constexpr int kB3ZLdsSteps = 9;                  // latent k-steps kept in LDS per wave (144 rows = 18 KiB); the rest is read from the tensor
 
 __host__ __device__ inline bool nvp_fwd_b3_ok(int d) { return ((d + 3) & ~3) <= 256; }     // forward: latent up to 256 rows
@@ -134,13 +147,17 @@ __host__ __device__ inline NvpFwdLayoutB3 nvp_fwd_layout_b3(int d) {
 // Small per-row tables in D-REGISTER order, appended to both b3 packed buffers so that a lane fetches the 16 values of its
 // rows of one 32-row tile with four 16-B loads instead of 16 scalar ones: table id t (0 sir_w0, 1 sir_b0, 2..4 last_w rows
 // 0..2), lane half h, tile T, register r -> value at row 32 T + 8 (r>>2) + 4 h + (r&3):   tab[((t * 2 + h) * 4 + T) * 16 + r]
-constexpr int kB3TabFloats = 5 * 2 * 64;
+// Behind the tables: the power-of-two scales of the packed weight streams (fp16 x 2 split; all 1.0 for bf16 x 3), written by
+// pack_b3_scales_kernel BEFORE the streams are packed: tab[kB3ScaleOff + seg] = 2^e of stream `seg` (forward: layer id
+// 0..4; backward: stream 0..6), tab[kB3ScaleOff + 8 + seg] = 2^-e.
+constexpr int kB3ScaleOff = 5 * 2 * 64;
+constexpr int kB3TabFloats = kB3ScaleOff + 16;
 
 __host__ __device__ inline int nvp_b3_chain_in(int c, int h, int q) { return 32 * (c >> 1) + 8 * (2 * (c & 1) + (q >> 2)) + 4 * h + (q & 3); }
 
 // Backward b3 streams (A = W^T: row i = INPUT index 32T' + i, k = OUTPUT index nvp_b3_chain_in(c, h, q)), 8 steps each,
 // no bias step: 0 sir2^T, 1 sir1^T, 2 mod2h^T, 3 mod1h^T (4 output tiles), 4 z0^T, 5 z1^T, 6 z2^T (zt = 4 or 8 output tiles: a
-// step then holds zt * 3 operand quads per lane; latent rows beyond D are zero).  Offsets in u32.
+// step then holds zt * kB3Parts operand quads per lane; latent rows beyond D are zero).  Offsets in u32.
 __host__ __device__ inline int64_t nvp_bwd_b3_off(int stream, int zt) {
     const int64_t h = 8 * (int64_t)kB3StepU32;
     return stream <= 4 ? stream * h : 4 * h + (stream - 4) * h * (zt / 4);

@@ -49,15 +49,84 @@ __device__ __forceinline__ unsigned nvp_bf16_rne(float f) {           // bf16 bi
 // the D-register-ordered tables behind a b3 packed buffer (mlp_layout.h, kB3TabFloats)
 __global__ __launch_bounds__(256) void pack_b3_tables_kernel(nvp_mlp_params p, float* __restrict__ tab) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= kB3TabFloats) return;
+    if (idx >= kB3ScaleOff) return;
     const int r = idx & 15, T = (idx >> 4) & 3, h = (idx >> 6) & 1, t = idx >> 7;
     const int row = 32 * T + 8 * (r >> 2) + 4 * h + (r & 3);
     tab[idx] = t == 0 ? p.sir_w[0][row] : (t == 1 ? p.sir_b[0][row] : p.last_w[(t - 2) * NVP_H + row]);
 }
 
-// bf16 x 3 forward stream (mlp_layout.h "b3"): one thread per packed u32 = two consecutive k of one part
+// ---- operand split of one packed weight (the same rounding the kernels apply to activations, mlp_b3.h) -----------------------
+// fp16 x 2: v * scale = hi + lo in fp16 (round to nearest even; subnormal parts are kept - the MFMA honours them);
+// bf16 x 3: v = hi + mid + lo in bf16, scale unused (1.0).  Returns the 16 bits of `part`.
+__device__ __forceinline__ unsigned nvp_split_part(float v, float scale, int part) {
+#if NVP_SPLIT_H2
+    const float t = v * scale;                                   // exact: power-of-two scale
+    const _Float16 hi = (_Float16)t;
+    if (part == 0) return (unsigned)__builtin_bit_cast(unsigned short, hi);
+    const _Float16 lo = (_Float16)(t - (float)hi);               // the residual is exact in fp32
+    return (unsigned)__builtin_bit_cast(unsigned short, lo);
+#else
+    const unsigned hi = nvp_bf16_rne(v);
+    const float r1 = v - __uint_as_float(hi << 16);
+    const unsigned mid = nvp_bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(mid << 16);
+    const unsigned lo = nvp_bf16_rne(r2);
+    return (part == 0 ? hi : (part == 1 ? mid : lo)) & 0xffffu;
+#endif
+}
+
+// Power-of-two scale per packed weight stream (fp16 x 2 split): 2^e with max|w| * 2^e in [2^13, 2^14), so that hi and lo stay
+// inside fp16's range (max 65504) and lo is a normal fp16 for every weight within 2^-16 of the largest.  One block per
+// stream; `bwd` selects the backward streams (mlp_layout.h).  A stream's maximum is taken over the whole tensor(s) it is cut
+// from (and the bias for the forward streams).  Non-finite tensors get scale 1.
+__global__ __launch_bounds__(256) void pack_b3_scales_kernel(nvp_mlp_params p, float* __restrict__ tab, int d, int bwd) {
+    const int seg = blockIdx.x;
+    const float* W; const float* b = nullptr; int64_t nw;
+    if (!bwd) {
+        switch (seg) {
+            case 0: W = p.mod_w[0]; b = p.mod_b[0]; nw = (int64_t)NVP_H * d; break;
+            case 1: W = p.mod_w[1]; b = p.mod_b[1]; nw = (int64_t)NVP_H * (NVP_H + d); break;
+            case 2: W = p.mod_w[2]; b = p.mod_b[2]; nw = (int64_t)NVP_H * (NVP_H + d); break;
+            case 3: W = p.sir_w[1]; b = p.sir_b[1]; nw = (int64_t)NVP_H * NVP_H; break;
+            default: W = p.sir_w[2]; b = p.sir_b[2]; nw = (int64_t)NVP_H * NVP_H; break;
+        }
+    } else {
+        switch (seg) {
+            case 0: W = p.sir_w[2]; nw = (int64_t)NVP_H * NVP_H; break;
+            case 1: W = p.sir_w[1]; nw = (int64_t)NVP_H * NVP_H; break;
+            case 2: case 6: W = p.mod_w[2]; nw = (int64_t)NVP_H * (NVP_H + d); break;
+            case 3: case 5: W = p.mod_w[1]; nw = (int64_t)NVP_H * (NVP_H + d); break;
+            default: W = p.mod_w[0]; nw = (int64_t)NVP_H * d; break;
+        }
+    }
+    unsigned m = 0u;
+    for (int64_t i = threadIdx.x; i < nw; i += 256) m = max(m, __float_as_uint(W[i]) & 0x7fffffffu);
+    if (b && threadIdx.x < NVP_H) m = max(m, __float_as_uint(b[threadIdx.x]) & 0x7fffffffu);
+    __shared__ unsigned red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned e = red[0] >> 23;                         // biased exponent of the largest magnitude
+        float sc = 1.0f, inv = 1.0f;
+#if NVP_SPLIT_H2
+        if (e < 255u) {                                          // tensors whose largest weight is below 2^-40 share the scale 2^53:
+            const unsigned ec = max(e, 87u);                     // the kernels multiply it with a per-pixel scale <= 2^63 (mlp_b3.h)
+            sc = __uint_as_float((267u - ec) << 23); inv = __uint_as_float((ec - 13u) << 23);
+        }
+#endif
+        tab[kB3ScaleOff + seg] = sc;
+        tab[kB3ScaleOff + 8 + seg] = inv;
+    }
+}
+
+// split forward stream (mlp_layout.h "b3"): one thread per packed u32 = two consecutive k of one part
 __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
     const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
+    const float* scales = reinterpret_cast<const float*>(out + L.off[5]) + kB3ScaleOff;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= L.off[5]) return;
     int seg = 0;                                   // layer whose stream holds idx (streams are stored in consumption order, not by id)
@@ -66,9 +135,9 @@ __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsi
     const int64_t loc = idx - L.off[seg];
     const int pr = (int)(loc & 3);                 // which pair of the lane's eight k
     const int lane = (int)((loc >> 2) & 63);
-    const int part = (int)((loc >> 8) % 3);
-    const int tp = (int)(((loc >> 8) / 3) & 3);
-    const int step = (int)((loc >> 8) / 12);
+    const int part = (int)((loc >> 8) % kB3Parts);
+    const int tp = (int)(((loc >> 8) / kB3Parts) & 3);
+    const int step = (int)((loc >> 8) / (4 * kB3Parts));
     const int i = lane & 31, h = lane >> 5;
     const int out_row = 32 * tp + i;
     const float* W; const float* b; int ld; bool has_h, has_z;
@@ -95,33 +164,27 @@ __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsi
                 if (in < d) v = W[(int64_t)out_row * ld + (has_h ? NVP_H : 0) + in];
             }
         }
-        // hi / mid / lo with the same rounding the kernel applies to activations
-        const unsigned hi = nvp_bf16_rne(v);
-        const float r1 = v - __uint_as_float(hi << 16);
-        const unsigned mid = nvp_bf16_rne(r1);
-        const float r2 = r1 - __uint_as_float(mid << 16);
-        const unsigned lo = nvp_bf16_rne(r2);
-        const unsigned bits = part == 0 ? hi : (part == 1 ? mid : lo);
-        packed |= (bits & 0xffffu) << (16 * e);
+        packed |= nvp_split_part(v, scales[seg], part) << (16 * e);
     }
     out[idx] = packed;
 }
 
-// bf16 x 3 backward streams (mlp_layout.h): one thread per packed u32
+// split backward streams (mlp_layout.h): one thread per packed u32
 __global__ __launch_bounds__(256) void pack_bwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
     const int zt = nvp_bwd_b3_zt(d);
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= nvp_bwd_b3_off(7, zt)) return;
+    const float* scales = reinterpret_cast<const float*>(out + nvp_bwd_b3_off(7, zt)) + kB3ScaleOff;
     int seg = 0;
     while (idx >= nvp_bwd_b3_off(seg + 1, zt)) ++seg;
     const int64_t loc = idx - nvp_bwd_b3_off(seg, zt);
     const int tiles = seg < 4 ? 4 : zt;            // output tiles per k-step of this stream
     const int pr = (int)(loc & 3);
     const int lane = (int)((loc >> 2) & 63);
-    const int quad = (int)(loc >> 8);              // (step * tiles + tile) * 3 + part
-    const int part = quad % 3;
-    const int tp = (quad / 3) % tiles;
-    const int step = quad / (3 * tiles);
+    const int quad = (int)(loc >> 8);              // (step * tiles + tile) * kB3Parts + part
+    const int part = quad % kB3Parts;
+    const int tp = (quad / kB3Parts) % tiles;
+    const int step = quad / (kB3Parts * tiles);
     const int i = lane & 31, h = lane >> 5;
     const int in = 32 * tp + i;                    // A row = input index
     unsigned packed = 0;
@@ -138,13 +201,7 @@ __global__ __launch_bounds__(256) void pack_bwd_b3_kernel(nvp_mlp_params p, unsi
             case 5: if (in < d) v = p.mod_w[1][(int64_t)o * (NVP_H + d) + NVP_H + in]; break;
             default: if (in < d) v = p.mod_w[2][(int64_t)o * (NVP_H + d) + NVP_H + in]; break;
         }
-        const unsigned hi = nvp_bf16_rne(v);
-        const float r1 = v - __uint_as_float(hi << 16);
-        const unsigned mid = nvp_bf16_rne(r1);
-        const float r2 = r1 - __uint_as_float(mid << 16);
-        const unsigned lo = nvp_bf16_rne(r2);
-        const unsigned bits = part == 0 ? hi : (part == 1 ? mid : lo);
-        packed |= (bits & 0xffffu) << (16 * e);
+        packed |= nvp_split_part(v, scales[seg], part) << (16 * e);
     }
     out[idx] = packed;
     if (zt == 4)        // the consumption-ordered copy the workgroup-shared ring kernel reads (mlp_layout.h)
@@ -201,8 +258,9 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
         const int64_t nb = nvp_fwd_layout_b3(d).off[5];
+        hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, *p, packed + nb, d, 0);
         hipLaunchKernelGGL(pack_fwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
-        hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3TabFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
+        hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3ScaleOff + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
         NVP_LAUNCH_CHECK();
         return 0;
     }
@@ -216,8 +274,9 @@ int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
         const int64_t nb = nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d));
+        hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(7), dim3(256), 0, (hipStream_t)stream, *p, packed + nb, d, 1);
         hipLaunchKernelGGL(pack_bwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
-        hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3TabFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
+        hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3ScaleOff + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
         NVP_LAUNCH_CHECK();
         return 0;
     }

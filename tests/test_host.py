@@ -33,13 +33,13 @@ def test_library_size_queries_match_layout_arithmetic():
     for d in (114, 228, 57):
         zs = (d + 1) // 2
         steps = (1 + zs) + 2 * (65 + zs) + 2 * 65
-        # latents of <= 256 rows use the bf16 x 3 forward stream: (1 + zs) + 2 (1 + 8 + zs) + 2 (1 + 8) k-steps, zs = ceil(rows / 16),
-        # of 4 tiles x 3 parts x 64 lanes x 4 u32
+        # latents of <= 256 rows use the split-operand forward stream: (1 + zs) + 2 (1 + 8 + zs) + 2 (1 + 8) k-steps, zs = ceil(rows / 16),
+        # of 4 tiles x P parts x 64 lanes x 4 u32 (P = 2: fp16 x 2 split, the default build; 3: bf16 x 3)
         rows = (d + 3) // 4 * 4
         zs16 = (rows + 15) // 16
-        # ... plus 5 tables x 2 lane halves x 64 rows in D-register order
-        want = ((1 + zs16) + 2 * (9 + zs16) + 18) * 4 * 3 * 64 * 4 + 640 if rows <= 256 else steps * 64 * 4
-        assert lib.nvp_packed_fwd_floats(d) == want
+        # ... plus 5 tables x 2 lane halves x 64 rows in D-register order and 16 stream scales
+        want = [((1 + zs16) + 2 * (9 + zs16) + 18) * 4 * parts * 64 * 4 + 640 + 16 if rows <= 256 else steps * 64 * 4 for parts in (2, 3)]
+        assert lib.nvp_packed_fwd_floats(d) in want
         H = 128
         total = H * d + H + 2 * (H * (H + d) + H) + (H + H) + 2 * (H * H + H) + 3 * H + 3
         assert lib.nvp_mlp_param_floats(d) == total
