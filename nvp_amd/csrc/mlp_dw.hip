@@ -1,8 +1,9 @@
 // Weight gradients of the modulator MLP + modulated SIREN (the dW half of R12):
 //   dW_k[out][in] = sum_px dY_k[out][px] * X_k[in][px]        db_k[out] = sum_px dY_k[out][px]
 // i.e. GEMMs whose CONTRACTION axis is the pixel axis (1.2 M long) and whose output is tiny
-// (128 x {114,242,128}).  They are run split-K over pixel chunks on the matrix cores - bf16 x 3 split MFMA by
-// default (NVP_DW_B3, fragments split into hi + mid + lo after the LDS read, see mlp_b3.h), fp32 MFMA otherwise:
+// (128 x {114,242,128}).  They are run split-K over pixel chunks on the matrix cores - split-operand 16-bit MFMA by
+// default (NVP_DW_B3; fragments split after the LDS read, see mlp_b3.h: fp16 x 2 with a running block scale per operand,
+// or bf16 x 3), fp32 MFMA otherwise:
 //
 //  * both operands come from the PTM4 streams written by mlp_fwd/mlp_bwd.  A 128-row x 32-px
 //    tile is 16 KiB contiguous: the block stages it through LDS with full-line 16-B loads
@@ -116,9 +117,12 @@ __device__ __forceinline__ void load_stage(Stage<NB>& s, const DwJob& J, int64_t
 }
 
 // `t` is the tile the stage holds (mode 2 needs its temporal steps); lb = the B tile of this thread's group
+// ma / mb: largest magnitude (bit pattern) among the A / B values this thread wrote (the fp16 x 2 split's block scale)
 template <bool XF, int NB>
 __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __restrict__ lb0, const Stage<NB>& s, const DwJob& J,
-                                            const DwArgs& A, const float* __restrict__ tab, int64_t t, int64_t n, int tid) {
+                                            const DwArgs& A, const float* __restrict__ tab, int64_t t, int64_t n, int tid,
+                                            unsigned& ma, unsigned& mb) {
+    ma = 0u; mb = 0u;
 #ifdef NVP_ABL_DW_NOWRITE         // ablation builds only
     if (t != 0x7fffffff) return;
 #endif
@@ -133,6 +137,7 @@ __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __res
         const int f = k * (256 * NB) + tid;
         const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
         la[o] = s.a[k].x; la[o + kRowStride] = s.a[k].y; la[o + 2 * kRowStride] = s.a[k].z; la[o + 3 * kRowStride] = s.a[k].w;
+        if (NVP_SPLIT_H2) ma = max(ma, __float_as_uint(absmax_f4(0.f, s.a[k])));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -151,6 +156,7 @@ __device__ __forceinline__ void write_stage(float* __restrict__ la, float* __res
         }
         lb[o] = ok ? bv[0] : 0.f; lb[o + kRowStride] = ok ? bv[1] : 0.f;
         lb[o + 2 * kRowStride] = ok ? bv[2] : 0.f; lb[o + 3 * kRowStride] = ok ? bv[3] : 0.f;
+        if (NVP_SPLIT_H2 && ok) mb = max(mb, __float_as_uint(absmax_f4(0.f, make_float4(bv[0], bv[1], bv[2], bv[3]))));
         __builtin_amdgcn_sched_barrier(0);       // one float4 at a time: keeps the sincos temporaries of 16 values from piling up
     }
 }
@@ -168,6 +174,31 @@ __device__ __forceinline__ void read_frag(float (&f)[16], const float* __restric
 #pragma unroll
         for (int k = 0; k < 16; ++k) f[k] = p[k];
     }
+}
+
+// ---- running block scale of the fp16 x 2 split (mlp_b3.h) ----------------------------------------------------------------------
+// The contraction axis is the pixel axis, so a scale must be constant along it: one power of two per operand and workgroup,
+// taken from the largest magnitude seen SO FAR in the chunk (the staging threads reduce each tile's maximum while they write
+// it to LDS; the maxima travel through LDS with the tile).  When a tile raises the maximum, the accumulators are multiplied by
+// the (exact, <= 1) ratio of the new to the old scale - a wave-uniform branch taken a handful of times per chunk.  Elements
+// more than 2^-16 below the running maximum lose relative precision (absolute error <= 2^-38 of the maximum), which is far
+// below the fp32 rounding of the sums they are added to.
+constexpr int kMxW = 8;                               // wave slots per operand (two 4-wave groups for the merged jobs)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));      // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));      // row_mirror: every lane holds its row's max
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+// the staging wave `wall` publishes its share of a tile's maxima next to the tile (slot set `par`)
+__device__ __forceinline__ void publish_max(unsigned* __restrict__ mx, int par, int wall, unsigned ma, unsigned mb, int lane) {
+#if NVP_SPLIT_H2
+    ma = wave_umax(ma); mb = wave_umax(mb);
+    if (lane == 0) { mx[(par * 2 + 0) * kMxW + wall] = ma; mx[(par * 2 + 1) * kMxW + wall] = mb; }
+#endif
 }
 
 // KIND 0: the modulator jobs (plain operands); KIND 1: SIREN layers 1-2, whose B operand x_k is rebuilt
@@ -213,7 +244,8 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
 
     // SIREN layer 0's weight and bias (mode 2 rebuilds x_0 from them) live in LDS behind the tile buffers:
     // a global load at the point of use would put a vmcnt(0) wait into the pipelined loop
-    float* tab = lds + 2 * kBufFloats;
+    unsigned* mx = reinterpret_cast<unsigned*>(lds + 2 * kBufFloats);       // [2 slot sets][A | B][kMxW] tile maxima (fp16 x 2 block scale)
+    float* tab = lds + 2 * kBufFloats + 4 * kMxW;
     if (XF && tid < NVP_H) { tab[tid] = A.sir0_wp[tid]; tab[NVP_H + tid] = A.sir0_bp[tid]; }
     if (XF) __syncthreads();
 
@@ -231,10 +263,17 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
 #define NVP_DW_DEPTH 1
 #endif
     Stage<NB> st, st2;
+    unsigned wma, wmb;
     if (t0 < t1) {
         load_stage<XF, NB>(st, J, t0, tid);
-        write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t0, n, tid);
+        write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t0, n, tid, wma, wmb);
+        publish_max(mx, 0, wall, wma, wmb, lane);
     }
+    // block-scale state: running maxima (bit patterns) per operand, the scale S = sA sB the accumulators are in, and 1 / S
+    unsigned runA = __float_as_uint(kTinyMax), runB = __float_as_uint(kTinyMax);
+    PxScale qa = px_scale(kTinyMax), qb = qa;
+    float curS = qa.s * qb.s, curU = qa.u * qb.u;
+    int par = 0;
 #if NVP_DW_DEPTH == 2
     if (t0 + 1 < t1) load_stage<XF, NB>(st, J, t0 + 1, tid);
 #endif
@@ -251,21 +290,41 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
         const float* lb = la + (1 + wb) * kTileFloats;
 #if NVP_DW_B3
         {
-            // bf16 x 3 split MFMA (mlp_b3.h): a lane's 16 pixels of a row are two k-steps of 8 (the SAME pixels on both
-            // operands); fragments are split into hi + mid + lo after the LDS read, six products per (row tile, column
-            // tile, k-step) accumulate in fp32
+            // split-operand MFMA (mlp_b3.h): a lane's 16 pixels of a row are two k-steps of 8 (the SAME pixels on both
+            // operands); fragments are split after the LDS read, the part products per (row tile, column tile, k-step)
+            // accumulate in fp32
+            if (NVP_SPLIT_H2) {
+                const unsigned* mr = mx + par * 2 * kMxW;
+                unsigned mA = 0u, mB = 0u;
+#pragma unroll
+                for (int u = 0; u < 4 * NB; ++u) mA = max(mA, mr[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mB = max(mB, mr[kMxW + 4 * wb + u]);
+                runA = max(runA, (unsigned)__builtin_amdgcn_readfirstlane((int)mA));
+                runB = max(runB, (unsigned)__builtin_amdgcn_readfirstlane((int)mB));
+                qa = px_scale(__uint_as_float(runA)); qb = px_scale(__uint_as_float(runB));
+                const float S = qa.s * qb.s;
+                if (S != curS) {                     // wave-uniform: a tile raised a running maximum
+                    const float ratio = S * curU;   // <= 1, a power of two
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[r][c] *= ratio;
+                    curS = S; curU = qa.u * qb.u;
+                }
+            }
             float fa[16], fb[2][16];
             read_frag(fa, la, 64 * wr + i, h);
 #pragma unroll
             for (int c = 0; c < 2; ++c) read_frag(fb[c], lb, 64 * wc + 32 * c + i, h);
-            u32x4 pb[2][2][3];
+            BOp pb[2][2];
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const float x[8] = {fb[c][8 * s2], fb[c][8 * s2 + 1], fb[c][8 * s2 + 2], fb[c][8 * s2 + 3],
                                         fb[c][8 * s2 + 4], fb[c][8 * s2 + 5], fb[c][8 * s2 + 6], fb[c][8 * s2 + 7]};
-                    split8_bf3(x, pb[c][s2][0], pb[c][s2][1], pb[c][s2][2]);
+                    split8(x, qb.s, pb[c][s2]);
                 }
 #pragma unroll
             for (int r2 = 0; r2 < 2; ++r2) {
@@ -277,17 +336,10 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const float x[8] = {fa[8 * s2], fa[8 * s2 + 1], fa[8 * s2 + 2], fa[8 * s2 + 3], fa[8 * s2 + 4], fa[8 * s2 + 5], fa[8 * s2 + 6], fa[8 * s2 + 7]};
-                    u32x4 ah, am, al;
-                    split8_bf3(x, ah, am, al);
+                    BOp pa;
+                    split8(x, qa.s, pa);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        acc[r2][c] = mf_bf16(al, pb[c][s2][0], acc[r2][c]);
-                        acc[r2][c] = mf_bf16(ah, pb[c][s2][2], acc[r2][c]);
-                        acc[r2][c] = mf_bf16(am, pb[c][s2][1], acc[r2][c]);
-                        acc[r2][c] = mf_bf16(am, pb[c][s2][0], acc[r2][c]);
-                        acc[r2][c] = mf_bf16(ah, pb[c][s2][1], acc[r2][c]);
-                        acc[r2][c] = mf_bf16(ah, pb[c][s2][0], acc[r2][c]);
-                    }
+                    for (int c = 0; c < 2; ++c) mac_parts(acc[r2][c], pa.p, pb[c][s2]);
                 }
             }
         }
@@ -323,10 +375,12 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
 #endif
         if (BUFS == 1) {
             __syncthreads();                        // everyone finished reading the single buffer
-            if (more) write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t + 1, n, tid);
+            if (more) write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t + 1, n, tid, wma, wmb);
         } else {
-            if (more) write_stage<XF, NB>(lds + (cur ^ 1) * kBufFloats, lds + (cur ^ 1) * kBufFloats + kTileFloats, st, J, A, tab, t + 1, n, tid);
+            if (more) write_stage<XF, NB>(lds + (cur ^ 1) * kBufFloats, lds + (cur ^ 1) * kBufFloats + kTileFloats, st, J, A, tab, t + 1, n, tid, wma, wmb);
         }
+        if (more) publish_max(mx, par ^ 1, wall, wma, wmb, lane);
+        par ^= 1;
 #if NVP_DW_DEPTH == 2
         st = st2;
 #endif
@@ -347,7 +401,7 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = 64 * wr + 32 * r2 + nvp_frag_row(r, h);
-                        part[woff + (int64_t)row * J.ld + col] = acc[r2][c][r];
+                        part[woff + (int64_t)row * J.ld + col] = (NVP_DW_B3 && NVP_SPLIT_H2) ? acc[r2][c][r] * curU : acc[r2][c][r];
                     }
             }
         }
@@ -475,9 +529,10 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
     // GEMM launches: plain jobs, merged jobs (512 threads, three LDS tiles per buffer), transform jobs; plus the record sums
-    const size_t lds_bytes = (2 * 2 * kTileFloats + 2 * NVP_H) * sizeof(float);
-    const size_t lds_bytes0 = (NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats * sizeof(float);
-    const size_t lds_bytes2 = 2 * 3 * kTileFloats * sizeof(float);          // 108 KiB: one 8-wave workgroup per CU
+    // every variant: 2 x kBufFloats of tile buffers (the kernel places the tile maxima and the table behind them), 4 kMxW maxima
+    const size_t lds_bytes = (2 * 2 * kTileFloats + 4 * kMxW + 2 * NVP_H) * sizeof(float);
+    const size_t lds_bytes0 = (2 * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
+    const size_t lds_bytes2 = (2 * 3 * kTileFloats + 4 * kMxW) * sizeof(float);          // 108 KiB: one 8-wave workgroup per CU
     if (n0) hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     if (n2) hipLaunchKernelGGL((mlp_dw_kernel<0, 2>), dim3(n_chunks * n2), dim3(512), lds_bytes2, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
