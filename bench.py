@@ -75,18 +75,24 @@ def work_per_pixel(F: int):
         "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 2 * 128 * 128 + 2 * 128 * 128 + 3 * 128),              # dX of every layer but SIREN 0
         "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),       # dW: same MACs as fwd
     }
+    R = (D + 3) // 4 * 4          # PTM4 rows of the latent
     byts = {
         # gather: coords 12 + 192 corner F-vectors + 9 sparse F-vectors (4F bytes each) + latent write 4D
         "nvp_encode_fwd": 12 + (192 + 9) * 4 * F + 4 * D,
         # scatter: coords 12 + latent-grad read 4D + the same cells read-modify-written once
         "nvp_encode_bwd": 12 + 4 * D + (192 + 9) * 4 * F,
+        # MLP stages: the activation / gradient streams they must move (128 rows x 4 B each; weights are L2-resident)
+        "nvp_mlp_fwd": 4 * R + 4 + 5 * 512 + 12,                    # latent + step in, h0 h1 h2 q1 q2 + RGB out
+        "nvp_mlp_bwd_dx": 12 + 4 + 5 * 512 + 5 * 512 + 80 + 4 * R,  # drgb + step + 5 saved streams in; dp0-2 dq1-2, tile records, latent gradient out
+        "nvp_mlp_bwd_dw": 5 * 512 + 4 * R + 3 * 512,                # every operand stream once: dp0-2 dq1-2, z, h0 h1 q1 (jobs that share a stream re-read it)
     }
     return flop, byts
 
 
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_MFMA_B3 = 2516.6e12 / 6    # bf16 dense peak / six bf16 products per fp32 product = 419 TF fp32-equivalent
-# stages that run on bf16x3 split MFMA: forward, backward chain and dW GEMMs (latents <= 256 rows)
+PEAK_MFMA_16 = 2516.6e12        # bf16 / fp16 dense peak (32x32x16 forms)
+# stages that run on split-operand 16-bit MFMA: forward, backward chain and dW GEMMs (latents <= 256 rows); their
+# peak in fp32-equivalent FLOP is the 16-bit dense peak / the products issued per fp32 product (3: fp16 x 2 split, 6: bf16 x 3)
 B3_STAGES = ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
 PEAK_HBM = 8.0e12
 
@@ -252,31 +258,41 @@ def main():
         if os.path.exists(tpath) and args.config == "s":
             traffic = json.load(open(tpath))
         dom = max(kms, key=kms.get) if kms else None
-        roof = None
-        if dom in FLOP_PX:
-            ach = FLOP_PX[dom] * N_PX / (kms[dom] * 1e-3)
-            pk = PEAK_MFMA_B3 if dom in B3_STAGES else PEAK_MFMA_F32
-            roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach / 1e12, 3), "peak": round(pk / 1e12, 1),
-                    "unit": "TFLOP/s", "frac": round(ach / pk, 4), "traffic": traffic.get(dom),
-                    "ms_per_launch": kms[dom], "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
-        elif dom in BYTES_PX:
-            ach = BYTES_PX[dom] * N_PX / (kms[dom] * 1e-3)
-            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9,
-                    "unit": "GB/s", "frac": round(ach / PEAK_HBM, 4), "traffic": traffic.get(dom),
-                    "ms_per_launch": kms[dom], "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
-        # every hot-path stage against its own roofline (SURVEY 8d asks for the isolated gather/scatter fractions too)
-        stages = {}
-        for k, ms in kms.items():
+        products = int(_lib.load().nvp_mlp_mfma_products())         # 3: fp16 x 2 split, 6: bf16 x 3 split, 1: fp32 MFMA
+        pk_mlp = PEAK_MFMA_16 / products if products > 1 else PEAK_MFMA_F32
+        split_name = {3: "fp16x2 scaled split, 3 products (fp32-equivalent FLOP)", 6: "bf16x3 split, 6 products (fp32-equivalent FLOP)", 1: "fp32"}[products]
+
+        # every hot-path stage against its rooflines (SURVEY 8d asks for the isolated gather/scatter fractions too).  The MLP
+        # stages are priced against BOTH the matrix peak of their arithmetic and HBM (their algorithmic stream bytes); the
+        # roof a stage sits closer to is reported as its bound.
+        def price(k, ms):
+            out = {"ms": ms}
+            if k in BYTES_PX:
+                a = BYTES_PX[k] * N_PX / (ms * 1e-3)
+                out.update({"achieved_gbs": round(a / 1e9, 1), "hbm_frac": round(a / PEAK_HBM, 4),
+                            "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None})
             if k in FLOP_PX:
                 a = FLOP_PX[k] * N_PX / (ms * 1e-3)
-                b3 = k in B3_STAGES
-                pk = PEAK_MFMA_B3 if b3 else PEAK_MFMA_F32
-                stages[k] = {"ms": ms, "bound": "mfma", "mfma": "bf16x3 split (fp32-equivalent FLOP)" if b3 else "fp32",
-                             "achieved_tflops": round(a / 1e12, 2), "peak_tflops": round(pk / 1e12, 1), "frac": round(a / pk, 4)}
-            elif k in BYTES_PX:
-                a = BYTES_PX[k] * N_PX / (ms * 1e-3)
-                stages[k] = {"ms": ms, "bound": "hbm", "achieved_gbs": round(a / 1e9, 1), "frac": round(a / PEAK_HBM, 4),
-                             "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None}
+                out.update({"mfma": split_name, "achieved_tflops": round(a / 1e12, 2), "peak_tflops": round(pk_mlp / 1e12, 1),
+                            "mfma_frac": round(a / pk_mlp, 4)})
+            hb, mf = out.get("hbm_frac", 0.0), out.get("mfma_frac", 0.0)
+            out["bound"] = "hbm" if hb >= mf else "mfma"
+            out["frac"] = max(hb, mf)
+            return out
+        stages = {k: price(k, ms) for k, ms in kms.items() if k in FLOP_PX or k in BYTES_PX}
+        roof = None
+        if dom in stages:
+            st = stages[dom]
+            if st["bound"] == "mfma":
+                roof = {"kernel": dom, "bound": "mfma", "achieved": st["achieved_tflops"], "peak": st["peak_tflops"], "unit": "TFLOP/s",
+                        "frac": st["mfma_frac"], "traffic": traffic.get(dom), "ms_per_launch": kms[dom],
+                        "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
+            else:
+                roof = {"kernel": dom, "bound": "hbm", "achieved": st["achieved_gbs"], "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                        "frac": st["hbm_frac"], "traffic": traffic.get(dom), "ms_per_launch": kms[dom],
+                        "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
+                if dom in FLOP_PX:
+                    roof["mfma_frac"] = st["mfma_frac"]
         hot_ms = sum(kms.values())
         n_params = sum(p.numel() for p in parallel.unique_parameters(model))
         exchange = {"replicated": "chunked all-reduce (grid grads async under the dW GEMMs) + AdamW on every rank",
@@ -289,8 +305,10 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 tensors and fp32 accumulation everywhere; the MLP GEMMs (forward, backward chain, dW) issue each fp32 product as "
-                          "six bf16 MFMA products of hi+mid+lo operand splits (error below an fp32 fma chain, DESIGN.md 4.1a); roofline peak for "
-                          "those stages = bf16 dense peak / 6 in fp32-equivalent FLOP",
+                          + {3: "three fp16 MFMA products of a power-of-two-scaled hi+lo operand split",
+                             6: "six bf16 MFMA products of hi+mid+lo operand splits", 1: "one fp32 MFMA product"}[products] +
+                          " (error below an fp32 fma chain, DESIGN.md 4.1a); matrix peak for those stages = 16-bit dense peak / products "
+                          "in fp32-equivalent FLOP",
             "config": {"workload": wl["label"] + f", {N_PX} (t,x,y) samples per GPU per step, random-init parameters",
                        "pixels_per_gpu_step": N_PX, "global_batch_pixels": world * N_PX,
                        "parallelism": f"dp{world}" if world > 1 else "single",

@@ -100,6 +100,10 @@ typedef struct nvp_mlp_grads {
 
 /* Library / device info ----------------------------------------------------------- */
 const char* nvp_version(void);
+/* How this build issues one fp32 product of the MLP GEMMs on the matrix cores: 3 = fp16 x 2 scaled operand split (three
+ * v_mfma_f32_32x32x16_f16 products, the default), 6 = bf16 x 3 split (six bf16 products, -DNVP_SPLIT_H2=0), 1 = fp32 MFMA
+ * (-DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0).  Results of all three agree within the parity tolerances; only the rate differs. */
+int32_t nvp_mlp_mfma_products(void);
 /* Number of floats of each workspace, so the host can allocate with torch.empty. */
 int64_t nvp_packed_fwd_floats(int32_t latent_dim);
 int64_t nvp_packed_bwd_floats(int32_t latent_dim);

@@ -95,11 +95,12 @@ SIGNATURES = {
     "nvp_mlp_param_floats": [_i32],
     "nvp_latent_rows": [_i32],
     "nvp_version": [],
+    "nvp_mlp_mfma_products": [],
 }
 _RESTYPES = {
     "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64,
     "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
-    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32,
+    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32, "nvp_mlp_mfma_products": _i32,
 }
 
 _lib: Optional[C.CDLL] = None

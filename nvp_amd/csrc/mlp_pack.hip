@@ -252,7 +252,8 @@ int64_t nvp_dw_partial_floats(int32_t d, int32_t n_chunks) {
 }
 int32_t nvp_latent_rows(int32_t d) { return nvp_rows4(d); }
 int32_t nvp_dz_stride(int32_t d) { return nvp_dz_stride_dev(d); }
-const char* nvp_version(void) { return "nvp_hip 0.1 (gfx950)"; }
+const char* nvp_version(void) { return "nvp_hip 0.2 (gfx950)"; }
+int32_t nvp_mlp_mfma_products(void) { return !(NVP_FWD_B3 && NVP_BWD_B3) ? 1 : (NVP_SPLIT_H2 ? 3 : 6); }
 
 int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* stream) {
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
