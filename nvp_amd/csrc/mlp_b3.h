@@ -79,6 +79,10 @@ __device__ __forceinline__ f32x16 mf_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+#ifndef NVP_SPLIT_ASM
+#define NVP_SPLIT_ASM 0          // 1: hand-selected v_fma_mix sequence for the fp16 x 2 split, 2 instead of 3 instructions per value, same bits -
+                                 // measured SLOWER (dW 1.80 vs 1.73 ms, chains unchanged: four dependent partial-register writes per pair)
+#endif
 // 8 floats -> parts.  fp16 x 2: of x * s.
 __device__ __forceinline__ void split8(const float (&x)[8], const float s, BOp& b) {
 #ifdef NVP_ABL_NOSPLIT          // ablation builds only (tools/ablate_b3.sh): one conversion per pair, no residuals
@@ -92,11 +96,25 @@ __device__ __forceinline__ void split8(const float (&x)[8], const float s, BOp& 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float a = x[2 * p], c = x[2 * p + 1];
+#if NVP_SPLIT_ASM
+        // Two instructions per value: v_fma_mix{lo,hi}_f16 computes fma(x, s, c) in fp32 and writes the fp16 result into one
+        // half of the destination; for the residual the addend is the matching HALF of the packed hi register (op_sel),
+        // so hi is never unpacked.  (hipcc's own selection of the C code below spends three: it converts hi twice.)
+        unsigned hh, ll;
+        asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+            "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+            "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(hh), "=&v"(ll) : "v"(a), "v"(c), "v"(s));
+        b.p[0][p] = hh;
+        b.p[1][p] = ll;
+#else
         const f16x2 h = {(_Float16)(a * s), (_Float16)(c * s)};
         // residual x s - hi is exact in fp32 (hipcc: v_fma_mixlo/hi_f16 - scale, subtraction and conversion in one instruction)
         const f16x2 l = {(_Float16)__builtin_fmaf(a, s, -(float)h.x), (_Float16)__builtin_fmaf(c, s, -(float)h.y)};
         b.p[0][p] = __builtin_bit_cast(unsigned, h);
         b.p[1][p] = __builtin_bit_cast(unsigned, l);
+#endif
     }
 #else
     split8_bf3(x, b.p[0], b.p[1], b.p[2]);

@@ -79,7 +79,7 @@ __device__ __forceinline__ unsigned nvp_split_part(float v, float scale, int par
 // inside fp16's range (max 65504) and lo is a normal fp16 for every weight within 2^-16 of the largest.  One block per
 // stream; `bwd` selects the backward streams (mlp_layout.h).  A stream's maximum is taken over the whole tensor(s) it is cut
 // from (and the bias for the forward streams).  Non-finite tensors get scale 1.
-__global__ __launch_bounds__(256) void pack_b3_scales_kernel(nvp_mlp_params p, float* __restrict__ tab, int d, int bwd) {
+__global__ __launch_bounds__(1024) void pack_b3_scales_kernel(nvp_mlp_params p, float* __restrict__ tab, int d, int bwd) {
     const int seg = blockIdx.x;
     const float* W; const float* b = nullptr; int64_t nw;
     if (!bwd) {
@@ -99,15 +99,24 @@ __global__ __launch_bounds__(256) void pack_b3_scales_kernel(nvp_mlp_params p, f
             default: W = p.mod_w[0]; nw = (int64_t)NVP_H * d; break;
         }
     }
+    // 1024 threads, 8 independent loads in flight per thread: the largest tensor (128 x 356) is four rounds
     unsigned m = 0u;
-    for (int64_t i = threadIdx.x; i < nw; i += 256) m = max(m, __float_as_uint(W[i]) & 0x7fffffffu);
+    for (int64_t i0 = threadIdx.x; i0 < nw; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < nw ? W[i0 + u * 1024] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = max(m, __float_as_uint(v[u]) & 0x7fffffffu);
+    }
     if (b && threadIdx.x < NVP_H) m = max(m, __float_as_uint(b[threadIdx.x]) & 0x7fffffffu);
-    __shared__ unsigned red[256];
-    red[threadIdx.x] = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) red[0] = max(red[0], red[w]);
     }
     if (threadIdx.x == 0) {
         const unsigned e = red[0] >> 23;                         // biased exponent of the largest magnitude
@@ -259,7 +268,7 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
         const int64_t nb = nvp_fwd_layout_b3(d).off[5];
-        hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(5), dim3(256), 0, (hipStream_t)stream, *p, packed + nb, d, 0);
+        hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(5), dim3(1024), 0, (hipStream_t)stream, *p, packed + nb, d, 0);
         hipLaunchKernelGGL(pack_fwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
         hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3ScaleOff + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
         NVP_LAUNCH_CHECK();
@@ -275,7 +284,7 @@ int nvp_mlp_pack_bwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
         const int64_t nb = nvp_bwd_b3_off(7, nvp_bwd_b3_zt(d));
-        hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(7), dim3(256), 0, (hipStream_t)stream, *p, packed + nb, d, 1);
+        hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(7), dim3(1024), 0, (hipStream_t)stream, *p, packed + nb, d, 1);
         hipLaunchKernelGGL(pack_bwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
         hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3ScaleOff + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);
         NVP_LAUNCH_CHECK();
