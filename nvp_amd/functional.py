@@ -48,6 +48,8 @@ class KernelTimer:
 
 
 TIMER = None      # set to a KernelTimer() to time launches
+DW_SIDE_STREAM = os.environ.get("NVP_DW_SIDE_STREAM", "0") == "1"      # experiment: dW GEMMs concurrent with the grid scatter
+_SIDE = None
 
 # Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
 # (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
@@ -204,12 +206,25 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     # lm (optional, fused NVP path with y-sorted batches): the scatter's level-major buffers for the xy / yt planes
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
                                L.ptr(dy), L.ptr(dz_rows), C.byref(lm) if lm is not None else None, n, d, stream), "nvp_mlp_bwd_dx")
-    if between is not None:
-        between(dz_rows)
     grads = [_grad_buffer(t) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
+    if DW_SIDE_STREAM and between is not None:
+        # experiment (NVP_DW_SIDE_STREAM=1): the dW GEMMs on a second stream, concurrent with the grid scatter
+        global _SIDE
+        if _SIDE is None:
+            _SIDE = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        _SIDE.wait_stream(main)
+        with torch.cuda.stream(_SIDE):
+            L.check(lib.nvp_mlp_bwd_dw(L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), C.byref(pstruct),
+                                       L.ptr(partials), nch, C.byref(gstruct), n, d, L.stream_ptr()), "nvp_mlp_bwd_dw")
+        between(dz_rows)
+        main.wait_stream(_SIDE)
+        return dz_rows, grads
+    if between is not None:
+        between(dz_rows)
     L.check(_call("nvp_mlp_bwd_dw", lib.nvp_mlp_bwd_dw, L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), C.byref(pstruct),
                                L.ptr(partials), nch, C.byref(gstruct), n, d, stream), "nvp_mlp_bwd_dw")
     return dz_rows, grads
