@@ -225,7 +225,8 @@ def main():
         tune = {}
         for cand in ("sharded", "a2a", "replicated"):
             st = make_state(cand)
-            one_step(st)                                  # first step of a scheme allocates / connects
+            one_step(st)                                  # first steps of a scheme allocate / connect (RCCL sets channels up lazily
+            one_step(st)                                  # per collective and message size: seen as one 400-ms step)
             tune[cand] = round(timed(st, 3)[0] / 3 * 1e3, 3)
             del st
             torch.cuda.empty_cache()

@@ -915,8 +915,8 @@ def test_sorted_hint_is_checked_on_request(monkeypatch):
 def test_kernel_variants_are_bit_identical(tmp_path):
     """The alternative kernels kept behind environment switches (read once per process by libnvp_hip.so) - the LDS-staged gather
     (NVP_ENCODE_LDS=1), the workgroup-shared weight ring of the forward chain (NVP_MLP_RING_FWD=1), the per-wave backward
-    chain (NVP_MLP_RING_BWD=0), the merged dW jobs (NVP_DW_MERGE=1) and the row-major latent-gradient hand-over to the scatter
-    (NVP_DZ_LEVEL_MAJOR=0) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
+    chain (NVP_MLP_RING_BWD=0), the merged dW jobs (NVP_DW_MERGE=1), the row-major latent-gradient hand-over to the scatter
+    (NVP_DZ_LEVEL_MAJOR=0), all dW jobs in one launch (NVP_DW_ONE_LAUNCH=1) on a second stream (NVP_DW_SIDE_STREAM=1) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
     accumulator, same index arithmetic; only where operands are staged differs)."""
     import subprocess
     import sys
@@ -924,12 +924,14 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     outs = []
     for k, env in enumerate(({"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # the defaults
                              {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1",
-                              "NVP_DZ_LEVEL_MAJOR": "0"})):                                                              # every alternative
+                              "NVP_DZ_LEVEL_MAJOR": "0"},                                                                # every alternative
+                             {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1"})):                                    # dW launch experiments
         out = str(tmp_path / f"v{k}.npz")
         subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300,
                        env={**os.environ, **env})
         outs.append(np.load(out))
-    a, b = outs
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 19
-    for k in a.files:
-        assert np.array_equal(a[k], b[k], equal_nan=True), f"{k} differs between kernel variants (max {np.abs(a[k] - b[k]).max()})"
+    a = outs[0]
+    for b in outs[1:]:
+        assert sorted(a.files) == sorted(b.files) and len(a.files) == 19
+        for k in a.files:
+            assert np.array_equal(a[k], b[k], equal_nan=True), f"{k} differs between kernel variants (max {np.abs(a[k] - b[k]).max()})"
