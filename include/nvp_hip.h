@@ -43,8 +43,12 @@ extern "C" {
 #define NVP_ERR_UNSUPPORTED (-2)
 
 /* nvp_encode_fwd / nvp_encode_bwd flags */
-#define NVP_DZ_PLANES_READY 2      /* nvp_encode_bwd: the xy / yt planes' latent gradients already sit level-major in the workspace
-                                      (written by nvp_mlp_bwd_dx through nvp_encode_bwd_prepare's pointers); needs NVP_COORDS_SORTED_BY_Y */
+#define NVP_DZ_PLANES_READY 2      /* nvp_encode_bwd: the xy / yt planes' latent gradients already sit level-major in the workspace and
+                                      the sparse columns' max|dz| in its slots (both written by nvp_mlp_bwd_dx through
+                                      nvp_encode_bwd_prepare's pointers); needs NVP_COORDS_SORTED_BY_Y */
+#define NVP_SCATTER_SPARSE_ONLY 8  /* nvp_encode_bwd (with NVP_DZ_PLANES_READY): only d_emb is produced by this call ... */
+#define NVP_SCATTER_DENSE_ONLY 16  /* ... only the three keyframe gradients.  Two calls (sparse first: 80 % of the gradient bytes) let a
+                                      data-parallel host start exchanging the sparse grid's gradient while the dense planes scatter. */
 #define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: the scatter skips one radix sort,
                                       the gather stages the xy / yt grid rows of a pixel run in LDS */
 
@@ -156,7 +160,9 @@ int64_t nvp_encode_bwd_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const
  * set NVP_DZ_PLANES_READY | NVP_COORDS_SORTED_BY_Y for nvp_encode_bwd on the SAME workspace.  Gradients are bit-identical. */
 typedef struct nvp_scatter_lm {
     float* dzs[2];          /* xy, yt: [n_levels][n][F] */
-    uint32_t* dzmax;        /* 256 slots, bit patterns of max|dz| */
+    uint32_t* dzmax;        /* 256 slots, bit patterns of max|dz| over the two planes */
+    uint32_t* sdzmax;       /* 256 slots, the same for the sparse grid's columns [scol0, scol0 + scols) of the latent gradient */
+    int32_t scol0, scols;
 } nvp_scatter_lm;
 int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                            const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, nvp_scatter_lm* out, void* stream);

@@ -20,6 +20,8 @@ LIB_PATH = os.environ.get("NVP_HIP_LIB") or os.path.join(_HERE, "csrc", "libnvp_
 NVP_MAX_LEVELS = 16
 COORDS_SORTED_BY_Y = 1
 DZ_PLANES_READY = 2
+SCATTER_SPARSE_ONLY = 8      # nvp_encode_bwd in two calls (needs DZ_PLANES_READY): sparse grid first ...
+SCATTER_DENSE_ONLY = 16      # ... then the three dense planes
 GRID_POS_FMA, GRID_INTERP_FMA, GRID_CLAMP = 1, 2, 4      # nvp_levels.flags (include/nvp_hip.h)
 HIDDEN = 128
 TILE = 32
@@ -54,7 +56,7 @@ MlpGrads = MlpParams  # identical layout (const-ness only differs in C)
 
 class ScatterLm(C.Structure):
     """struct nvp_scatter_lm - device pointers into the scatter workspace (nvp_encode_bwd_prepare)."""
-    _fields_ = [("dzs", C.c_void_p * 2), ("dzmax", C.c_void_p)]
+    _fields_ = [("dzs", C.c_void_p * 2), ("dzmax", C.c_void_p), ("sdzmax", C.c_void_p), ("scol0", C.c_int32), ("scols", C.c_int32)]
 
 
 class AdamwSeg(C.Structure):

@@ -129,13 +129,13 @@ int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape*
     for (int p = 0; p < 3; ++p) { W.cs[p] = o; o = align_up(o + n * 8); }
     for (int p = 0; p < 3; ++p) { W.dzs[p] = o; o = align_up(o + (size_t)n * lv[p]->n_levels * lv[p]->n_features * 4); }
     for (int p = 0; p < 3; ++p) { W.rowstart[p] = o; o = align_up(o + (size_t)P.rs_total[p] * 4); }
-    W.dzmax = o; o = align_up(o + kMaxSlots * 4);
+    W.dzmax = o; o += kMaxSlots * 4;
+    W.sdzmax = o; o = align_up(o + kMaxSlots * 4);             // adjacent to dzmax: nvp_encode_bwd_prepare zeroes both with one memset
     W.slabs = o; o = align_up(o + (size_t)P.slab_floats * 4);
     W.skey_in = o; o = align_up(o + n * 4);
     W.skey_out = o; o = align_up(o + n * 4);
     W.sorder = o; o = align_up(o + n * 4);
     W.srowstart = o; o = align_up(o + ((size_t)sh->t_res * sh->x_res + 1) * 4);
-    W.sdzmax = o; o = align_up(o + kMaxSlots * 4);
     size_t tmp = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
                                              (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
@@ -521,88 +521,96 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     float* kx = (float*)(ws + W.keys_in[1]);
     int* iota = (int*)(ws + W.iota);
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
-    const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;        // xy / yt latent gradients already level-major in ws
-    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
-                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, n);
-    size_t tmp = W.sort_tmp_bytes;
-    for (int k = 0; k < 2; ++k) {
-        if (k == 0 && y_sorted) continue;          // the batch already arrives in ascending y: identity order
-        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[k]), (float*)(ws + W.keys_out[k]),
-                                                 (const int*)iota, (int*)(ws + W.order[k]), (size_t)n, 0, 32, s);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (!planes_ready) {          // otherwise nvp_encode_bwd_prepare zeroed the slots before the chain kernel fed them
-        hipError_t me = hipMemsetAsync(ws + W.dzmax, 0, kMaxSlots * 4, s);
-        if (me != hipSuccess) return (int)me;
-    }
-
-    // planes in latent order: xy <- (x, y) sorted by y ; yt <- (t, y) sorted by y ; xt <- (t, x) sorted by x
-    PermArgs PA;
-    int col = 0;
-    const int c0[3] = {1, 0, 0}, c1[3] = {2, 2, 1}, ord[3] = {0, 0, 1};
-    for (int p = 0; p < 3; ++p) {
-        PA.order[p] = (ord[p] == 0 && y_sorted) ? (const int*)iota : (const int*)(ws + W.order[ord[p]]);
-        PA.cs[p] = (float2*)(ws + W.cs[p]);
-        PA.dzs[p] = (float*)(ws + W.dzs[p]);
-        PA.col0[p] = col; PA.nlev[p] = lv[p]->n_levels; PA.c0[p] = c0[p]; PA.c1[p] = c1[p];
-        col += lv[p]->n_levels * lv[p]->n_features;
-    }
-    PA.scol0 = col; PA.scols = 9 * sh->n_features; PA.sdzmax = (unsigned*)(ws + W.sdzmax);
-    if ((col & 3) != 0 || col + ((PA.scols + 3) & ~3) > dz_stride) return NVP_ERR_UNSUPPORTED;
-    {
-        hipError_t me2 = hipMemsetAsync(PA.sdzmax, 0, kMaxSlots * 4, s);
-        if (me2 != hipSuccess) return (int)me2;
-    }
-    if (PA.scols > 16 * F) return NVP_ERR_UNSUPPORTED;         // the sparse columns are scanned by the plane's own lanes
-    PA.plane0 = planes_ready ? 2 : 0;
-    hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + PermCfg<F>::PIX - 1) / PermCfg<F>::PIX), 3 - PA.plane0), dim3(256),
-                       (size_t)PermCfg<F>::PIX * PermCfg<F>::STRIDE * sizeof(float), s, coords, dz, dz_stride, PA, (unsigned*)(ws + W.dzmax), n);
-
-    RowArgs RA;
-    int rs_max = 0;
-    for (int p = 0; p < 3; ++p) {
-        RA.cs[p] = (const float2*)(ws + W.cs[p]);
-        RA.rowstart[p] = (int*)(ws + W.rowstart[p]);
-        RA.lv[p] = *lv[p];
-        for (int l = 0; l < lv[p]->n_levels; ++l) RA.rs_off[p][l] = P.lp[p][l].rs_off;
-        RA.rs_total[p] = P.rs_total[p];
-        if (P.rs_total[p] > rs_max) rs_max = P.rs_total[p];
-    }
-    hipLaunchKernelGGL(rowstart_kernel, dim3((rs_max + 255) / 256, 3), dim3(256), 0, s, RA, n);
-
-    BandArgs BA;
-    BA.plan = P;
-    float* grads[3] = {g0, g1, g2};
-    for (int p = 0; p < 3; ++p) {
-        BA.lv[p] = *lv[p];
-        BA.cs[p] = (const float2*)(ws + W.cs[p]);
-        BA.dzs[p] = (const float*)(ws + W.dzs[p]);
-        BA.rowstart[p] = (const int*)(ws + W.rowstart[p]);
-        BA.grad[p] = grads[p];
-    }
-    BA.slabs = (float*)(ws + W.slabs);
-    BA.dzmax = (const unsigned*)(ws + W.dzmax);
+    // xy / yt latent gradients already level-major in ws AND the sparse columns' max|dz| already in its slots (chain kernel)
+    const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;
+    const bool do_sparse = !(flags & NVP_SCATTER_DENSE_ONLY), do_dense = !(flags & NVP_SCATTER_SPARSE_ONLY);
+    if ((!do_sparse || !do_dense) && !planes_ready) return NVP_ERR_BADARG;      // the split calls need the sparse max from the chain kernel
     int hb = 1;
     while (((int64_t)1 << hb) < n) ++hb;
-    BA.headroom_bits = hb + 1;
-    hipLaunchKernelGGL((band_kernel<F>), dim3(P.total_blocks), dim3(kBandThreads), (size_t)P.entries * 8, s, BA, n);
+    const int headroom_bits = hb + 1;
+    int col = 0;
+    for (int p = 0; p < 3; ++p) col += lv[p]->n_levels * lv[p]->n_features;
+    const int scol0 = col, scols = 9 * sh->n_features;
+    if ((scol0 & 3) != 0 || scol0 + ((scols + 3) & ~3) > dz_stride) return NVP_ERR_UNSUPPORTED;
+    if (scols > 16 * F) return NVP_ERR_UNSUPPORTED;            // the sparse columns are scanned by the xt plane's own lanes
+    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
+                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, n);
 
-    if (P.reduce_items > 0) {
-        ReduceArgs R;
-        R.plan = P;
-        for (int p = 0; p < 3; ++p) { R.lv[p] = *lv[p]; R.grad[p] = grads[p]; }
-        R.slabs = (const float*)(ws + W.slabs);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(64, P.reduce_items), dim3(256), 0, s, R);
-    }
+    // ---- the three dense planes
+    auto dense = [&]() -> int {
+        size_t tmp = W.sort_tmp_bytes;
+        for (int k = 0; k < 2; ++k) {
+            if (k == 0 && y_sorted) continue;          // the batch already arrives in ascending y: identity order
+            hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[k]), (float*)(ws + W.keys_out[k]),
+                                                     (const int*)iota, (int*)(ws + W.order[k]), (size_t)n, 0, 32, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (!planes_ready) {          // otherwise nvp_encode_bwd_prepare zeroed both slot arrays before the chain kernel fed them
+            hipError_t me = hipMemsetAsync(ws + W.dzmax, 0, 2 * kMaxSlots * 4, s);
+            if (me != hipSuccess) return (int)me;
+        }
+        // planes in latent order: xy <- (x, y) sorted by y ; yt <- (t, y) sorted by y ; xt <- (t, x) sorted by x
+        PermArgs PA;
+        int c = 0;
+        const int c0[3] = {1, 0, 0}, c1[3] = {2, 2, 1}, ord[3] = {0, 0, 1};
+        for (int p = 0; p < 3; ++p) {
+            PA.order[p] = (ord[p] == 0 && y_sorted) ? (const int*)iota : (const int*)(ws + W.order[ord[p]]);
+            PA.cs[p] = (float2*)(ws + W.cs[p]);
+            PA.dzs[p] = (float*)(ws + W.dzs[p]);
+            PA.col0[p] = c; PA.nlev[p] = lv[p]->n_levels; PA.c0[p] = c0[p]; PA.c1[p] = c1[p];
+            c += lv[p]->n_levels * lv[p]->n_features;
+        }
+        PA.scol0 = scol0; PA.scols = planes_ready ? 0 : scols;      // 0: the sparse max came from the chain kernel
+        PA.sdzmax = (unsigned*)(ws + W.sdzmax);
+        PA.plane0 = planes_ready ? 2 : 0;
+        hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + PermCfg<F>::PIX - 1) / PermCfg<F>::PIX), 3 - PA.plane0), dim3(256),
+                           (size_t)PermCfg<F>::PIX * PermCfg<F>::STRIDE * sizeof(float), s, coords, dz, dz_stride, PA, (unsigned*)(ws + W.dzmax), n);
 
-    // ---- sparse grid
-    {
+        RowArgs RA;
+        int rs_max = 0;
+        for (int p = 0; p < 3; ++p) {
+            RA.cs[p] = (const float2*)(ws + W.cs[p]);
+            RA.rowstart[p] = (int*)(ws + W.rowstart[p]);
+            RA.lv[p] = *lv[p];
+            for (int l = 0; l < lv[p]->n_levels; ++l) RA.rs_off[p][l] = P.lp[p][l].rs_off;
+            RA.rs_total[p] = P.rs_total[p];
+            if (P.rs_total[p] > rs_max) rs_max = P.rs_total[p];
+        }
+        hipLaunchKernelGGL(rowstart_kernel, dim3((rs_max + 255) / 256, 3), dim3(256), 0, s, RA, n);
+
+        BandArgs BA;
+        BA.plan = P;
+        float* grads[3] = {g0, g1, g2};
+        for (int p = 0; p < 3; ++p) {
+            BA.lv[p] = *lv[p];
+            BA.cs[p] = (const float2*)(ws + W.cs[p]);
+            BA.dzs[p] = (const float*)(ws + W.dzs[p]);
+            BA.rowstart[p] = (const int*)(ws + W.rowstart[p]);
+            BA.grad[p] = grads[p];
+        }
+        BA.slabs = (float*)(ws + W.slabs);
+        BA.dzmax = (const unsigned*)(ws + W.dzmax);
+        BA.headroom_bits = headroom_bits;
+        hipLaunchKernelGGL((band_kernel<F>), dim3(P.total_blocks), dim3(kBandThreads), (size_t)P.entries * 8, s, BA, n);
+
+        if (P.reduce_items > 0) {
+            ReduceArgs R;
+            R.plan = P;
+            for (int p = 0; p < 3; ++p) { R.lv[p] = *lv[p]; R.grad[p] = grads[p]; }
+            R.slabs = (const float*)(ws + W.slabs);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(64, P.reduce_items), dim3(256), 0, s, R);
+        }
+        return 0;
+    };
+
+    // ---- sparse grid (its max|dz| slots were filled by the permute pass above, or by the chain kernel when planes_ready)
+    auto sparse = [&]() -> int {
         unsigned* sk_in = (unsigned*)(ws + W.skey_in);
         unsigned* sk_out = (unsigned*)(ws + W.skey_out);
         int* sorder = (int*)(ws + W.sorder);
         int* srs = (int*)(ws + W.srowstart);
         unsigned* sdzmax = (unsigned*)(ws + W.sdzmax);
-        hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk_in, n, *sh);      // max|dz|: permute_kernel
+        hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk_in, n, *sh);
         const int nkeys = sh->t_res * sh->x_res;
         int end_bit = 1;
         while (((int64_t)1 << end_bit) < nkeys && end_bit < 32) ++end_bit;
@@ -617,9 +625,21 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         if (rows > sh->x_res) rows = sh->x_res;
         const int bands = (sh->x_res + rows - 1) / rows;
         hipLaunchKernelGGL(sparse_band_kernel, dim3((unsigned)(sh->t_res * bands)), dim3(kSparseThreads), (size_t)sentries * 8, s,
-                           coords, dz, dz_stride, col, (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, BA.headroom_bits + 2);
+                           coords, dz, dz_stride, scol0, (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, headroom_bits + 2);
+        return 0;
+    };
+
+    // With the sparse max already known the sparse grid goes FIRST: it is 80 % of the gradient bytes, and a data-parallel host
+    // that splits the call (NVP_SCATTER_SPARSE_ONLY, then NVP_SCATTER_DENSE_ONLY) can start exchanging it while the planes scatter.
+    int rc = 0;
+    if (planes_ready) {
+        if (do_sparse) rc = sparse();
+        if (rc == 0 && do_dense) rc = dense();
+    } else {
+        rc = dense();
+        if (rc == 0) rc = sparse();
     }
-    return 0;
+    return rc;
 }
 
 }  // namespace
@@ -649,11 +669,16 @@ int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels*
     if (rc) return rc;
     if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
     char* ws = (char*)workspace;
-    hipError_t e = hipMemsetAsync(ws + W.dzmax, 0, kMaxSlots * 4, (hipStream_t)stream);
+    if (W.sdzmax != W.dzmax + kMaxSlots * 4) return NVP_ERR_UNSUPPORTED;       // carve() keeps the two slot arrays adjacent: one memset
+    hipError_t e = hipMemsetAsync(ws + W.dzmax, 0, 2 * kMaxSlots * 4, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     out->dzs[0] = (float*)(ws + W.dzs[0]);
     out->dzs[1] = (float*)(ws + W.dzs[1]);
     out->dzmax = (uint32_t*)(ws + W.dzmax);
+    out->sdzmax = (uint32_t*)(ws + W.sdzmax);
+    out->scol0 = 0;
+    for (int p = 0; p < 3; ++p) out->scol0 += lv[p]->n_levels * lv[p]->n_features;
+    out->scols = 9 * sh->n_features;
     return 0;
 }
 

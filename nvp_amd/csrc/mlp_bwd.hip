@@ -348,10 +348,12 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
                               const float* packed_bwd, float* dy, float* dz_rows, const nvp_scatter_lm* lm_host,
                               int64_t n, int32_t d, void* stream) {
     if (!drgb || !steps || !saved || !p || !packed_bwd || !dy || !dz_rows || n < 0 || d < 1) return NVP_ERR_BADARG;
-    NvpDzLm lm = {{nullptr, nullptr}, nullptr};
+    NvpDzLm lm = NVP_DZLM_OFF;
     if (lm_host && lm_host->dzs[0]) {
-        if (!nvp_dz_lm_supported(d) || !lm_host->dzs[1] || !lm_host->dzmax) return NVP_ERR_UNSUPPORTED;
+        if (!nvp_dz_lm_supported(d) || !lm_host->dzs[1] || !lm_host->dzmax || !lm_host->sdzmax) return NVP_ERR_UNSUPPORTED;
+        if ((lm_host->scol0 & 3) || lm_host->scol0 < 0 || lm_host->scols < 0 || lm_host->scol0 + lm_host->scols > nvp_dz_stride_dev(d)) return NVP_ERR_BADARG;
         lm.dzs[0] = lm_host->dzs[0]; lm.dzs[1] = lm_host->dzs[1]; lm.dzmax = lm_host->dzmax;
+        lm.sdzmax = lm_host->sdzmax; lm.scol0 = lm_host->scol0; lm.scols = lm_host->scols;
     }
     if (n == 0) return 0;
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {

@@ -305,16 +305,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3_kernel(const float*
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
             const int F = d / 57;                       // latent = 57 F columns (modules.py:42-45)
-            unsigned mx = 0u;
+            unsigned mx = 0u, msx = 0u;
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int base = 32 * T + 8 * g + 4 * h;
-                    if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3], mx))
+                    if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3], mx, msx))
                         *reinterpret_cast<float4*>(o + base) = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
                 }
-            nvp_dz_lm_finish(lm, mx, tile, lane);
+            nvp_dz_lm_finish(lm, mx, msx, tile, lane);
         }
     }
 }
@@ -368,16 +368,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3_kernel(const flo
     float* o = dzr + (tile * 32 + j) * stride;
     const int F = d / 57;
     const int64_t px = tile * 32 + j;
-    unsigned mx = 0u;
+    unsigned mx = 0u, msx = 0u;
 #pragma unroll
     for (int T = 0; T < ZT; ++T)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int base = 32 * T + 8 * g + 4 * h;
-            if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3], mx))
+            if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3], mx, msx))
                 *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
         }
-    nvp_dz_lm_finish(lm, mx, tile, lane);
+    nvp_dz_lm_finish(lm, mx, msx, tile, lane);
 }
 
 }  // namespace
@@ -392,7 +392,7 @@ int nvp_mlp_bwd_b3_launch(const float* drgb, const float* steps, const float* sa
     if (nvp_bwd_b3_zt(d) == 4) {
         hipLaunchKernelGGL(mlp_bwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, lm, n, ntiles, d);
     } else {
-        hipLaunchKernelGGL(mlp_bwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, NvpDzLm{{nullptr, nullptr}, nullptr}, n, ntiles, d);
+        hipLaunchKernelGGL(mlp_bwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, NVP_DZLM_OFF, n, ntiles, d);
         hipLaunchKernelGGL(mlp_bwd_dz_b3_kernel<8>, grid, dim3(kWaves * 64), 0, (hipStream_t)stream, dy, pk, dz_rows, lm, n, ntiles, d);
     }
     NVP_LAUNCH_CHECK();

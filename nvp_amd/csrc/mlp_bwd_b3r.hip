@@ -263,16 +263,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
             const int stride = nvp_dz_stride_dev(d);
             float* o = dzr + (tile * 32 + j) * stride;
             const int F = d / 57;                       // latent = 57 F columns (modules.py:42-45)
-            unsigned mx = 0u;
+            unsigned mx = 0u, msx = 0u;
 #pragma unroll
             for (int T = 0; T < 4; ++T)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int base = 32 * T + 8 * g + 4 * h;
-                    if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3], mx))
+                    if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3], mx, msx))
                         *reinterpret_cast<float4*>(o + base) = make_float4(dzacc[T][4 * g], dzacc[T][4 * g + 1], dzacc[T][4 * g + 2], dzacc[T][4 * g + 3]);
                 }
-            nvp_dz_lm_finish(lm, mx, tile, lane);
+            nvp_dz_lm_finish(lm, mx, msx, tile, lane);
         }
     }
 }

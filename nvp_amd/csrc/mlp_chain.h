@@ -264,13 +264,21 @@ __device__ __forceinline__ void store_ptm16(float* __restrict__ tile_base, const
 struct NvpDzLm {
     float* dzs[2];
     unsigned* dzmax;
+    unsigned* sdzmax;          // max|dz| slots of the sparse grid's columns [scol0, scol0 + scols) (those rows stay row-major)
+    int scol0, scols;
 };
+#define NVP_DZLM_OFF NvpDzLm{{nullptr, nullptr}, nullptr, nullptr, 0, 0}
 
 // one float4 = latent rows base..base+3 of pixel px.  Returns true when the rows belong to plane 0 / 1 and were stored level-major.
-__device__ __forceinline__ bool nvp_dz_store_lm(const NvpDzLm& lm, int F, int base, int64_t px, int64_t n, float a, float b, float c, float d4, unsigned& m) {
+// `ms` collects max|dz| of the sparse columns (which the caller then stores row-major as before).
+__device__ __forceinline__ bool nvp_dz_store_lm(const NvpDzLm& lm, int F, int base, int64_t px, int64_t n, float a, float b, float c, float d4, unsigned& m, unsigned& ms) {
     if (lm.dzs[0] == nullptr) return false;
     const int plane_rows = 16 * F;
-    if (base >= 2 * plane_rows) return false;
+    if (base >= 2 * plane_rows) {
+        if (px < n && base >= lm.scol0 && base < lm.scol0 + lm.scols)        // rows past scols inside the last float4 are padding: exact zeros
+            ms = max(ms, max(max(__float_as_uint(fabsf(a)), __float_as_uint(fabsf(b))), max(__float_as_uint(fabsf(c)), __float_as_uint(fabsf(d4)))));
+        return false;
+    }
     const int plane = base >= plane_rows ? 1 : 0;
     const int rowin = base - plane * plane_rows;
     if (px < n) {
@@ -288,9 +296,10 @@ __device__ __forceinline__ bool nvp_dz_store_lm(const NvpDzLm& lm, int F, int ba
 }
 
 // after the stores: the wave's max|dz| (bit patterns: NaN / Inf win, see encode_bwd.hip) into one of the scatter's slots
-__device__ __forceinline__ void nvp_dz_lm_finish(const NvpDzLm& lm, unsigned m, int64_t tile, int lane) {
+__device__ __forceinline__ void nvp_dz_lm_finish(const NvpDzLm& lm, unsigned m, unsigned ms, int64_t tile, int lane) {
     if (lm.dzs[0] == nullptr) return;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    for (int o = 32; o > 0; o >>= 1) { m = max(m, (unsigned)__shfl_xor((int)m, o)); ms = max(ms, (unsigned)__shfl_xor((int)ms, o)); }
     if (lane == 0 && m > 0u) atomicMax(lm.dzmax + (int)(tile & 255), m);
+    if (lane == 0 && ms > 0u) atomicMax(lm.sdzmax + (int)(tile & 255), ms);
 }

@@ -54,6 +54,9 @@ _SIDE = None
 # Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
 # (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
 GRIDS_READY_HOOK = None
+# ... and this one as soon as the sparse grid's gradient alone has been enqueued (only when the scatter runs sparse-first: y-sorted
+# batches with the level-major hand-over); the dense planes follow, then GRIDS_READY_HOOK
+SPARSE_READY_HOOK = None
 
 # Batches that do not arrive sorted by their y coordinate (the reference's own sampler, dataio.py:104-120) are
 # put into that order inside NVPFused for the duration of the step and the RGB rows are returned in the
@@ -377,12 +380,25 @@ class NVPFused(torch.autograd.Function):
                                                L.ptr(ws, torch.uint8), ws_bytes, C.byref(lm), L.stream_ptr()), "nvp_encode_bwd_prepare")
             flags |= L.DZ_PLANES_READY
 
-        def scatter(dz_rows):
-            L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1],
+        def scatter_call(fl):
+            L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows_ref[0]), dz_rows_ref[0].shape[1],
                           L.ptr(d_xy), L.ptr(d_yt), L.ptr(d_xt), L.ptr(d_emb), n,
                           C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
-                          L.ptr(ws, torch.uint8), ws_bytes, flags, L.stream_ptr()),
+                          L.ptr(ws, torch.uint8), ws_bytes, fl, L.stream_ptr()),
                     "nvp_encode_bwd")
+
+        dz_rows_ref = [None]
+
+        def scatter(dz_rows):
+            dz_rows_ref[0] = dz_rows
+            if SPARSE_READY_HOOK is not None and (flags & L.DZ_PLANES_READY):
+                # data parallel: the sparse grid (80 % of the gradient bytes) is scattered first and handed to the exchange while
+                # the dense planes are still being scattered
+                scatter_call(flags | L.SCATTER_SPARSE_ONLY)
+                SPARSE_READY_HOOK()
+                scatter_call(flags | L.SCATTER_DENSE_ONLY)
+            else:
+                scatter_call(flags)
             if GRIDS_READY_HOOK is not None:
                 GRIDS_READY_HOOK()            # e.g. start the (async) all-reduce of the grid gradients
 

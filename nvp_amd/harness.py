@@ -162,6 +162,7 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
         bucket.detach_grads()                       # == zero_grad(set_to_none=True)
         functional.GRAD_SINK = bucket.sink()        # backward writes straight into the flat buffer
         functional.GRIDS_READY_HOOK = opt.start_early if sharded else bucket.start_early   # grid grads exchanged underneath the dW GEMMs
+        functional.SPARSE_READY_HOOK = opt.start_first if sharded else None                 # ... the sparse grid's even earlier
     else:
         opt.zero_grad()
     try:
@@ -169,6 +170,7 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     finally:
         functional.GRAD_SINK = None
         functional.GRIDS_READY_HOOK = None
+        functional.SPARSE_READY_HOOK = None
     if AFTER_BACKWARD_HOOK is not None:
         AFTER_BACKWARD_HOOK()
     if sharded:
@@ -196,7 +198,7 @@ def make_dp(model: torch.nn.Module, total_steps: int, mode: str = "sharded", alg
     if mode == "sharded":
         world = parallel.GradBucket.world_size()
         bucket = parallel.GradBucket(params, early=grids, pad_to=parallel.ShardedAdamW.alignment(world))
-        opt = parallel.ShardedAdamW(bucket, lr=lr, weight_decay=0.001, algo=algo)
+        opt = parallel.ShardedAdamW(bucket, lr=lr, weight_decay=0.001, algo=algo, first=[model.sparse_grid.embeddings] if early else None)
     elif mode == "replicated":
         bucket = parallel.GradBucket(params, early=grids)
         opt = AdamW(params, lr=lr, weight_decay=0.001)

@@ -28,6 +28,9 @@ from typing import Callable, Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
+# ShardedAdamW: update + all-gather the grid shards on a side stream, underneath the dW GEMMs (0: everything on the compute stream)
+EARLY_UPDATE = os.environ.get("NVP_DP_EARLY_UPDATE", "1") != "0"
+
 
 def _force() -> bool:
     """NVP_DP_FORCE_COLLECTIVES=1: run the collective code paths even with ONE rank (a single-GPU box can then exercise
@@ -297,7 +300,7 @@ class ShardedAdamW(torch.optim.Optimizer):
         return 64 * max(world, 1)
 
     def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 algo: str = "reduce_scatter", update: Optional[Callable] = None):
+                 algo: str = "reduce_scatter", update: Optional[Callable] = None, first: Optional[Iterable[torch.nn.Parameter]] = None):
         if algo not in ("reduce_scatter", "all_to_all"):
             raise ValueError("algo must be 'reduce_scatter' or 'all_to_all'")
         super().__init__(bucket.params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -336,7 +339,22 @@ class ShardedAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)
         self.steps_done = 0
         self._scratch = torch.empty(bucket.padded, device=dev, dtype=torch.float32) if (algo == "all_to_all" and (self.world > 1 or _force())) else None
-        self._early_work = None
+        self._early_work = None          # [(piece index, wait)] in launch order, once start_first / start_early have run
+        self._early_event = None
+        self._first_event = None
+        self._first_started = False
+        self._early_started = False
+        self._side = None
+        # `first`: early parameters whose gradients are complete BEFORE the other early ones (NVP: the sparse grid, which the
+        # scatter produces first).  The early pieces that lie wholly inside them can be exchanged from start_first() on.
+        self._first_pieces = []
+        if first is not None:
+            ids = {id(p) for p in first}
+            rng = [(o, o + p.numel()) for p, o in zip(bucket.params, bucket._offsets) if id(p) in ids]
+            if rng and len(rng) == len(ids):
+                f_lo, f_hi = min(a for a, _ in rng), max(e for _, e in rng)
+                if sum(e - a for a, e in rng) == f_hi - f_lo:
+                    self._first_pieces = [i for i in range(self.n_early) if self.pieces[i][0] >= f_lo and self.pieces[i][1] <= f_hi]
 
     # -- exchange of one piece: after wait(), flat[own shard] holds the cross-rank SUM of that shard
     def _reduce_piece(self, i: int):
@@ -356,10 +374,27 @@ class ShardedAdamW(torch.optim.Optimizer):
             torch.sum(recv.view(self.world, hi - lo), dim=0, out=g[lo:hi])          # ranks summed in rank order: deterministic
         return fin
 
+    def start_first(self) -> None:
+        """Start the exchange of the early pieces that only hold `first` parameters; call once THEIR gradients are enqueued
+        (functional.SPARSE_READY_HOOK).  Optional: start_early() picks up whatever has not been started."""
+        if self._first_started or self._early_started or not self.bucket._sink_armed or not self._first_pieces:
+            return
+        self._first_started = True
+        self._early_work = [(i, self._reduce_piece(i)) for i in self._first_pieces]
+        if self.pflat.is_cuda:
+            self._first_event = torch.cuda.Event()
+            self._first_event.record()              # the `first` gradients are complete at this point of the compute stream
+
     def start_early(self) -> None:
-        """Start the exchange of the early (grid) pieces; call once their gradients are enqueued (GRIDS_READY_HOOK)."""
-        if self._early_work is None and self.bucket._sink_armed:
-            self._early_work = [self._reduce_piece(i) for i in range(self.n_early)]
+        """Start the exchange of the (remaining) early grid pieces; call once their gradients are enqueued (GRIDS_READY_HOOK)."""
+        if self._early_started or not self.bucket._sink_armed:
+            return
+        self._early_started = True
+        started = {i for i, _ in (self._early_work or [])}
+        self._early_work = (self._early_work or []) + [(i, self._reduce_piece(i)) for i in range(self.n_early) if i not in started]
+        if self.pflat.is_cuda:
+            self._early_event = torch.cuda.Event()
+            self._early_event.record()              # every grid gradient is complete at this point of the compute stream
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -367,30 +402,35 @@ class ShardedAdamW(torch.optim.Optimizer):
             raise RuntimeError("ShardedAdamW.step does not take a closure")
         b = self.bucket
         b._sink_armed = False
+        early = list(self._early_work or [])
+        first_ev, early_ev = self._first_event, self._early_event
+        self._early_work, self._first_event, self._early_event = None, None, None
+        self._first_started = self._early_started = False
         if not b.consistent():
             # a gradient did not land in the bucket.  Pieces already exchanged were written through the sink and are valid
-            # (see GradBucket._repair); the rest is copied back before it is exchanged.
-            started = self.n_early if self._early_work is not None else 0
-            done_hi = self.pieces[started - 1][1] if started else 0
+            # (see GradBucket._repair): bucket memory stands inside them; everything else is copied back before it is exchanged.
+            done = sorted(self.pieces[i] for i, _ in early)
             for p, v, o in zip(b.params, b.views, b._offsets):
                 if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
                     continue
-                keep = min(max(done_hi - o, 0), p.numel())       # leading elements inside an exchanged piece: bucket memory stands
-                if keep == p.numel():
-                    continue
-                if p.grad is None:
-                    v.reshape(-1)[keep:].zero_()
-                else:
-                    v.reshape(-1)[keep:].copy_(p.grad.reshape(-1)[keep:])
+                flat_v = v.reshape(-1)
+                flat_g = None if p.grad is None else p.grad.reshape(-1)
+                pos = o
+                for a, e in done + [(o + p.numel(), o + p.numel())]:
+                    hi = min(max(a, o), o + p.numel())         # [pos, hi): not covered by an exchanged piece
+                    if hi > pos:
+                        if flat_g is None:
+                            flat_v[pos - o:hi - o].zero_()
+                        else:
+                            flat_v[pos - o:hi - o].copy_(flat_g[pos - o:hi - o])
+                    pos = max(pos, min(e, o + p.numel()))
             b.attach()
-        waits = list(self._early_work or [])
-        self._early_work = None
-        waits += [self._reduce_piece(i) for i in range(len(waits), len(self.pieces))]
         group = self.param_groups[0]
         b1, b2 = group["betas"]
         self.steps_done += 1
         gathers = []
-        for i, wait in enumerate(waits):
+
+        def finish_piece(i, wait):
             wait()
             lo, hi, off = self.shards[i]
             self.update(self.pflat[lo:hi], b._flat_all[lo:hi], self.exp_avg[off:off + hi - lo], self.exp_avg_sq[off:off + hi - lo],
@@ -398,6 +438,32 @@ class ShardedAdamW(torch.optim.Optimizer):
             if self.world > 1 or _force():
                 a, e = self.pieces[i]
                 gathers.append(dist.all_gather_into_tensor(self.pflat[a:e], self.pflat[lo:hi], async_op=True))   # in place
+
+        # Early (grid) pieces: update + parameter all-gather on a SIDE stream that only waits for the pieces' own exchange, not for
+        # the dW GEMMs still running on the compute stream (nothing after the scatter reads a grid parameter, and the MLP
+        # parameters the dW kernels do read sit in the remainder piece).  The grid shards' AdamW and most of their all-gather then
+        # run underneath the dW GEMMs instead of after them.  NVP_DP_EARLY_UPDATE=0: everything on the compute stream, in order.
+        side = None
+        if early and EARLY_UPDATE and self.pflat.is_cuda and early_ev is not None:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.pflat.device)
+            side = self._side
+            n_first = len(self._first_pieces) if first_ev is not None else 0
+            side.wait_event(first_ev if n_first else early_ev)
+            with torch.cuda.stream(side):
+                for k, (i, wait) in enumerate(early):
+                    if k == n_first and n_first:
+                        side.wait_event(early_ev)       # from here on the pieces hold the later (dense-plane) gradients
+                    finish_piece(i, wait)
+        else:
+            for i, wait in early:
+                finish_piece(i, wait)
+        started = {i for i, _ in early}
+        for i in range(len(self.pieces)):
+            if i not in started:
+                finish_piece(i, self._reduce_piece(i))
+        if side is not None:
+            torch.cuda.current_stream(self.pflat.device).wait_stream(side)
         for w in gathers:
             w.wait()
         return None

@@ -472,6 +472,24 @@ def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
                                                model.keyframes_xt.params, model.sparse_grid.embeddings)])
     for a, b, c in zip(*grads):
         assert torch.equal(a, b) and torch.equal(b, c)
+    # Data parallelism splits the scatter into two calls (NVP_SCATTER_SPARSE_ONLY, then NVP_SCATTER_DENSE_ONLY) with a hook in
+    # between, so that the sparse grid's gradient can be exchanged while the dense planes scatter: same bits, and at the
+    # time of the first hook the sparse gradient must already be complete on the stream.
+    from nvp_amd import functional
+    seen = {}
+
+    def sparse_ready():
+        seen["calls"] = seen.get("calls", 0) + 1
+    functional.SPARSE_READY_HOOK = sparse_ready
+    try:
+        model.zero_grad(set_to_none=True)
+        (model({"all_coords": coords, "temporal_steps": steps, "sorted_by_y": True})["model_out"] * w).sum().backward()
+    finally:
+        functional.SPARSE_READY_HOOK = None
+    assert seen.get("calls") == 1, "the split scatter path did not run (level-major hand-over off?)"
+    split = [p.grad for p in (model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings)]
+    for a, b in zip(grads[1], split):
+        assert torch.equal(a, b), "two-call scatter differs from the single call"
 
 
 @pytest.mark.parametrize("F,n,border", [(2, 200000, "wrap"), (4, 70000, "wrap"), (2, 3000, "wrap"), (2, 257, "clamp"), (2, 50000, "clamp")])

@@ -200,7 +200,7 @@ def _sharded_worker(rank, world, port, q, algo):
     from nvp_amd import parallel
     from nvp_amd.modules import NVP
     parallel.init_distributed(backend="gloo")
-    cfg = small_cfg(F=2, T=4, X=5, Y=5, n_levels=4)
+    cfg = small_cfg(F=2, T=16, X=20, Y=20, n_levels=4)       # sparse grid of 12 800 elements: several 3000-element pieces lie wholly inside it
 
     def build():
         torch.manual_seed(7)
@@ -223,9 +223,12 @@ def _sharded_worker(rank, world, port, q, algo):
     p_sh = parallel.unique_parameters(m_sh)
     grids_sh = [m_sh.keyframes_xy.params, m_sh.keyframes_yt.params, m_sh.keyframes_xt.params, m_sh.sparse_grid.embeddings]
     b_sh = parallel.GradBucket(p_sh, early=grids_sh, chunk_elems=3000, pad_to=parallel.ShardedAdamW.alignment(world))
-    opt = parallel.ShardedAdamW(b_sh, lr=1e-2, weight_decay=1e-3, algo=algo, update=_cpu_adamw_update)
+    opt = parallel.ShardedAdamW(b_sh, lr=1e-2, weight_decay=1e-3, algo=algo, update=_cpu_adamw_update, first=[m_sh.sparse_grid.embeddings])
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=4, eta_min=1e-5)
     assert len(opt.pieces) >= 3 and opt.n_early >= 2 and opt.pieces[-1][1] == b_sh.padded
+    # the pieces that only hold the sparse grid can be exchanged before the dense planes' gradients exist
+    emb_lo = b_sh._offsets[3]
+    assert opt._first_pieces and all(opt.pieces[i][0] >= emb_lo for i in opt._first_pieces) and 0 not in opt._first_pieces
     assert all((b - a) % (64 * world) == 0 for a, b in opt.pieces)
     assert opt.exp_avg.numel() * world == b_sh.padded                      # optimizer state is 1/world of the flat vector
     assert all(p.data_ptr() == opt.pflat[o:o + 1].data_ptr() for p, o in zip(p_sh, b_sh._offsets))    # parameters re-homed, values kept
@@ -240,9 +243,24 @@ def _sharded_worker(rank, world, port, q, algo):
             wait()
         _cpu_adamw_update(flat_p, b_rep.flat, m1, v1, lr_now, 0.9, 0.999, 1e-8, 1e-3, it, 1.0 / world)
         # sharded: same local gradients
-        fake_grads(b_sh.views, it)
-        b_sh.sink()
-        opt.start_early()                             # GRIDS_READY_HOOK: the early pieces' reduce-scatter is in flight
+        if it % 2 == 0:
+            # SPARSE_READY_HOOK: only the sparse grid's gradient exists yet - its pieces go out; the dense planes' gradients are
+            # written AFTERWARDS (stale values in their range must not have been sent)
+            for v in b_sh.views[:3]:
+                v.fill_(float("nan"))
+            b_sh.sink()
+            g_all = [torch.empty_like(v) for v in b_sh.views]
+            fake_grads(g_all, it)
+            b_sh.views[3].copy_(g_all[3])
+            opt.start_first()
+            opt.start_first()                         # (idempotent)
+            for v, gsrc in zip(b_sh.views, g_all):
+                if v is not b_sh.views[3]:
+                    v.copy_(gsrc)
+        else:
+            fake_grads(b_sh.views, it)
+            b_sh.sink()
+        opt.start_early()                             # GRIDS_READY_HOOK: the (remaining) early pieces' reduce-scatter is in flight
         if it == 3:                                   # the MLP range lost its views (autograd cloned): repaired, exchanged once
             for p in p_sh[4:]:
                 p.grad = p.grad.clone()
