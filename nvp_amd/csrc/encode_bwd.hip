@@ -152,14 +152,24 @@ int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape*
 }
 
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int row_of(float c1, float scale, int flags) { return (int)floorf(nvp_grid_pos(c1, scale, flags)); }
+
 // cs_xy / cs_yt (optional): the (dim0, dim1) coordinate pairs of the xy and yt planes in batch order - what the permute pass
-// would write for them when their sorted order is the identity (NVP_DZ_PLANES_READY)
-__global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ coords, float* __restrict__ ky, float* __restrict__ kx,
-                                                   int* __restrict__ iota, float2* __restrict__ cs_xy, float2* __restrict__ cs_yt, int64_t n) {
+// would write for them when their sorted order is the identity (NVP_DZ_PLANES_READY).
+// kx: the sort key of the xt plane.  The scatter needs the pixels ordered so that the grid ROW index is non-decreasing at EVERY
+// level; ordering by x itself does that, but costs four 8-bit radix passes over the float's 32 bits.  key(x) = sum over the levels
+// of row_l(x) is a non-decreasing step function that steps exactly where some level's row index steps, so equal keys mean equal
+// rows at every level (ties may sit in any order: the fixed-point accumulation does not depend on it) - and it has ~14 bits: two
+// passes.  Rows are clamped to [0, res + 1]; coordinates outside [0, 1] keep a valid (if arbitrary) order, as before.
+__global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ coords, float* __restrict__ ky, unsigned* __restrict__ kx,
+                                                   int* __restrict__ iota, float2* __restrict__ cs_xy, float2* __restrict__ cs_yt,
+                                                   nvp_levels lvx, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float t = coords[i * 3], x = coords[i * 3 + 1], y = coords[i * 3 + 2];
-    kx[i] = x;
+    unsigned key = 0u;
+    for (int l = 0; l < lvx.n_levels; ++l) key += (unsigned)min(max(row_of(x, lvx.scale[l], lvx.flags), 0), lvx.res[l] + 1);
+    kx[i] = key;
     ky[i] = y;
     iota[i] = (int)i;
     if (cs_xy) { cs_xy[i] = make_float2(x, y); cs_yt[i] = make_float2(t, y); }
@@ -253,8 +263,6 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
         if (plane == 2 && ms > 0u) atomicMax(A.sdzmax + slot, ms);
     }
 }
-
-__device__ __forceinline__ int row_of(float c1, float scale, int flags) { return (int)floorf(nvp_grid_pos(c1, scale, flags)); }
 
 struct RowArgs {
     const float2* cs[3];
@@ -518,7 +526,7 @@ template <int F>
 int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
                const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s) {
     float* ky = (float*)(ws + W.keys_in[0]);
-    float* kx = (float*)(ws + W.keys_in[1]);
+    unsigned* kx = (unsigned*)(ws + W.keys_in[1]);
     int* iota = (int*)(ws + W.iota);
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     // xy / yt latent gradients already level-major in ws AND the sparse columns' max|dz| already in its slots (chain kernel)
@@ -534,15 +542,25 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     if ((scol0 & 3) != 0 || scol0 + ((scols + 3) & ~3) > dz_stride) return NVP_ERR_UNSUPPORTED;
     if (scols > 16 * F) return NVP_ERR_UNSUPPORTED;            // the sparse columns are scanned by the xt plane's own lanes
     hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
-                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, n);
+                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, *lv[2], n);
+    int kx_bits = 1;
+    {
+        int64_t kmax = 0;
+        for (int l = 0; l < lv[2]->n_levels; ++l) kmax += lv[2]->res[l] + 1;
+        while (((int64_t)1 << kx_bits) <= kmax && kx_bits < 32) ++kx_bits;
+    }
 
     // ---- the three dense planes
     auto dense = [&]() -> int {
         size_t tmp = W.sort_tmp_bytes;
-        for (int k = 0; k < 2; ++k) {
-            if (k == 0 && y_sorted) continue;          // the batch already arrives in ascending y: identity order
-            hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[k]), (float*)(ws + W.keys_out[k]),
-                                                     (const int*)iota, (int*)(ws + W.order[k]), (size_t)n, 0, 32, s);
+        if (!y_sorted) {                               // otherwise the batch already arrives in ascending y: identity order
+            hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[0]), (float*)(ws + W.keys_out[0]),
+                                                     (const int*)iota, (int*)(ws + W.order[0]), (size_t)n, 0, 32, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        {
+            hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const unsigned*)kx, (unsigned*)(ws + W.keys_out[1]),
+                                                     (const int*)iota, (int*)(ws + W.order[1]), (size_t)n, 0, kx_bits, s);
             if (e != hipSuccess) return (int)e;
         }
         if (!planes_ready) {          // otherwise nvp_encode_bwd_prepare zeroed both slot arrays before the chain kernel fed them
