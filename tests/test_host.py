@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.SIGNATURES), "ctypes signature table out of sync with the header"
 
 
+def test_ctypes_structs_and_flags_follow_the_header():
+    """The ctypes mirrors of the C-ABI structs and the flag constants are written by hand: keep them in step with include/nvp_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "nvp_hip.h")).read()
+    for name, val in (("NVP_COORDS_SORTED_BY_Y", L.COORDS_SORTED_BY_Y), ("NVP_DZ_PLANES_READY", L.DZ_PLANES_READY),
+                      ("NVP_SCATTER_SPARSE_ONLY", L.SCATTER_SPARSE_ONLY), ("NVP_SCATTER_DENSE_ONLY", L.SCATTER_DENSE_ONLY)):
+        m = re.search(rf"#define\s+{name}\s+(\d+)", hdr)
+        assert m and int(m.group(1)) == val, name
+    # struct nvp_scatter_lm { float* dzs[2]; uint32_t* dzmax; uint32_t* sdzmax; int32_t scol0, scols; }
+    body = re.search(r"typedef struct nvp_scatter_lm \{(.*?)\} nvp_scatter_lm;", hdr, re.S).group(1)
+    fields = re.findall(r"(?:float|uint32_t|int32_t)\*?\s+([a-z0-9_]+(?:\[\d\])?(?:,\s*[a-z0-9_]+)*);", body)
+    names = [n.split("[")[0].strip() for f in fields for n in f.split(",")]
+    assert names == [f[0] for f in L.ScatterLm._fields_], (names, L.ScatterLm._fields_)
+    assert ctypes.sizeof(L.ScatterLm) == 2 * 8 + 8 + 8 + 4 + 4
+    assert L.load().nvp_mlp_mfma_products() in (1, 3, 6)
+
+
 def test_library_size_queries_match_layout_arithmetic():
     lib = L.load()
     assert lib.nvp_version().startswith(b"nvp_hip")
