@@ -29,8 +29,8 @@ for M in auto sharded a2a replicated; do
   stage dp1_$M 600 env NVP_DP_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --dp $M
   grep '^{' gpurun_out/${TAG}_dp1_$M.log | tail -1 > gpurun_out/${TAG}_dp1_$M.json
 done
-stage psnr_bisect 1500 python tools/psnr_bisect.py
+[ -n "${SKIP_BISECT:-}" ] || stage psnr_bisect 1500 python tools/psnr_bisect.py
 for f in gpurun_out/${TAG}_bench_*.json gpurun_out/${TAG}_dp1_*.json; do python -c "
 import json,sys
 d=json.load(open('$f')); print('$f', d['ms_per_step'], d['value'], d.get('dp',{}).get('mode'), d.get('dp',{}).get('autotune_ms_per_step'), d.get('dp',{}).get('post_backward_ms_per_rank'))"; done
-tail -8 gpurun_out/${TAG}_psnr_bisect.log
+[ -n "${SKIP_BISECT:-}" ] || tail -8 gpurun_out/${TAG}_psnr_bisect.log
