@@ -47,6 +47,7 @@ extern "C" {
                                       the sparse columns' max|dz| in its slots (both written by nvp_mlp_bwd_dx through
                                       nvp_encode_bwd_prepare's pointers); needs NVP_COORDS_SORTED_BY_Y */
 #define NVP_SCATTER_SPARSE_ONLY 8  /* nvp_encode_bwd (with NVP_DZ_PLANES_READY): only d_emb is produced by this call ... */
+#define NVP_SCATTER_PRESORTED 32   /* nvp_encode_bwd: nvp_encode_bwd_presort already ran on this workspace (same n, levels, flags) */
 #define NVP_SCATTER_DENSE_ONLY 16  /* ... only the three keyframe gradients.  Two calls (sparse first: 80 % of the gradient bytes) let a
                                       data-parallel host start exchanging the sparse grid's gradient while the dense planes scatter. */
 #define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: the scatter skips one radix sort,
@@ -166,6 +167,12 @@ typedef struct nvp_scatter_lm {
 } nvp_scatter_lm;
 int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                            const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, nvp_scatter_lm* out, void* stream);
+/* Optional early start: everything the scatter derives from the coordinates alone (sort keys, the planes' sorted orders, the sparse
+ * grid's row table: a dozen small latency-bound kernels, ~0.26 ms back to back) on `stream` - typically a side stream, underneath
+ * the backward chain kernel.  Order the streams with an event, then call nvp_encode_bwd with NVP_SCATTER_PRESORTED on the same
+ * workspace; `flags` as for nvp_encode_bwd.  Bit-identical gradients. */
+int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                           const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream);
 int32_t nvp_dz_lm_supported(int32_t latent_dim);   /* does nvp_mlp_bwd_dx honour `lm` for this latent width in this build? */
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,

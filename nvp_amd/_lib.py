@@ -22,6 +22,7 @@ COORDS_SORTED_BY_Y = 1
 DZ_PLANES_READY = 2
 SCATTER_SPARSE_ONLY = 8      # nvp_encode_bwd in two calls (needs DZ_PLANES_READY): sparse grid first ...
 SCATTER_DENSE_ONLY = 16      # ... then the three dense planes
+SCATTER_PRESORTED = 32       # nvp_encode_bwd_presort already ran on the workspace
 GRID_POS_FMA, GRID_INTERP_FMA, GRID_CLAMP = 1, 2, 4      # nvp_levels.flags (include/nvp_hip.h)
 HIDDEN = 128
 TILE = 32
@@ -86,6 +87,7 @@ SIGNATURES = {
     "nvp_mlp_bwd_dx": [_p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, C.POINTER(ScatterLm), _i64, _i32, _vp],
     "nvp_encode_bwd_prepare": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64,
                                C.POINTER(ScatterLm), _vp],
+    "nvp_encode_bwd_presort": [_p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64, _i32, _vp],
     "nvp_dz_lm_supported": [_i32],
     "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],

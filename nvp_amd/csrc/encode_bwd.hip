@@ -522,11 +522,50 @@ bool levels_ok(const nvp_levels* lv) {
     return true;
 }
 
+// Everything the scatter derives from the COORDINATES alone: sort keys, the xt plane's order (and the y order for unsorted
+// batches), the sparse grid's (t, x) order and row table.  A dozen small latency-bound kernels (~0.26 ms back to back) that a host
+// can run early on a side stream - underneath the backward chain kernel - through nvp_encode_bwd_presort.
+int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, int flags, hipStream_t s) {
+    float* ky = (float*)(ws + W.keys_in[0]);
+    unsigned* kx = (unsigned*)(ws + W.keys_in[1]);
+    int* iota = (int*)(ws + W.iota);
+    const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
+    const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;
+    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
+                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, *lv[2], n);
+    int kx_bits = 1;
+    {
+        int64_t kmax = 0;
+        for (int l = 0; l < lv[2]->n_levels; ++l) kmax += lv[2]->res[l] + 1;
+        while (((int64_t)1 << kx_bits) <= kmax && kx_bits < 32) ++kx_bits;
+    }
+    size_t tmp = W.sort_tmp_bytes;
+    if (!y_sorted) {                               // otherwise the batch already arrives in ascending y: identity order
+        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[0]), (float*)(ws + W.keys_out[0]),
+                                                 (const int*)iota, (int*)(ws + W.order[0]), (size_t)n, 0, 32, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    {
+        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const unsigned*)kx, (unsigned*)(ws + W.keys_out[1]),
+                                                 (const int*)iota, (int*)(ws + W.order[1]), (size_t)n, 0, kx_bits, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    unsigned* sk_in = (unsigned*)(ws + W.skey_in);
+    unsigned* sk_out = (unsigned*)(ws + W.skey_out);
+    hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk_in, n, *sh);
+    const int nkeys = sh->t_res * sh->x_res;
+    int end_bit = 1;
+    while (((int64_t)1 << end_bit) < nkeys && end_bit < 32) ++end_bit;
+    size_t tmp2 = W.sort_tmp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp2, (const unsigned*)sk_in, sk_out, (const int*)iota, (int*)(ws + W.sorder), (size_t)n, 0, end_bit, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sparse_rowstart_kernel, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, s, (const unsigned*)sk_out, (int*)(ws + W.srowstart), nkeys, n);
+    return 0;
+}
+
 template <int F>
 int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
                const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s) {
-    float* ky = (float*)(ws + W.keys_in[0]);
-    unsigned* kx = (unsigned*)(ws + W.keys_in[1]);
     int* iota = (int*)(ws + W.iota);
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     // xy / yt latent gradients already level-major in ws AND the sparse columns' max|dz| already in its slots (chain kernel)
@@ -541,28 +580,14 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     const int scol0 = col, scols = 9 * sh->n_features;
     if ((scol0 & 3) != 0 || scol0 + ((scols + 3) & ~3) > dz_stride) return NVP_ERR_UNSUPPORTED;
     if (scols > 16 * F) return NVP_ERR_UNSUPPORTED;            // the sparse columns are scanned by the xt plane's own lanes
-    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
-                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, *lv[2], n);
-    int kx_bits = 1;
-    {
-        int64_t kmax = 0;
-        for (int l = 0; l < lv[2]->n_levels; ++l) kmax += lv[2]->res[l] + 1;
-        while (((int64_t)1 << kx_bits) <= kmax && kx_bits < 32) ++kx_bits;
+    const bool presorted = (flags & NVP_SCATTER_PRESORTED) != 0;      // nvp_encode_bwd_presort already ran on this workspace
+    if (!presorted) {
+        int rc0 = presort(coords, n, lv, sh, ws, W, flags, s);
+        if (rc0) return rc0;
     }
 
     // ---- the three dense planes
     auto dense = [&]() -> int {
-        size_t tmp = W.sort_tmp_bytes;
-        if (!y_sorted) {                               // otherwise the batch already arrives in ascending y: identity order
-            hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[0]), (float*)(ws + W.keys_out[0]),
-                                                     (const int*)iota, (int*)(ws + W.order[0]), (size_t)n, 0, 32, s);
-            if (e != hipSuccess) return (int)e;
-        }
-        {
-            hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const unsigned*)kx, (unsigned*)(ws + W.keys_out[1]),
-                                                     (const int*)iota, (int*)(ws + W.order[1]), (size_t)n, 0, kx_bits, s);
-            if (e != hipSuccess) return (int)e;
-        }
         if (!planes_ready) {          // otherwise nvp_encode_bwd_prepare zeroed both slot arrays before the chain kernel fed them
             hipError_t me = hipMemsetAsync(ws + W.dzmax, 0, 2 * kMaxSlots * 4, s);
             if (me != hipSuccess) return (int)me;
@@ -623,19 +648,9 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
 
     // ---- sparse grid (its max|dz| slots were filled by the permute pass above, or by the chain kernel when planes_ready)
     auto sparse = [&]() -> int {
-        unsigned* sk_in = (unsigned*)(ws + W.skey_in);
-        unsigned* sk_out = (unsigned*)(ws + W.skey_out);
         int* sorder = (int*)(ws + W.sorder);
         int* srs = (int*)(ws + W.srowstart);
         unsigned* sdzmax = (unsigned*)(ws + W.sdzmax);
-        hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk_in, n, *sh);
-        const int nkeys = sh->t_res * sh->x_res;
-        int end_bit = 1;
-        while (((int64_t)1 << end_bit) < nkeys && end_bit < 32) ++end_bit;
-        size_t tmp2 = W.sort_tmp_bytes;
-        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp2, (const unsigned*)sk_in, sk_out, (const int*)iota, sorder, (size_t)n, 0, end_bit, s);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(sparse_rowstart_kernel, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, s, (const unsigned*)sk_out, srs, nkeys, n);
         int sentries = kSparseEntries;
         if (sh->y_res * sh->n_features > sentries) sentries = sh->y_res * sh->n_features;
         if (sentries > kMaxLdsEntries) return NVP_ERR_UNSUPPORTED;          // one x-row does not fit the LDS
@@ -698,6 +713,22 @@ int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels*
     for (int p = 0; p < 3; ++p) out->scol0 += lv[p]->n_levels * lv[p]->n_features;
     out->scols = 9 * sh->n_features;
     return 0;
+}
+
+// The coordinate-only part of the scatter (sort keys, orders, the sparse row table) on `stream`; nvp_encode_bwd then takes
+// NVP_SCATTER_PRESORTED with the SAME flags otherwise.  The caller orders the two streams (an event between them).
+int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                           const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream) {
+    if (n < 1 || !coords || !levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh || !workspace) return NVP_ERR_BADARG;
+    if (n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;
+    const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
+    Plan P;
+    make_plan(P, lv, n);
+    Ws W;
+    int rc = carve(W, P, lv, sh, n);
+    if (rc) return rc;
+    if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
+    return presort(coords, n, lv, sh, (char*)workspace, W, flags, (hipStream_t)stream);
 }
 
 // dz: row-major latent gradient [>= n][dz_stride] (columns xy | yt | xt | sparse).

@@ -50,6 +50,8 @@ class KernelTimer:
 TIMER = None      # set to a KernelTimer() to time launches
 DW_SIDE_STREAM = os.environ.get("NVP_DW_SIDE_STREAM", "0") == "1"      # experiment: dW GEMMs concurrent with the grid scatter
 _SIDE = None
+PRESORT = os.environ.get("NVP_SCATTER_PRESORT", "1") != "0"      # the scatter's coordinate-only kernels on a side stream, under the backward chain
+_PRESORT_STREAM = None
 
 # Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
 # (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
@@ -331,6 +333,31 @@ class NVPFused(torch.autograd.Function):
             order = torch.argsort(coords[:, 2])
             coords, steps, y_sorted = coords[order], steps[order], True
         zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32)
+        # Scatter workspace, allocated here when a backward pass will follow: (a) for y-sorted batches the backward chain writes the
+        # xy / yt planes' latent gradients straight into the scatter's level-major buffers, (b) everything the scatter derives from
+        # the COORDINATES alone (sort keys, orders, the sparse row table: a dozen small latency-bound kernels, ~0.26 ms back to
+        # back) is started NOW on a side stream, underneath the gather kernel, and the scatter later only waits for its event.
+        ctx.ws = ctx.presorted = None
+        if need_grad and n and not temporal_interp:
+            lvs = (lv_xy, lv_yt, lv_xt)
+            ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh))
+            if ws_bytes < 0:
+                raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
+            ctx.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            bflags = L.COORDS_SORTED_BY_Y if y_sorted else 0
+            if DZ_LEVEL_MAJOR and y_sorted and lib.nvp_dz_lm_supported(d):
+                bflags |= L.DZ_PLANES_READY
+            ctx.bflags = bflags
+            if PRESORT:
+                global _PRESORT_STREAM
+                if _PRESORT_STREAM is None:
+                    _PRESORT_STREAM = torch.cuda.Stream(device=dev)
+                _PRESORT_STREAM.wait_stream(torch.cuda.current_stream(dev))     # the workspace and the coordinates are ordered on the compute stream
+                with torch.cuda.stream(_PRESORT_STREAM):
+                    L.check(lib.nvp_encode_bwd_presort(L.ptr(coords), n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh),
+                                                       L.ptr(ctx.ws, torch.uint8), ws_bytes, bflags, L.stream_ptr()), "nvp_encode_bwd_presort")
+                    ctx.presorted = torch.cuda.Event()
+                    ctx.presorted.record()
         if n:
             L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
@@ -367,18 +394,21 @@ class NVPFused(torch.autograd.Function):
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
         d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t) for t in (kf_xy, kf_yt, kf_xt, emb))
 
-        # scatter workspace: allocated up front so that, for y-sorted batches, the backward chain can write the xy / yt planes'
-        # latent gradients straight into the scatter's level-major buffers (the permute pass then only handles the xt plane)
-        ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
-        if ws_bytes < 0:
-            raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
-        ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
-        flags, lm = ctx.flags, None
-        if DZ_LEVEL_MAJOR and (flags & L.COORDS_SORTED_BY_Y) and lib.nvp_dz_lm_supported(d):
+        # scatter workspace: allocated (and its coordinate-only part started) in forward
+        ws, flags, presorted, lm = ctx.ws, ctx.bflags, ctx.presorted, None
+        ctx.ws = ctx.presorted = None
+        if ws is None:          # a second backward through the same graph (retain_graph): fresh workspace, nothing presorted
+            ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh))
+            if ws_bytes < 0:
+                raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
+            ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
+        ws_bytes = ws.numel()
+        if flags & L.DZ_PLANES_READY:
             lm = L.ScatterLm()
             L.check(lib.nvp_encode_bwd_prepare(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
                                                L.ptr(ws, torch.uint8), ws_bytes, C.byref(lm), L.stream_ptr()), "nvp_encode_bwd_prepare")
-            flags |= L.DZ_PLANES_READY
+        if presorted is not None:
+            flags |= L.SCATTER_PRESORTED
 
         def scatter_call(fl):
             L.check(_call("nvp_encode_bwd", lib.nvp_encode_bwd, L.ptr(coords), L.ptr(dz_rows_ref[0]), dz_rows_ref[0].shape[1],
@@ -391,12 +421,14 @@ class NVPFused(torch.autograd.Function):
 
         def scatter(dz_rows):
             dz_rows_ref[0] = dz_rows
+            if presorted is not None:
+                torch.cuda.current_stream(coords.device).wait_event(presorted)
             if SPARSE_READY_HOOK is not None and (flags & L.DZ_PLANES_READY):
                 # data parallel: the sparse grid (80 % of the gradient bytes) is scattered first and handed to the exchange while
                 # the dense planes are still being scattered
                 scatter_call(flags | L.SCATTER_SPARSE_ONLY)
                 SPARSE_READY_HOOK()
-                scatter_call(flags | L.SCATTER_DENSE_ONLY)
+                scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
             else:
                 scatter_call(flags)
             if GRIDS_READY_HOOK is not None:
