@@ -339,6 +339,7 @@ class NVPFused(torch.autograd.Function):
         # back) is started NOW on a side stream, underneath the gather kernel, and the scatter later only waits for its event.
         ctx.ws = ctx.presorted = None
         if need_grad and n and not temporal_interp:
+            L.ptr(coords)                      # CPU tensors are refused here, before any stream is touched (no CPU path)
             lvs = (lv_xy, lv_yt, lv_xt)
             ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh))
             if ws_bytes < 0:
