@@ -50,7 +50,9 @@ class KernelTimer:
 TIMER = None      # set to a KernelTimer() to time launches
 DW_SIDE_STREAM = os.environ.get("NVP_DW_SIDE_STREAM", "0") == "1"      # experiment: dW GEMMs concurrent with the grid scatter
 _SIDE = None
-PRESORT = os.environ.get("NVP_SCATTER_PRESORT", "1") != "0"      # the scatter's coordinate-only kernels on a side stream, under the backward chain
+# NVPFused: the small kernels that depend on the coordinates or on the parameters only (the scatter's keys / sorts / sparse row table,
+# the weight packing for forward and backward) run on a side stream underneath the gather kernel (NVP_SCATTER_PRESORT=0: in line)
+SIDE_WORK = os.environ.get("NVP_SCATTER_PRESORT", "1") != "0"
 _PRESORT_STREAM = None
 
 # Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
@@ -177,15 +179,20 @@ class SparseGrid3x3(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # MLP core shared by SirenWrapper and the fused NVP function
 # --------------------------------------------------------------------------------------
-def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tensor], n: int, d: int, save: bool):
+def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tensor], n: int, d: int, save: bool, packed=None):
+    """`packed`: (tensor, event) of weights already packed on another stream (NVPFused packs underneath the gather kernel)."""
     lib = L.load()
     dev = zt.device
     if n == 0:
         return torch.empty((0, 3), device=dev, dtype=torch.float32), None
     stream = L.stream_ptr()
     pstruct = L.mlp_params_struct(mlp)
-    packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
-    L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_fwd")
+    if packed is not None:
+        packed, ev = packed
+        torch.cuda.current_stream(dev).wait_event(ev)
+    else:
+        packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
+        L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_fwd")
     rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
     saved = torch.empty((5, L.ntiles(n), L.HIDDEN, L.TILE), device=dev, dtype=torch.float32) if save else None
     L.check(_call("nvp_mlp_fwd", lib.nvp_mlp_fwd, L.ptr(zt), L.ptr(steps), C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), n, d, stream),
@@ -194,7 +201,7 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
 
 
 def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, saved: torch.Tensor,
-                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None, packed=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """dX chain (+ latent gradient), then the dW GEMMs.  `between(dz_rows)`, if given, runs after the
     dX kernels are enqueued and before the dW kernels: the fused NVP path uses it to enqueue the grid
     scatter (which only needs dz) first, so its gradients can be all-reduced underneath the dW GEMMs."""
@@ -203,8 +210,12 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     stream = L.stream_ptr()
     nt = L.ntiles(n)
     pstruct = L.mlp_params_struct(mlp)
-    packed = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32)
-    L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
+    if packed is not None:          # (tensor, event): packed during forward on the side stream
+        packed, ev = packed
+        torch.cuda.current_stream(dev).wait_event(ev)
+    else:
+        packed = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32)
+        L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
     dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
     dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
     drgb = _f32c(drgb)
@@ -337,9 +348,28 @@ class NVPFused(torch.autograd.Function):
         # xy / yt planes' latent gradients straight into the scatter's level-major buffers, (b) everything the scatter derives from
         # the COORDINATES alone (sort keys, orders, the sparse row table: a dozen small latency-bound kernels, ~0.26 ms back to
         # back) is started NOW on a side stream, underneath the gather kernel, and the scatter later only waits for its event.
-        ctx.ws = ctx.presorted = None
-        if need_grad and n and not temporal_interp:
+        # The side stream also packs the MLP weights (forward layout now, backward layout for later): ~0.1 ms of small kernels that
+        # depend on the parameters only.
+        ctx.ws = ctx.presorted = ctx.packed_bwd = None
+        packed_fwd = None
+        bwd_follows = need_grad and n and not temporal_interp
+        if n and SIDE_WORK:
             L.ptr(coords)                      # CPU tensors are refused here, before any stream is touched (no CPU path)
+            global _PRESORT_STREAM
+            if _PRESORT_STREAM is None:
+                _PRESORT_STREAM = torch.cuda.Stream(device=dev)
+            side = _PRESORT_STREAM
+            pstruct = L.mlp_params_struct(mlp)
+            pk_f = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
+            pk_b = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32) if bwd_follows else None
+            side.wait_stream(torch.cuda.current_stream(dev))     # allocations, parameters and coordinates are ordered on the compute stream
+            with torch.cuda.stream(side):
+                L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(pk_f), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
+                ev = torch.cuda.Event()
+                ev.record()
+                packed_fwd = (pk_f, ev)
+        if bwd_follows:
+            L.ptr(coords)
             lvs = (lv_xy, lv_yt, lv_xt)
             ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh))
             if ws_bytes < 0:
@@ -349,21 +379,22 @@ class NVPFused(torch.autograd.Function):
             if DZ_LEVEL_MAJOR and y_sorted and lib.nvp_dz_lm_supported(d):
                 bflags |= L.DZ_PLANES_READY
             ctx.bflags = bflags
-            if PRESORT:
-                global _PRESORT_STREAM
-                if _PRESORT_STREAM is None:
-                    _PRESORT_STREAM = torch.cuda.Stream(device=dev)
-                _PRESORT_STREAM.wait_stream(torch.cuda.current_stream(dev))     # the workspace and the coordinates are ordered on the compute stream
-                with torch.cuda.stream(_PRESORT_STREAM):
+            if SIDE_WORK:
+                side.wait_stream(torch.cuda.current_stream(dev))     # the workspace allocation
+                with torch.cuda.stream(side):
                     L.check(lib.nvp_encode_bwd_presort(L.ptr(coords), n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh),
                                                        L.ptr(ctx.ws, torch.uint8), ws_bytes, bflags, L.stream_ptr()), "nvp_encode_bwd_presort")
                     ctx.presorted = torch.cuda.Event()
                     ctx.presorted.record()
+                    L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(pk_b), d, L.stream_ptr()), "nvp_mlp_pack_bwd")
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    ctx.packed_bwd = (pk_b, ev)
         if n:
             L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                        C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
                                        1 if temporal_interp else 0, L.COORDS_SORTED_BY_Y if y_sorted else 0, L.stream_ptr()), "nvp_encode_fwd")
-        rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad)
+        rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad, packed=packed_fwd)
         if need_grad:
             if temporal_interp:
                 raise NotImplementedError("temporal_interp=True is an inference-only path (reference eval.py --t_interp)")
@@ -436,5 +467,6 @@ class NVPFused(torch.autograd.Function):
                 GRIDS_READY_HOOK()            # e.g. start the (async) all-reduce of the grid gradients
 
         # order: dX chain -> grid scatter (needs only dz) -> dW GEMMs (independent of the scatter)
-        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm)
+        packed_bwd, ctx.packed_bwd = ctx.packed_bwd, None
+        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm, packed=packed_bwd)
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, *grads)

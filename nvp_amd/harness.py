@@ -66,8 +66,8 @@ class DeviceVideo:
         self.gen = torch.Generator(device=dev).manual_seed(seed)
         # prefetch: the NEXT batch is drawn on a side stream while the current step's kernels run (the sampler is a chain of
         # small latency-bound kernels - two randint, a 16-bit argsort, a 3-byte gather - that depends on nothing the step
-        # computes); same draws, same order of batches as without it.  Measured neutral on MI355X (the GPU is saturated by the
-        # step's own kernels, 9.04 / 9.11 vs 9.08 / 9.04 ms per step): off by default
+        # computes); same draws, same order of batches as without it.  Worth 0.05 ms of a 7.5-ms step on MI355X (the sampler's
+        # ~0.2 ms of small kernels hide underneath the gather / MLP kernels, which slow down by 0.06 ms): bench.py and train.py turn it on
         self._side = torch.cuda.Stream(device=dev) if (prefetch and video_u8.is_cuda) else None
         self._next = None
 

@@ -77,7 +77,7 @@ def main():
         source = args.video
     T, H, W = (int(v) for v in video.shape[:3])
     model = NVP(out_features=3, encoding_config=config(args.config, T)).to(dev)
-    data = harness.DeviceVideo(video, seed=args.seed)
+    data = harness.DeviceVideo(video, seed=args.seed, prefetch=True)
     frames = [int(round(i * (T - 1) / max(args.eval_frames - 1, 1))) for i in range(args.eval_frames)]
     n_slice = harness.eval_slices(H * W)
 
