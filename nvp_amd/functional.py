@@ -49,11 +49,18 @@ class KernelTimer:
 
 TIMER = None      # set to a KernelTimer() to time launches
 DW_SIDE_STREAM = os.environ.get("NVP_DW_SIDE_STREAM", "0") == "1"      # experiment: dW GEMMs concurrent with the grid scatter
-_SIDE = None
 # NVPFused: the small kernels that depend on the coordinates or on the parameters only (the scatter's keys / sorts / sparse row table,
 # the weight packing for forward and backward) run on a side stream underneath the gather kernel (NVP_SCATTER_PRESORT=0: in line)
 SIDE_WORK = os.environ.get("NVP_SCATTER_PRESORT", "1") != "0"
-_PRESORT_STREAM = None
+_SIDE_STREAMS = {}          # device index -> the side stream of that device (one process normally drives one GPU)
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+    return st
 
 # Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
 # (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
@@ -101,7 +108,8 @@ def _call(name, fn, *args):
 
 def dw_chunks(n: int) -> int:
     """Number of pixel chunks of the split-K weight-gradient GEMMs."""
-    return max(1, min(256, L.ntiles(n) // 8))
+    cap = int(os.environ.get("NVP_DW_CHUNKS", "256"))
+    return max(1, min(cap, L.ntiles(n) // 8))
 
 
 # --------------------------------------------------------------------------------------
@@ -228,16 +236,14 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
     if DW_SIDE_STREAM and between is not None:
         # experiment (NVP_DW_SIDE_STREAM=1): the dW GEMMs on a second stream, concurrent with the grid scatter
-        global _SIDE
-        if _SIDE is None:
-            _SIDE = torch.cuda.Stream(device=dev)
+        side = _side_stream(dev)
         main = torch.cuda.current_stream(dev)
-        _SIDE.wait_stream(main)
-        with torch.cuda.stream(_SIDE):
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             L.check(lib.nvp_mlp_bwd_dw(L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), C.byref(pstruct),
                                        L.ptr(partials), nch, C.byref(gstruct), n, d, L.stream_ptr()), "nvp_mlp_bwd_dw")
         between(dz_rows)
-        main.wait_stream(_SIDE)
+        main.wait_stream(side)
         return dz_rows, grads
     if between is not None:
         between(dz_rows)
@@ -355,10 +361,7 @@ class NVPFused(torch.autograd.Function):
         bwd_follows = need_grad and n and not temporal_interp
         if n and SIDE_WORK:
             L.ptr(coords)                      # CPU tensors are refused here, before any stream is touched (no CPU path)
-            global _PRESORT_STREAM
-            if _PRESORT_STREAM is None:
-                _PRESORT_STREAM = torch.cuda.Stream(device=dev)
-            side = _PRESORT_STREAM
+            side = _side_stream(dev)
             pstruct = L.mlp_params_struct(mlp)
             pk_f = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
             pk_b = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32) if bwd_follows else None
