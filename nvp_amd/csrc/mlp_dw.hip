@@ -204,7 +204,9 @@ __device__ __forceinline__ void publish_max(unsigned* __restrict__ mx, int par, 
 // KIND 0: the modulator jobs (plain operands); KIND 1: SIREN layers 1-2, whose B operand x_k is rebuilt
 // on the fly.  Separate instantiations keep each variant's register budget tight (the union spilled).
 #ifndef NVP_DW_BUFS
-#define NVP_DW_BUFS 2        // LDS tile buffers: 2 = double-buffered (one barrier per tile, 2 workgroups/CU), 1 = single (two barriers, 3-4 workgroups/CU)
+#define NVP_DW_BUFS 1        // LDS tile buffers of the PLAIN jobs: 1 = single (two barriers per tile, 36 KB: three workgroups per CU at 168 VGPRs;
+                             // dW 1.735 -> 1.69 ms with the fp16 x 2 split), 2 = double-buffered (one barrier, two workgroups per CU).  The
+                             // transform-capable instantiation (214 VGPRs) is always double-buffered.
 #endif
 template <int KIND, int NB>
 __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1) ? 3 : 2) void mlp_dw_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
@@ -244,8 +246,8 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
 
     // SIREN layer 0's weight and bias (mode 2 rebuilds x_0 from them) live in LDS behind the tile buffers:
     // a global load at the point of use would put a vmcnt(0) wait into the pipelined loop
-    unsigned* mx = reinterpret_cast<unsigned*>(lds + 2 * kBufFloats);       // [2 slot sets][A | B][kMxW] tile maxima (fp16 x 2 block scale)
-    float* tab = lds + 2 * kBufFloats + 4 * kMxW;
+    unsigned* mx = reinterpret_cast<unsigned*>(lds + BUFS * kBufFloats);    // [2 slot sets][A | B][kMxW] tile maxima (fp16 x 2 block scale)
+    float* tab = lds + BUFS * kBufFloats + 4 * kMxW;
     if (XF && tid < NVP_H) { tab[tid] = A.sir0_wp[tid]; tab[NVP_H + tid] = A.sir0_bp[tid]; }
     if (XF) __syncthreads();
 
@@ -538,9 +540,9 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
     // GEMM launches: plain jobs, merged jobs (512 threads, three LDS tiles per buffer), transform jobs; plus the record sums
-    // every variant: 2 x kBufFloats of tile buffers (the kernel places the tile maxima and the table behind them), 4 kMxW maxima
+    // tile buffers (the kernel places the tile maxima and the table behind them), 4 kMxW maxima
     const size_t lds_bytes = (2 * 2 * kTileFloats + 4 * kMxW + 2 * NVP_H) * sizeof(float);
-    const size_t lds_bytes0 = (2 * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
+    const size_t lds_bytes0 = ((NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
     const size_t lds_bytes2 = (2 * 3 * kTileFloats + 4 * kMxW) * sizeof(float);          // 108 KiB: one 8-wave workgroup per CU
     if (n0) hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
