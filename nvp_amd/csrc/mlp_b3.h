@@ -155,9 +155,25 @@ __device__ __forceinline__ void mac_parts(f32x16& acc, const u32x4 (&a)[kP], con
 #else
 #define NVP_WSTRIDE(x) (x)
 #endif
+#ifndef NVP_STEP_PF_ALL
+#define NVP_STEP_PF_ALL 0        // experiment: all 4 kP operand quads of a k-step requested before its first MFMA (32 registers in flight)
+#endif
 template <bool PF = true>
 __device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const BOp& b, int lane) {
     const unsigned ul = (unsigned)lane;
+#if NVP_STEP_PF_ALL
+    if (PF) {
+        u32x4 q[4][kP];
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int k = 0; k < kP; ++k) q[T][k] = (w + (T * kP + k) * 64)[ul];
+        NVP_CHAIN_FENCE();
+#pragma unroll
+        for (int T = 0; T < 4; ++T) mac_parts(acc[T], q[T], b);
+        return;
+    }
+#endif
     u32x4 a[2][kP];
     if (PF) {
 #pragma unroll

@@ -229,11 +229,11 @@ struct HRing {
 #endif
 };
 
-// one k-step (two half-steps of the ring) into four output tiles.  LEAN: one tile's operand quads live at a time
-// (the backward chain has two accumulator sets live in its shared pass and no registers to spare); otherwise the second
-// tile's quads are read ahead of the first tile's MFMAs.
+// one k-step (two half-steps of the ring) into four output tiles.  LEAN: one tile's operand quads live at a time (what the
+// bf16 x 3 split needed: two accumulator sets live in the shared pass, no registers to spare); otherwise both tiles' quads of a
+// half-step are read ahead of the first MFMA - with the fp16 x 2 split's smaller operands that fits: 1.875 -> 1.80 ms.
 #ifndef NVP_HRING_LEAN
-#define NVP_HRING_LEAN 1
+#define NVP_HRING_LEAN 0
 #endif
 __device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& hs, const BOp& b, int lane) {
     const unsigned ul = (unsigned)lane;
