@@ -239,9 +239,69 @@ __device__ __forceinline__ void chain_in8(float (&x)[8], const f32x16 (&hin)[4],
     for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
 }
 
+// one k-step's operand quads (all four output tiles) requested at once
+struct StepOps { u32x4 q[4][kP]; };
+__device__ __forceinline__ void load_step(StepOps& o, const u32x4* __restrict__ w, int lane) {
+    const unsigned ul = (unsigned)lane;
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int k = 0; k < kP; ++k) o.q[T][k] = (w + (T * kP + k) * 64)[ul];
+}
+#ifndef NVP_CHAIN_PF_STEP
+#define NVP_CHAIN_PF_STEP 0      // experiment: a whole k-step of weights requested one k-step ahead (64 operand registers double-buffered)
+#endif
+
 // 8 k-steps over the previous layer's D registers, scaled by s
 template <bool PF = true>
 __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane) {
+#if NVP_CHAIN_PF_STEP == 1
+    if (PF) {
+        StepOps o[2];
+        load_step(o[0], w, lane);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c + 1 < 8) load_step(o[(c + 1) & 1], w + NVP_WSTRIDE((c + 1) * kB3StepQuads), lane);
+            float x[8];
+            chain_in8(x, hin, c);
+            BOp b;
+            split8(x, s, b);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[c & 1].q[T], b);
+        }
+        return;
+    }
+#elif NVP_CHAIN_PF_STEP == 2
+    if (PF) {
+        // tile PAIRS: while pair p (two output tiles of k-step p >> 1) issues its MFMAs, pair p + 1 - possibly of the next
+        // k-step - is in flight: twice the prefetch distance of step_b3 for 16 more operand registers
+        const unsigned ul = (unsigned)lane;
+        u32x4 a[2][2][kP];
+        auto load_pair = [&](int p, int buf) {
+            const u32x4* wp = w + NVP_WSTRIDE((p >> 1) * kB3StepQuads) + (p & 1) * 2 * kP * 64;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < kP; ++k) a[buf][t][k] = (wp + (t * kP + k) * 64)[ul];
+        };
+        load_pair(0, 0);
+        BOp b;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (p + 1 < 16) load_pair(p + 1, (p + 1) & 1);
+            if ((p & 1) == 0) {
+                float x[8];
+                chain_in8(x, hin, p >> 1);
+                split8(x, s, b);
+            }
+            NVP_CHAIN_FENCE();
+            mac_parts(acc[2 * (p & 1)], a[p & 1][0], b);
+            mac_parts(acc[2 * (p & 1) + 1], a[p & 1][1], b);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];

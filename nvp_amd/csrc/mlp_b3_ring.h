@@ -186,6 +186,12 @@ __device__ __forceinline__ void chain_h_b3_ring(f32x16 (&acc)[4], const f32x16 (
 constexpr int kHalfPieces = 2 * kP;
 constexpr int kHalfQuads = kHalfPieces * 64;
 
+#ifndef NVP_HRING_DEEP
+#define NVP_HRING_DEEP (NVP_SPLIT_H2 ? 2 : 0)     // fp16 x 2 only: extra half-steps of weights in flight per wave (0: 1.82, 1: 1.75, 2: 1.735, 3: 1.73 ms)
+#endif
+#if NVP_HRING_DEEP && !NVP_SPLIT_H2
+#error "NVP_HRING_DEEP needs the fp16 x 2 split (one ring piece per wave)"
+#endif
 struct HRing {
     u32x4* lds;                // two slots of kHalfQuads
     const u32x4* g;            // packed stream in consumption order, half-step 0
@@ -210,6 +216,31 @@ struct HRing {
     // across chains) so that the staging registers are DEAD during the element-wise stages between the chains, where the
     // backward kernel has no register to spare (kept alive there they cost ~480 spill instructions); the price is one exposed
     // L2 round trip per chain (seven per tile, ~2-3 % of a tile's cycles, mostly covered by the partner workgroup's wave).
+#if NVP_HRING_DEEP
+    // fp16 x 2 (one piece per wave and half-step): 1 + NVP_HRING_DEEP half-steps in flight in registers - the piece published at
+    // half-step hs was requested 2 + NVP_HRING_DEEP half-steps earlier instead of two (one more quad of registers per level; the L2
+    // round trip under load is longer than two half-steps of MFMAs)
+    u32x4 nx[NVP_HRING_DEEP];
+    __device__ __forceinline__ u32x4 load_piece(int hs) const { return (g + (int64_t)hs * kHalfQuads + wv * 64)[(unsigned)lane]; }
+    __device__ __forceinline__ void open(int hs0, int nh) {
+        chain_end = hs0 + nh;
+        fetch(hs0);
+        publish(hs0);
+        if (nh > 1) fetch(hs0 + 1);
+#pragma unroll
+        for (int k = 0; k < NVP_HRING_DEEP; ++k)
+            if (nh > 2 + k) nx[k] = load_piece(hs0 + 2 + k);
+        end();
+    }
+    __device__ __forceinline__ const u32x4* begin(int hs) {
+        if (hs + 1 < chain_end) publish(hs + 1);
+        sg[0] = nx[0];
+#pragma unroll
+        for (int k = 0; k + 1 < NVP_HRING_DEEP; ++k) nx[k] = nx[k + 1];
+        if (hs + 2 + NVP_HRING_DEEP < chain_end) nx[NVP_HRING_DEEP - 1] = load_piece(hs + 2 + NVP_HRING_DEEP);
+        return lds + (hs & 1) * kHalfQuads;
+    }
+#else
     __device__ __forceinline__ void open(int hs0, int nh) {
         chain_end = hs0 + nh;
         fetch(hs0);
@@ -222,6 +253,7 @@ struct HRing {
         if (hs + 2 < chain_end) fetch(hs + 2);
         return lds + (hs & 1) * kHalfQuads;
     }
+#endif
 #ifdef NVP_ABL_NOBARRIER
     __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #else

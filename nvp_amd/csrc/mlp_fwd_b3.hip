@@ -33,9 +33,39 @@ __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __res
     const int j = lane & 31, h = lane >> 5;
 #if NVP_B3_ZUNROLL
     if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
+#if NVP_CHAIN_PF_STEP == 2
+        // tile pairs, one pair of operand quads in flight ahead of the pair being multiplied (see chain_h_b3)
+        const unsigned ul = (unsigned)lane;
+        u32x4 a[2][2][kP];
+        auto load_pair = [&](int p, int buf) {
+            const u32x4* wp = w + NVP_WSTRIDE((p >> 1) * kB3StepQuads) + (p & 1) * 2 * kP * 64;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < kP; ++k) a[buf][t][k] = (wp + (t * kP + k) * 64)[ul];
+        };
+        load_pair(0, 0);
+        BOp b;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (p + 1 < 16) load_pair(p + 1, (p + 1) & 1);
+            if ((p & 1) == 0) {
+                const int s = p >> 1;
+                const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+                const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+                const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                split8(x, sc, b);
+            }
+            NVP_CHAIN_FENCE();
+            mac_parts(acc[2 * (p & 1)], a[p & 1][0], b);
+            mac_parts(acc[2 * (p & 1) + 1], a[p & 1][1], b);
+        }
+        return;
+#else
 #pragma unroll
         for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane);
         return;
+#endif
     }
 #endif
 #pragma unroll 1
