@@ -300,8 +300,10 @@ __device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& h
     }
 }
 
-__device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane) {
-    R.open(hs, 16);
+// `open_nh`: half-steps to open the ring for (16 = this chain alone; more = the chains that follow are fed by the same fill,
+// 0 = a previous chain already opened the ring for this one: one exposed L2 round trip less)
+__device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane, int open_nh = 16) {
+    if (open_nh) R.open(hs, open_nh);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
@@ -314,8 +316,8 @@ __device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 
 
 // two transposed GEMMs over the SAME input registers, one operand split per k-step; the packed stream interleaves the two
 // weight streams k-step by k-step (a's step c, then b's step c)
-__device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&acc_b)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane) {
-    R.open(hs, 32);
+__device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&acc_b)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane, int open_nh = 32) {
+    if (open_nh) R.open(hs, open_nh);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];

@@ -6,6 +6,10 @@
 // accumulator); the packed weights are read from the consumption-ordered copy behind the tables (mlp_layout.h).
 #include "mlp_b3_ring.h"
 
+#ifndef NVP_RING_MERGE_OPEN
+#define NVP_RING_MERGE_OPEN 0     // experiment: a layer's dx chain and its shared dz / dh pass are fed by ONE ring fill (48 half-steps)
+#endif
+
 namespace {
 
 constexpr int kWaves = 4;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
         {
             const PxScale pq = px_scale(fmaxf(px_absmax(dx), kTinyMax));
-            chain_h_b3_hring(acc, dx, pq.s, R, hs, lane);        // streams 0 (sir2^T), 1 (sir1^T)
+            chain_h_b3_hring(acc, dx, pq.s, R, hs, lane, NVP_RING_MERGE_OPEN ? 48 : 16);        // streams 0 (sir2^T), 1 (sir1^T)
             scale4(acc, pq.u * wsc[8 + 2 - k]);
         }
 #pragma unroll
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
             }
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
-            chain_h2_b3_hring(dzacc, acc, dh, pp.s, R, hs, lane);    // streams 6/2 (z2^T, mod2h^T), 5/3 (z1^T, mod1h^T), interleaved per k-step
+            chain_h2_b3_hring(dzacc, acc, dh, pp.s, R, hs, lane, NVP_RING_MERGE_OPEN ? 0 : 32);    // streams 6/2 (z2^T, mod2h^T), 5/3 (z1^T, mod1h^T), interleaved per k-step
             scale4(acc, pp.u * wsc[8 + 4 - k]);
             scale4(dzacc, pp.u * wsc[8 + 4 + k]);
 #pragma unroll
