@@ -492,6 +492,28 @@ def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
         assert torch.equal(a, b), "two-call scatter differs from the single call"
 
 
+def test_whole_backward_is_exactly_linear_in_the_upstream_gradient():
+    """Every scale inside the backward pass is a power of two taken from the data (per-pixel operand scales of the MLP chains, the
+    running block scale of the dW GEMMs, the fixed-point scale of the grid scatter), so multiplying the upstream gradient by 2^-17
+    must multiply EVERY parameter gradient of the fused NVP path by exactly 2^-17 - a size-independent check that no scale is
+    applied twice, dropped, or taken from stale data."""
+    cfg, sd, model = _nvp_pair(2)
+    gen = torch.Generator().manual_seed(91)
+    n = 30000
+    coords = torch.rand((n, 3), generator=gen)
+    coords = coords[torch.argsort(coords[:, 2])].unsqueeze(0).to(dev())
+    steps = torch.rand((1, n), generator=gen).to(dev())
+    w = (torch.randn((1, n, 3), generator=gen) * 1e-2).to(dev())
+    mi = {"all_coords": coords, "temporal_steps": steps, "sorted_by_y": True}
+    got = []
+    for k in (0, -17):
+        model.zero_grad(set_to_none=True)
+        (model(mi)["model_out"] * (w * 2.0 ** k)).sum().backward()
+        got.append({name: p.grad.clone() for name, p in model.named_parameters()})
+    for name in got[0]:
+        assert torch.equal(got[0][name], got[1][name] * 2.0 ** 17), f"{name}: backward is not exactly linear in the upstream gradient"
+
+
 @pytest.mark.parametrize("F,n,border", [(2, 200000, "wrap"), (4, 70000, "wrap"), (2, 3000, "wrap"), (2, 257, "clamp"), (2, 50000, "clamp")])
 def test_sorted_hint_forward_is_bit_identical(F, n, border):
     """The sorted_by_y hint must never change a bit of the forward result - whichever gather serves it: by default the global
