@@ -291,8 +291,16 @@ __global__ __launch_bounds__(256) void rowstart_kernel(RowArgs A, int64_t n) {
     A.rowstart[plane][idx] = (int)lo;
 }
 
-// value * 2^k as a signed 64-bit integer, round-half-up in magnitude
+// value * 2^k as a signed 64-bit integer (|value * 2^k| < 2^41 by the choice of k: max|dz| * 2^k < 2^(62 - headroom), headroom >= 21).
+// The band kernels are VALU-bound on this conversion (478 M of them per step), so it is built from what the hardware converts
+// natively: t = v 2^k (exact, v_ldexp_f32) is cut into hi = trunc(t 2^-20) (|hi| < 2^21: v_cvt_i32_f32) and lo = t - hi 2^20
+// (one exact fma, |lo| < 2^20, rounded to nearest even) - 11 instructions instead of the 23 of a hand-rolled mantissa shift.
+// NVP_TO_FIXED_SHIFT=1 selects that earlier formulation (round-half-up in magnitude; differs from this one only on exact ties).
+#ifndef NVP_TO_FIXED_SHIFT
+#define NVP_TO_FIXED_SHIFT 0
+#endif
 __device__ __forceinline__ long long to_fixed(float v, int k) {
+#if NVP_TO_FIXED_SHIFT
     const unsigned b = __float_as_uint(v);
     const int e = (b >> 23) & 0xff;
     const unsigned m = (b & 0x7fffffu) | (e ? 0x800000u : 0u);
@@ -304,6 +312,11 @@ __device__ __forceinline__ long long to_fixed(float v, int k) {
         q = rs > 24 ? 0 : (long long)((m + (1u << (rs - 1))) >> rs);
     }
     return (b >> 31) ? -q : q;
+#else
+    const float th = truncf(ldexpf(v, k - 20));
+    const float lo = __builtin_fmaf(th, -1048576.0f, ldexpf(v, k));
+    return ((long long)(int)th << 20) + (long long)__float2int_rn(lo);
+#endif
 }
 
 struct BandArgs {
@@ -574,7 +587,9 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     if ((!do_sparse || !do_dense) && !planes_ready) return NVP_ERR_BADARG;      // the split calls need the sparse max from the chain kernel
     int hb = 1;
     while (((int64_t)1 << hb) < n) ++hb;
-    const int headroom_bits = hb + 1;
+    // n contributions of magnitude <= max|dz| must fit 2^62: log2(n) + 1 bits of headroom - and never fewer than 22, so that a
+    // single contribution stays below 2^40 (to_fixed converts it in two 32-bit halves) whatever the batch size
+    const int headroom_bits = hb + 1 > 22 ? hb + 1 : 22;
     int col = 0;
     for (int p = 0; p < 3; ++p) col += lv[p]->n_levels * lv[p]->n_features;
     const int scol0 = col, scols = 9 * sh->n_features;
