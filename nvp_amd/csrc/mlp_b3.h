@@ -80,8 +80,9 @@ __device__ __forceinline__ f32x16 mf_bf16(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 #ifndef NVP_SPLIT_ASM
-#define NVP_SPLIT_ASM 0          // 1: hand-selected v_fma_mix sequence for the fp16 x 2 split, 2 instead of 3 instructions per value, same bits -
-                                 // measured SLOWER (dW 1.80 vs 1.73 ms, chains unchanged: four dependent partial-register writes per pair)
+#define NVP_SPLIT_ASM 0          // fp16 x 2 split, instruction selection (same bits): 0 = hipcc's (3 per value); 1 = four v_fma_mix per pair (2 per
+                                 // value) - SLOWER, dW 1.80 vs 1.73 ms: v_fma_mix is not full rate; 2 = hi by hipcc, the two residuals as v_fma_mix
+                                 // with op_sel (2 per value, two of them mix): chains -0.02 ms each (their default), dW +0.19 ms (register limit)
 #endif
 // 8 floats -> parts.  fp16 x 2: of x * s.
 __device__ __forceinline__ void split8(const float (&x)[8], const float s, BOp& b) {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], const float s, BOp& 
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float a = x[2 * p], c = x[2 * p + 1];
-#if NVP_SPLIT_ASM
+#if NVP_SPLIT_ASM == 1
         // Two instructions per value: v_fma_mix{lo,hi}_f16 computes fma(x, s, c) in fp32 and writes the fp16 result into one
         // half of the destination; for the residual the addend is the matching HALF of the packed hi register (op_sel),
         // so hi is never unpacked.  (hipcc's own selection of the C code below spends three: it converts hi twice.)
@@ -106,6 +107,17 @@ __device__ __forceinline__ void split8(const float (&x)[8], const float s, BOp& 
             "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
             "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
             : "=&v"(hh), "=&v"(ll) : "v"(a), "v"(c), "v"(s));
+        b.p[0][p] = hh;
+        b.p[1][p] = ll;
+#elif NVP_SPLIT_ASM == 2
+        // hi from hipcc's v_pk_mul_f32 + v_cvt_pk_f16_f32; the two residuals as v_fma_mix{lo,hi}_f16 whose addend is the matching
+        // HALF of the packed hi register (op_sel) - hipcc's own selection converts hi a second time, once per half
+        const f16x2 h = {(_Float16)(a * s), (_Float16)(c * s)};
+        const unsigned hh = __builtin_bit_cast(unsigned, h);
+        unsigned ll;
+        asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+            : "=&v"(ll) : "v"(a), "v"(c), "v"(s), "v"(hh));
         b.p[0][p] = hh;
         b.p[1][p] = ll;
 #else

@@ -5,6 +5,9 @@
 // after it - both exact), the transposed weights come pre-split from pack_bwd_b3_kernel, products are accumulated in fp32.
 // Used for latents of <= 256 rows when the library is built with NVP_BWD_B3=1 (latent gradient fused up to 128 rows,
 // separate mlp_bwd_dz_b3_kernel beyond).
+#ifndef NVP_SPLIT_ASM
+#define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
+#endif
 #include "mlp_b3.h"
 
 #ifndef NVP_BWD_B3_SHARE

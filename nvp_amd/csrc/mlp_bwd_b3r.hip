@@ -4,6 +4,9 @@
 // 12 KiB per workgroup with two workgroups per CU) instead of 8 / 12 KiB of per-wave global loads per k-step.  Arithmetic,
 // streams, records and the latent gradient are those of mlp_bwd_b3_kernel<true>, bit for bit (same MFMA order per
 // accumulator); the packed weights are read from the consumption-ordered copy behind the tables (mlp_layout.h).
+#ifndef NVP_SPLIT_ASM
+#define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
+#endif
 #include "mlp_b3_ring.h"
 
 #ifndef NVP_RING_MERGE_OPEN

@@ -8,6 +8,9 @@
 // fewer matrix-pipe cycles.  Used for latents of <= 256 rows when the library is built with NVP_FWD_B3=1 (beyond 144
 // rows the rest is read from the tensor); everything else (element-wise stages, saved streams, RGB layout) is identical
 // to the fp32 kernel.
+#ifndef NVP_SPLIT_ASM
+#define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
+#endif
 #include "mlp_b3.h"
 
 #ifndef NVP_B3_ZUNROLL

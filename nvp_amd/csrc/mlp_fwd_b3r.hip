@@ -4,6 +4,9 @@
 // cooperatively by the workgroup's four waves instead of 8 / 12 KiB of per-wave global loads per k-step) and where the
 // latent comes from (the B operands of the latent k-steps are read from the PTM4 tensor one step ahead - 2 x 16 B per
 // lane and step - which frees the 64 KiB of LDS the per-wave latent tiles used, so two workgroups still share a CU).
+#ifndef NVP_SPLIT_ASM
+#define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
+#endif
 #include "mlp_b3_ring.h"
 
 #ifndef NVP_RING_FLAGS
