@@ -193,9 +193,13 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
     const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
     return max(max(a, b), max(c, d));
 }
-// the staging wave `wall` publishes its share of a tile's maxima next to the tile (slot set `par`)
-__device__ __forceinline__ void publish_max(unsigned* __restrict__ mx, int par, int wall, unsigned ma, unsigned mb, int lane) {
+// The staging wave `wall` publishes its share of a tile's maxima next to the tile (slot set `par`) - but only when one of its
+// values exceeds the running maximum (run_a / run_b: what every wave of the workgroup has derived from the tiles so far): a
+// tile that raises nothing needs no reduction, and whatever older tile's maxima its slots still hold are <= the running
+// maximum already, so they change nothing.  After the first few tiles of a chunk the wave-uniform branch is not taken.
+__device__ __forceinline__ void publish_max(unsigned* __restrict__ mx, int par, int wall, unsigned ma, unsigned mb, unsigned run_a, unsigned run_b, int lane) {
 #if NVP_SPLIT_H2
+    if (!__any(ma > run_a || mb > run_b)) return;
     ma = wave_umax(ma); mb = wave_umax(mb);
     if (lane == 0) { mx[(par * 2 + 0) * kMxW + wall] = ma; mx[(par * 2 + 1) * kMxW + wall] = mb; }
 #endif
@@ -269,7 +273,9 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
     if (t0 < t1) {
         load_stage<XF, NB>(st, J, t0, tid);
         write_stage<XF, NB>(lds, lds + kTileFloats, st, J, A, tab, t0, n, tid, wma, wmb);
-        publish_max(mx, 0, wall, wma, wmb, lane);
+        if (tid < 4 * kMxW) mx[tid] = 0u;            // a skipped publish leaves its slots untouched: start them below every running maximum
+        __syncthreads();
+        publish_max(mx, 0, wall, wma, wmb, 0u, 0u, lane);
     }
     // block-scale state: running maxima (bit patterns) per operand, the scale S = sA sB the accumulators are in, and 1 / S
     unsigned runA = __float_as_uint(kTinyMax), runB = __float_as_uint(kTinyMax);
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
         } else {
             if (more) write_stage<XF, NB>(lds + (cur ^ 1) * kBufFloats, lds + (cur ^ 1) * kBufFloats + kTileFloats, st, J, A, tab, t + 1, n, tid, wma, wmb);
         }
-        if (more) publish_max(mx, par ^ 1, wall, wma, wmb, lane);
+        if (more) publish_max(mx, par ^ 1, wall, wma, wmb, runA, runB, lane);
         par ^= 1;
 #if NVP_DW_DEPTH == 2
         st = st2;
