@@ -68,6 +68,10 @@ GRIDS_READY_HOOK = None
 # ... and this one as soon as the sparse grid's gradient alone has been enqueued (only when the scatter runs sparse-first: y-sorted
 # batches with the level-major hand-over); the dense planes follow, then GRIDS_READY_HOOK
 SPARSE_READY_HOOK = None
+# Optional callback(list of (parameter tensor, gradient tensor)) fired as soon as those grid gradients have been enqueued - the
+# sparse grid's first, then the three planes' (harness.train_step: optim.AdamW.early_update runs their AdamW on a side stream,
+# underneath the rest of the scatter and the dW GEMMs).  Only meaningful when each grid feeds ONE NVPFused call per step.
+EARLY_GRADS_HOOK = None
 
 # Batches that do not arrive sorted by their y coordinate (the reference's own sampler, dataio.py:104-120) are
 # put into that order inside NVPFused for the duration of the step and the RGB rows are returned in the
@@ -458,14 +462,21 @@ class NVPFused(torch.autograd.Function):
             dz_rows_ref[0] = dz_rows
             if presorted is not None:
                 torch.cuda.current_stream(coords.device).wait_event(presorted)
-            if SPARSE_READY_HOOK is not None and (flags & L.DZ_PLANES_READY):
-                # data parallel: the sparse grid (80 % of the gradient bytes) is scattered first and handed to the exchange while
-                # the dense planes are still being scattered
+            if (SPARSE_READY_HOOK is not None or EARLY_GRADS_HOOK is not None) and (flags & L.DZ_PLANES_READY):
+                # the sparse grid (80 % of the gradient bytes) is scattered first and handed on - to the data-parallel exchange, or
+                # to the optimizer - while the dense planes are still being scattered
                 scatter_call(flags | L.SCATTER_SPARSE_ONLY)
-                SPARSE_READY_HOOK()
+                if SPARSE_READY_HOOK is not None:
+                    SPARSE_READY_HOOK()
+                if EARLY_GRADS_HOOK is not None:
+                    EARLY_GRADS_HOOK([(emb, d_emb)])
                 scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
+                if EARLY_GRADS_HOOK is not None:
+                    EARLY_GRADS_HOOK([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
             else:
                 scatter_call(flags)
+                if EARLY_GRADS_HOOK is not None:
+                    EARLY_GRADS_HOOK([(emb, d_emb), (kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
             if GRIDS_READY_HOOK is not None:
                 GRIDS_READY_HOOK()            # e.g. start the (async) all-reduce of the grid gradients
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -18,6 +19,8 @@ N_SAMPLES = 1245184          # reference dataio.py:91
 # Optional callable fired inside train_step right after loss.backward() has returned (everything of backward is enqueued,
 # nothing of the gradient exchange / optimizer yet): bench.py records a HIP event there to time the exposed exchange.
 AFTER_BACKWARD_HOOK = None
+# one GPU, nvp_amd.optim.AdamW: update the grids on a side stream as soon as the scatter has produced their gradients (0: after backward)
+EARLY_ADAMW = os.environ.get("NVP_EARLY_ADAMW", "1") != "0"
 
 
 class ImageMSEU8(torch.autograd.Function):
@@ -165,12 +168,15 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
         functional.SPARSE_READY_HOOK = opt.start_first if sharded else None                 # ... the sparse grid's even earlier
     else:
         opt.zero_grad()
+        if EARLY_ADAMW and isinstance(opt, AdamW):
+            functional.EARLY_GRADS_HOOK = opt.early_update      # the grids' AdamW underneath the rest of backward (one GPU)
     try:
         loss.backward()
     finally:
         functional.GRAD_SINK = None
         functional.GRIDS_READY_HOOK = None
         functional.SPARSE_READY_HOOK = None
+        functional.EARLY_GRADS_HOOK = None
     if AFTER_BACKWARD_HOOK is not None:
         AFTER_BACKWARD_HOOK()
     if sharded:

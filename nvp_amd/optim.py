@@ -21,6 +21,51 @@ class AdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._early_done = set()        # id(param) of the parameters early_update() has already stepped in the current iteration
+        self._side = None               # side stream of early_update()
+        self._by_ptr = None
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
+    @torch.no_grad()
+    def early_update(self, pairs, grad_scale: float = 1.0) -> None:
+        """AdamW step of some parameters NOW, before backward has finished: `pairs` = [(parameter tensor, gradient tensor)] whose
+        gradients are complete on the current stream (functional.EARLY_GRADS_HOOK: NVP's grids, 99.7 % of the parameters, are
+        done after the scatter while the dW GEMMs - which read no grid parameter - still have 1.7 ms to run).  The update runs on a
+        side stream; step() skips what was updated here and joins the stream.  Same kernel, same scalars, same result as step()."""
+        if self._by_ptr is None:
+            self._by_ptr = {p.data_ptr(): (p, g) for g in self.param_groups for p in g["params"]}
+        lib = _lib.load()
+        dev = pairs[0][0].device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        ready = torch.cuda.Event()
+        ready.record()                                        # the gradients are complete at this point of the compute stream
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            for t, g in pairs:
+                ent = self._by_ptr.get(t.data_ptr())
+                if ent is None or id(ent[0]) in self._early_done:
+                    continue
+                p, group = ent
+                st = self._state_of(p)
+                st["step"] += 1
+                for x in (p, g, st["exp_avg"], st["exp_avg_sq"]):
+                    _lib.ptr(x)
+                if g.numel() != p.numel():
+                    raise RuntimeError("early_update: gradient and parameter sizes differ")
+                seg = (_lib.AdamwSeg * 1)(_lib.AdamwSeg(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
+                b1, b2 = group["betas"]
+                _lib.check(lib.nvp_adamw_step(seg, 1, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                              float(group["weight_decay"]), int(st["step"]), float(grad_scale), _lib.stream_ptr()),
+                           "nvp_adamw_step")
+                self._early_done.add(id(p))
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, schedule=None):
@@ -36,17 +81,16 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         info = {}                                   # id(param) -> (param, group, step, covered ranges)
+        early, self._early_done = self._early_done, set()
+        if early and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # the early updates are part of this step
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or id(p) in early:          # early_update() already stepped it in this iteration
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError("nvp_amd.optim.AdamW does not support sparse gradients")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st = self._state_of(p)
                 st["step"] += 1
                 for t in (p, p.grad, st["exp_avg"], st["exp_avg_sq"]):
                     _lib.ptr(t)                     # loud errors for CPU / non-contiguous tensors

@@ -773,6 +773,38 @@ def test_psnr_at_equal_steps_full_levels():
     assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"
 
 
+def test_early_grid_update_equals_the_in_order_optimizer_step():
+    """harness.train_step lets nvp_amd.optim.AdamW update the four grids on a side stream as soon as the scatter has produced their
+    gradients (functional.EARLY_GRADS_HOOK -> AdamW.early_update), underneath the dW GEMMs; the MLP tensors follow in step().
+    Same kernel, same scalars: after four steps with a cosine schedule every parameter and every moment must equal the in-order
+    optimizer's, bit for bit."""
+    from nvp_amd import harness
+    from nvp_amd.modules import NVP
+    cfg = small_cfg(F=2, T=6, X=20, Y=20)          # 16 levels: the level-major hand-over and with it the sparse-first, two-call scatter are on
+    video = torch.randint(0, 256, (6, 48, 64, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(dev())
+    results = []
+    for early in (True, False):
+        torch.manual_seed(11)
+        model = NVP(out_features=3, encoding_config=cfg).to(dev())
+        data = harness.DeviceVideo(video, n_samples=20000, seed=5)
+        opt, sched = harness.make_optimizer(model, total_steps=4)
+        old = harness.EARLY_ADAMW
+        harness.EARLY_ADAMW = early
+        try:
+            for _ in range(4):
+                mi, gt = data.sample()
+                harness.train_step(model, opt, sched, mi, gt)
+        finally:
+            harness.EARLY_ADAMW = old
+        torch.cuda.synchronize()
+        results.append(([p.detach().clone() for p in model.parameters()],
+                        [opt.state[p]["exp_avg_sq"].clone() for p in model.parameters()], [opt.state[p]["step"] for p in model.parameters()]))
+    (pa, va, sa), (pb, vb, sb) = results
+    assert sa == sb and all(x == 4 for x in sa)
+    for a, b in zip(pa + va, pb + vb):
+        assert torch.equal(a, b), "early grid update differs from the in-order optimizer step"
+
+
 @pytest.mark.gpu
 def test_adamw_kernel_matches_torch_adamw():
     """nvp_adamw_step against the reference's optimizer, torch.optim.AdamW (training.py:13),
