@@ -251,7 +251,8 @@ def main():
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = world * N_PX / (ms_per_step * 1e-3) / 1e6
     if rank == 0:
-        kms = {k: round(v[0], 4) for k, v in kernels.items()}
+        # per STEP: a stage that is called twice per step (the sparse-first, two-call scatter) counts with both calls
+        kms = {k: round(v[0] * v[1] / max(args.steps, 1), 4) for k, v in kernels.items()}
         # HBM bytes per launch measured with rocprofv3 PMC passes (tools/pmc.sh -> tools/pmc_summarize.py);
         # bench.py cannot collect counters itself, so it reports the committed measurement if present.
         traffic = {}
