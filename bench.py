@@ -163,7 +163,7 @@ def main():
     T, H, W = wl["video"]
     cfg = make_cfg(F, T)
     FLOP_PX, BYTES_PX = work_per_pixel(F)
-    model = NVP(out_features=3, encoding_config=cfg).to(dev)
+    model = NVP(out_features=3, encoding_config=cfg, verbose=False).to(dev)
     parallel.broadcast_parameters(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     video = torch.randint(0, 256, (T, H, W, 3), device=dev, dtype=torch.uint8, generator=g)   # synthetic u8 RGB (3.7 GB; 7.5 GB for 4K)

@@ -1,30 +1,46 @@
 #!/usr/bin/env bash
-# Build libnvp_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+# Build libnvp_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU), plus its all-fp32-MFMA twin
+# libnvp_hip_fp32mfma.so (same sources, -DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0: every MLP GEMM on v_mfma_f32_32x32x2_f32).
+# The twin is TEST INFRASTRUCTURE: tests/test_gpu_long_horizon.py trains both builds on identical batches to bound what the
+# split-operand 16-bit MFMA arithmetic of the default build does to the PSNR trajectory.  NVP_SKIP_TWIN=1 skips it.
 # A failed compile aborts the build: its old object is removed first and every job's exit status is
 # checked, so the link can never pick up a stale object (bare `wait` returns 0 whatever the jobs did).
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed ${NVP_EXTRA_FLAGS:-}"
-OBJS=()
-PIDS=()
-NAMES=()
-for f in encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r mlp_bwd mlp_bwd_b3 mlp_bwd_b3r mlp_dw harness optim; do
-  [ -f "$f.hip" ] || continue
-  if [ ! -f "$f.o" ] || [ "$f.hip" -nt "$f.o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$f.o" 2>/dev/null)" ] || [ ../../include/nvp_hip.h -nt "$f.o" ] || [ -n "${NVP_REBUILD:-}" ]; then
-    EXTRA=""
-    case "$f" in encode|encode_fwd_lds|encode_bwd|harness|optim) EXTRA="-ffp-contract=off";; esac   # separately rounded mul/add (index parity)
-    rm -f "$f.o"
-    "$HIPCC" $FLAGS $EXTRA -c "$f.hip" -o "$f.o" &
-    PIDS+=($!)
-    NAMES+=("$f")
-  fi
-  OBJS+=("$f.o")
-done
-rc=0
-for i in "${!PIDS[@]}"; do
-  if ! wait "${PIDS[$i]}"; then echo "build.sh: compiling ${NAMES[$i]}.hip FAILED" >&2; rm -f "${NAMES[$i]}.o"; rc=1; fi
-done
-if [ $rc -ne 0 ]; then rm -f libnvp_hip.so; exit 1; fi
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o libnvp_hip.so
-echo "built $(pwd)/libnvp_hip.so"
+SRCS="encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r mlp_bwd mlp_bwd_b3 mlp_bwd_b3r mlp_dw harness optim"
+
+# build_lib OUT.so OBJDIR "extra flags"
+build_lib() {
+  local out=$1 objdir=$2 extra=$3
+  local FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed ${NVP_EXTRA_FLAGS:-} $extra"
+  local OBJS=() PIDS=() NAMES=()
+  mkdir -p "$objdir"
+  # a change of flags invalidates every object of that directory
+  if [ ! -f "$objdir/.flags" ] || [ "$(cat "$objdir/.flags")" != "$FLAGS" ]; then rm -f "$objdir"/*.o; echo "$FLAGS" > "$objdir/.flags"; fi
+  for f in $SRCS; do
+    [ -f "$f.hip" ] || continue
+    local o="$objdir/$f.o"
+    if [ ! -f "$o" ] || [ "$f.hip" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o" 2>/dev/null)" ] || [ ../../include/nvp_hip.h -nt "$o" ] || [ -n "${NVP_REBUILD:-}" ]; then
+      local EXTRA=""
+      case "$f" in encode|encode_fwd_lds|encode_bwd|harness|optim) EXTRA="-ffp-contract=off";; esac   # separately rounded mul/add (index parity)
+      rm -f "$o"
+      "$HIPCC" $FLAGS $EXTRA -c "$f.hip" -o "$o" &
+      PIDS+=($!)
+      NAMES+=("$f")
+    fi
+    OBJS+=("$o")
+  done
+  local rc=0
+  for i in "${!PIDS[@]}"; do
+    if ! wait "${PIDS[$i]}"; then echo "build.sh: compiling ${NAMES[$i]}.hip ($out) FAILED" >&2; rm -f "$objdir/${NAMES[$i]}.o"; rc=1; fi
+  done
+  if [ $rc -ne 0 ]; then rm -f "$out"; exit 1; fi
+  "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$out"
+  echo "built $(pwd)/$out"
+}
+
+build_lib libnvp_hip.so obj ""
+if [ -z "${NVP_SKIP_TWIN:-}" ]; then
+  build_lib libnvp_hip_fp32mfma.so obj_fp32mfma "-DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0"
+fi

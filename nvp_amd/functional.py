@@ -62,16 +62,32 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
         st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
     return st
 
-# Optional callback fired inside NVPFused.backward as soon as the four grid gradients have been enqueued
-# (before the dW GEMMs): data parallelism starts their all-reduce there (parallel.GradBucket).
-GRIDS_READY_HOOK = None
-# ... and this one as soon as the sparse grid's gradient alone has been enqueued (only when the scatter runs sparse-first: y-sorted
-# batches with the level-major hand-over); the dense planes follow, then GRIDS_READY_HOOK
-SPARSE_READY_HOOK = None
-# Optional callback(list of (parameter tensor, gradient tensor)) fired as soon as those grid gradients have been enqueued - the
-# sparse grid's first, then the three planes' (harness.train_step: optim.AdamW.early_update runs their AdamW on a side stream,
-# underneath the rest of the scatter and the dW GEMMs).  Only meaningful when each grid feeds ONE NVPFused call per step.
-EARLY_GRADS_HOOK = None
+class StepHooks:
+    """Per-call hooks of ONE NVPFused forward/backward pair.  The caller (harness.train_step) creates one, hands it to the model as
+    `model_input['nvp_hooks']` and may fill it in any time before backward runs; backward reads it from its own autograd context,
+    so two models, two threads or two overlapping steps in one process never see each other's hooks (autograd runs backward on
+    its own worker thread: neither module globals nor thread-locals would be safe).
+
+      grad_sink     {param.data_ptr(): preallocated tensor} (data parallelism): backward writes that parameter's gradient straight
+                    into the tensor (a view of the flat exchange bucket) and returns it - no zero-fill / accumulate / flatten pass;
+      sparse_ready  callback() fired as soon as the sparse grid's gradient alone has been enqueued (only when the scatter runs
+                    sparse-first: y-sorted batches with the level-major hand-over); the dense planes follow;
+      grids_ready   callback() fired as soon as all four grid gradients have been enqueued (before the dW GEMMs): data parallelism
+                    starts their exchange there (parallel.GradBucket / ShardedAdamW);
+      early_grads   callback([(parameter tensor, gradient tensor)]) fired as soon as those grid gradients have been enqueued - the
+                    sparse grid's first, then the three planes' (optim.AdamW.early_update runs their AdamW on a side stream,
+                    underneath the rest of the scatter and the dW GEMMs).  Only meaningful when each grid feeds ONE NVPFused call
+                    per step."""
+    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads")
+
+    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None):
+        self.grad_sink, self.sparse_ready, self.grids_ready, self.early_grads = grad_sink, sparse_ready, grids_ready, early_grads
+
+    def clear(self) -> None:
+        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = None
+
+
+_NO_HOOKS = StepHooks()
 
 # Batches that do not arrive sorted by their y coordinate (the reference's own sampler, dataio.py:104-120) are
 # put into that order inside NVPFused for the duration of the step and the RGB rows are returned in the
@@ -90,15 +106,9 @@ CHECK_SORTED = os.environ.get("NVP_CHECK_SORTED", "0") == "1"
 # the row-major hand-over for every plane (bit-identical gradients either way).
 DZ_LEVEL_MAJOR = os.environ.get("NVP_DZ_LEVEL_MAJOR", "1") != "0"
 
-# Optional gradient sink (data parallelism): {param.data_ptr(): preallocated tensor}.  When a
-# parameter has an entry, backward writes its gradient straight into that tensor (a view of the
-# flat all-reduce bucket) and returns it, so no zero-fill / accumulate / flatten pass exists.
-GRAD_SINK = None
-
-
-def _grad_buffer(param: torch.Tensor) -> torch.Tensor:
-    if GRAD_SINK is not None:
-        t = GRAD_SINK.get(param.data_ptr())
+def _grad_buffer(param: torch.Tensor, sink=None) -> torch.Tensor:
+    if sink is not None:
+        t = sink.get(param.data_ptr())
         if t is not None and t.shape == param.shape and t.is_contiguous() and t.dtype == torch.float32:
             return t.detach()      # fresh alias (use_count 1) so autograd adopts it as .grad without a clone
     return torch.empty_like(param)
@@ -213,7 +223,7 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
 
 
 def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, saved: torch.Tensor,
-                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None, packed=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None, packed=None, sink=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """dX chain (+ latent gradient), then the dW GEMMs.  `between(dz_rows)`, if given, runs after the
     dX kernels are enqueued and before the dW kernels: the fused NVP path uses it to enqueue the grid
     scatter (which only needs dz) first, so its gradients can be all-reduced underneath the dW GEMMs."""
@@ -234,7 +244,7 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     # lm (optional, fused NVP path with y-sorted batches): the scatter's level-major buffers for the xy / yt planes
     L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
                                L.ptr(dy), L.ptr(dz_rows), C.byref(lm) if lm is not None else None, n, d, stream), "nvp_mlp_bwd_dx")
-    grads = [_grad_buffer(t) for t in mlp]
+    grads = [_grad_buffer(t, sink) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
     partials = torch.empty(lib.nvp_dw_partial_floats(d, nch), device=dev, dtype=torch.float32)
@@ -330,7 +340,7 @@ class NVPFused(torch.autograd.Function):
     (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""
 
     @staticmethod
-    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, grad_mode, y_sorted, *mlp):
+    def forward(ctx, coords, steps, kf_xy, kf_yt, kf_xt, emb, lv_xy, lv_yt, lv_xt, temporal_interp, grad_mode, y_sorted, hooks, *mlp):
         lib = L.load()
         coords = _f32c(coords)
         steps = _f32c(steps).reshape(-1)
@@ -370,6 +380,17 @@ class NVPFused(torch.autograd.Function):
             pk_f = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
             pk_b = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32) if bwd_follows else None
             side.wait_stream(torch.cuda.current_stream(dev))     # allocations, parameters and coordinates are ordered on the compute stream
+            # Lifetimes: these buffers come from the COMPUTE stream's allocator pool but are written (and the coordinates /
+            # parameters read) on the side stream.  If the autograd graph is dropped without a backward pass (a validation
+            # loss under grad mode, an exception between forward and backward), nothing ever makes the compute stream wait
+            # for the side stream again - record_stream keeps the allocator from handing the blocks out while the side
+            # stream may still be using them.
+            pk_f.record_stream(side)
+            coords.record_stream(side)
+            for t in mlp:
+                t.record_stream(side)
+            if pk_b is not None:
+                pk_b.record_stream(side)
             with torch.cuda.stream(side):
                 L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(pk_f), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
                 ev = torch.cuda.Event()
@@ -388,6 +409,7 @@ class NVPFused(torch.autograd.Function):
             ctx.bflags = bflags
             if SIDE_WORK:
                 side.wait_stream(torch.cuda.current_stream(dev))     # the workspace allocation
+                ctx.ws.record_stream(side)
                 with torch.cuda.stream(side):
                     L.check(lib.nvp_encode_bwd_presort(L.ptr(coords), n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh),
                                                        L.ptr(ctx.ws, torch.uint8), ws_bytes, bflags, L.stream_ptr()), "nvp_encode_bwd_presort")
@@ -406,6 +428,7 @@ class NVPFused(torch.autograd.Function):
             if temporal_interp:
                 raise NotImplementedError("temporal_interp=True is an inference-only path (reference eval.py --t_interp)")
             ctx.n, ctx.d = n, d
+            ctx.hooks = hooks
             ctx.order = order
             ctx.flags = L.COORDS_SORTED_BY_Y if y_sorted else 0
             ctx.lv = (lv_xy, lv_yt, lv_xt)
@@ -428,10 +451,12 @@ class NVPFused(torch.autograd.Function):
             drgb = drgb[ctx.order]
         if n == 0:
             z = [torch.zeros_like(t) for t in (kf_xy, kf_yt, kf_xt, emb)]
-            return (None, None, *z, None, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
+            return (None, None, *z, None, None, None, None, None, None, None, *[torch.zeros_like(t) for t in mlp])
         lv = ctx.lv
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
-        d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t) for t in (kf_xy, kf_yt, kf_xt, emb))
+        hk = ctx.hooks if ctx.hooks is not None else _NO_HOOKS
+        sink = hk.grad_sink
+        d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt, emb))
 
         # scatter workspace: allocated (and its coordinate-only part started) in forward
         ws, flags, presorted, lm = ctx.ws, ctx.bflags, ctx.presorted, None
@@ -462,25 +487,25 @@ class NVPFused(torch.autograd.Function):
             dz_rows_ref[0] = dz_rows
             if presorted is not None:
                 torch.cuda.current_stream(coords.device).wait_event(presorted)
-            if (SPARSE_READY_HOOK is not None or EARLY_GRADS_HOOK is not None) and (flags & L.DZ_PLANES_READY):
+            if (hk.sparse_ready is not None or hk.early_grads is not None) and (flags & L.DZ_PLANES_READY):
                 # the sparse grid (80 % of the gradient bytes) is scattered first and handed on - to the data-parallel exchange, or
                 # to the optimizer - while the dense planes are still being scattered
                 scatter_call(flags | L.SCATTER_SPARSE_ONLY)
-                if SPARSE_READY_HOOK is not None:
-                    SPARSE_READY_HOOK()
-                if EARLY_GRADS_HOOK is not None:
-                    EARLY_GRADS_HOOK([(emb, d_emb)])
+                if hk.sparse_ready is not None:
+                    hk.sparse_ready()
+                if hk.early_grads is not None:
+                    hk.early_grads([(emb, d_emb)])
                 scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
-                if EARLY_GRADS_HOOK is not None:
-                    EARLY_GRADS_HOOK([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
+                if hk.early_grads is not None:
+                    hk.early_grads([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
             else:
                 scatter_call(flags)
-                if EARLY_GRADS_HOOK is not None:
-                    EARLY_GRADS_HOOK([(emb, d_emb), (kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
-            if GRIDS_READY_HOOK is not None:
-                GRIDS_READY_HOOK()            # e.g. start the (async) all-reduce of the grid gradients
+                if hk.early_grads is not None:
+                    hk.early_grads([(emb, d_emb), (kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
+            if hk.grids_ready is not None:
+                hk.grids_ready()            # e.g. start the (async) all-reduce of the grid gradients
 
         # order: dX chain -> grid scatter (needs only dz) -> dW GEMMs (independent of the scatter)
         packed_bwd, ctx.packed_bwd = ctx.packed_bwd, None
-        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm, packed=packed_bwd)
-        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, *grads)
+        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm, packed=packed_bwd, sink=sink)
+        return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, None, *grads)

@@ -88,6 +88,8 @@ class DeviceVideo:
         return batch
 
     def _issue(self) -> None:
+        # the video and the coordinate tables may still be being produced on the caller's stream (procedural_video, a H2D copy)
+        self._side.wait_stream(torch.cuda.current_stream(self.video.device))
         with torch.cuda.stream(self._side):
             batch = self._draw()
             ev = torch.cuda.Event()
@@ -159,24 +161,23 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     sharded = isinstance(opt, ShardedAdamW)
     if sharded:
         bucket = opt.bucket
-    out = model(model_input)["model_out"]
+    hooks = functional.StepHooks()                  # this step's own hooks: read by this call's backward only (re-entrant)
+    out = model(dict(model_input, nvp_hooks=hooks))["model_out"]
     loss = image_mse_u8(out, gt["img"])
     if bucket is not None:
         bucket.detach_grads()                       # == zero_grad(set_to_none=True)
-        functional.GRAD_SINK = bucket.sink()        # backward writes straight into the flat buffer
-        functional.GRIDS_READY_HOOK = opt.start_early if sharded else bucket.start_early   # grid grads exchanged underneath the dW GEMMs
-        functional.SPARSE_READY_HOOK = opt.start_first if sharded else None                 # ... the sparse grid's even earlier
+        hooks.grad_sink = bucket.sink()             # backward writes straight into the flat buffer
+        hooks.grids_ready = opt.start_early if sharded else bucket.start_early   # grid grads exchanged underneath the dW GEMMs
+        hooks.sparse_ready = opt.start_first if sharded else None                 # ... the sparse grid's even earlier
     else:
         opt.zero_grad()
         if EARLY_ADAMW and isinstance(opt, AdamW):
-            functional.EARLY_GRADS_HOOK = opt.early_update      # the grids' AdamW underneath the rest of backward (one GPU)
+            opt.begin_step()                        # forget early updates of an iteration whose step() never ran (exception)
+            hooks.early_grads = opt.early_update    # the grids' AdamW underneath the rest of backward (one GPU)
     try:
         loss.backward()
     finally:
-        functional.GRAD_SINK = None
-        functional.GRIDS_READY_HOOK = None
-        functional.SPARSE_READY_HOOK = None
-        functional.EARLY_GRADS_HOOK = None
+        hooks.clear()
     if AFTER_BACKWARD_HOOK is not None:
         AFTER_BACKWARD_HOOK()
     if sharded:
@@ -336,6 +337,82 @@ def load_video(path: str, frames: int, height: int = 0, width: int = 0) -> torch
                 out[i] = np.clip(np.stack((r, g, b), -1) + 0.5, 0, 255).astype(np.uint8)
         return torch.from_numpy(out)
     raise ValueError(f"unsupported video source {path!r}: expected .npy, a PNG directory or .yuv")
+
+
+def _pink_field(ch: int, h: int, w: int, alpha: float, gen: torch.Generator, device, r0: float = 0.0) -> torch.Tensor:
+    """[ch, h, w] fields whose amplitude spectrum falls as 1 / f^alpha (power 1 / f^(2 alpha): alpha = 1 is the classic
+    natural-image spectrum), zero mean, unit standard deviation per channel."""
+    noise = torch.randn((ch, h, w), generator=gen, device=device)
+    fy = torch.fft.fftfreq(h, device=device)[:, None]
+    fx = torch.fft.rfftfreq(w, device=device)[None, :]
+    r = torch.sqrt(fx * fx + fy * fy)
+    filt = 1.0 / torch.clamp(r + r0, min=1.0 / max(h, w)) ** alpha
+    filt[0, 0] = 0.0
+    out = torch.fft.irfft2(torch.fft.rfft2(noise) * filt, s=(h, w))
+    return (out - out.mean(dim=(1, 2), keepdim=True)) / out.std(dim=(1, 2), keepdim=True)
+
+
+def natural_video(T: int, H: int, W: int, device, seed: int = 0, grain: float = 1.5, alpha: float = 1.0, n_objects: int = 6) -> torch.Tensor:
+    """Synthetic clip with NATURAL-IMAGE STATISTICS - a stand-in for the UVG clips the reference's README table is measured
+    on (README.md:92-100), which are not shipped and cannot be fetched.  NOT UVG: numbers measured on it only say how the
+    encoder behaves on content with a 1/f spectrum, edges, motion and sensor noise instead of a handful of sinusoids.
+
+      * scene: a texture larger than the frame with a 1/f^alpha amplitude spectrum (luma + weaker, smoother chroma), cut by
+        the level sets of a smoother field into regions of different brightness (occlusion-like edges);
+      * global motion: the camera pans (two incommensurate sinusoids) and breathes (+-2 % zoom) over the scene, sub-pixel
+        bilinear resampling per frame;
+      * local motion: `n_objects` soft-edged discs with their own texture and brightness cross the frame on curved paths;
+      * grain: independent Gaussian noise per frame, pixel and channel (`grain` 8-bit levels: caps the PSNR any encoder can
+        reach at about 20 log10(255 / grain) dB = 44.6 dB for 1.5).
+    Deterministic for a (device type, seed).  uint8 [T, H, W, 3] on `device`."""
+    import torch.nn.functional as Fn
+    device = torch.device(device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    pad_y, pad_x = max(2, int(0.12 * H)), max(2, int(0.12 * W))
+    Hs, Ws = H + 2 * pad_y, W + 2 * pad_x
+    luma = _pink_field(1, Hs, Ws, alpha, gen, device)
+    chroma = _pink_field(2, Hs, Ws, alpha + 0.4, gen, device)
+    region = _pink_field(1, Hs, Ws, 1.8, gen, device)[0]
+    luma = 0.55 * luma + 0.9 * (region > 0.35).float() - 0.7 * (region < -0.6).float() + 0.35 * (region.abs() < 0.08).float()
+    luma = (luma - luma.mean()) / luma.std()
+    c1, c2 = 0.07 * chroma[0], 0.07 * chroma[1]
+    y = 0.45 + 0.17 * luma[0]
+    scene = torch.stack((y + 1.402 * c2, y - 0.344 * c1 - 0.714 * c2, y + 1.772 * c1), dim=0)[None]       # [1,3,Hs,Ws]
+    obj_tex = _pink_field(3, Hs, Ws, alpha, gen, device)[None] * 0.16
+    # object parameters (host side, from a CPU generator so that they do not depend on the device's RNG stream)
+    hg = torch.Generator().manual_seed(seed + 77)
+    ob = torch.rand((n_objects, 8), generator=hg)
+    ys = torch.linspace(-1, 1, H, device=device)[:, None].expand(H, W)
+    xs = torch.linspace(-1, 1, W, device=device)[None, :].expand(H, W)
+    py = torch.arange(H, device=device, dtype=torch.float32)[:, None]
+    px = torch.arange(W, device=device, dtype=torch.float32)[None, :]
+    out = torch.empty((T, H, W, 3), device=device, dtype=torch.uint8)
+    for f in range(T):
+        t = f / max(T - 1, 1)
+        # camera: pan inside the padding, slow zoom
+        oy = 0.8 * pad_y * math.sin(2 * math.pi * 0.45 * t + 1.0)
+        ox = 0.8 * pad_x * math.sin(2 * math.pi * 0.70 * t)
+        zoom = 1.0 + 0.02 * math.sin(2 * math.pi * 0.9 * t + 0.5)
+        gy = (ys * (H / 2) / zoom + oy) / (Hs / 2)
+        gx = (xs * (W / 2) / zoom + ox) / (Ws / 2)
+        img = Fn.grid_sample(scene, torch.stack((gx, gy), dim=-1)[None], mode="bilinear", padding_mode="border", align_corners=False)[0]
+        for k in range(n_objects):
+            o = ob[k]
+            rad = (0.04 + 0.10 * float(o[0])) * H
+            cy = (0.15 + 0.7 * float(o[1])) * H + 0.25 * H * math.sin(2 * math.pi * (0.3 + float(o[2])) * t + 6.28 * float(o[3]))
+            cx = (-0.1 + 1.2 * ((float(o[4]) + (0.4 + 0.8 * float(o[5])) * t) % 1.0)) * W
+            d = torch.sqrt((py - cy) ** 2 + (px - cx) ** 2)
+            a = torch.clamp((rad - d) / 1.5 + 0.5, 0, 1)[None]                                  # soft 1.5-px edge
+            # the object's texture moves with it: sample obj_tex at (pixel - centre) + a per-object offset
+            ty = ((py - cy) + (0.2 + 0.6 * float(o[6])) * Hs - Hs / 2) / (Hs / 2)
+            tx = ((px - cx) + (0.2 + 0.6 * float(o[7])) * Ws - Ws / 2) / (Ws / 2)
+            tex = Fn.grid_sample(obj_tex, torch.stack((tx.expand(H, W), ty.expand(H, W)), dim=-1)[None], mode="bilinear",
+                                 padding_mode="border", align_corners=False)[0]
+            col = torch.tensor([0.25 + 0.5 * float(o[(k + c) % 8]) for c in range(3)], device=device)[:, None, None]
+            img = img * (1 - a) + (col + tex) * a
+        img = img * 255.0 + grain * torch.randn((3, H, W), generator=gen, device=device)
+        out[f] = torch.clamp(img + 0.5, 0, 255).to(torch.uint8).permute(1, 2, 0)
+    return out
 
 
 def procedural_video(T: int, H: int, W: int, device, seed: int = 0) -> torch.Tensor:

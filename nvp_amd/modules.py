@@ -39,8 +39,8 @@ class NVP(nn.Module):
         latent_dim += c3["n_features_per_level"] * 9
         self.latent_dim = latent_dim
         self.wrapper = modulation.SirenWrapper(self.net, latent_dim=latent_dim)
-        if kwargs.get("verbose", False):
-            print(self)          # the reference prints unconditionally (modules.py:49)
+        if kwargs.get("verbose", True):
+            print(self)          # as the reference does (modules.py:49); verbose=False (not a reference argument) silences it
 
     def forward(self, model_input, temporal_interp=False, params=None):
         timesteps = model_input['temporal_steps']
@@ -53,5 +53,6 @@ class NVP(nn.Module):
                              self.keyframes_xy.levels, self.keyframes_yt.levels, self.keyframes_xt.levels,
                              bool(temporal_interp), torch.is_grad_enabled(),
                              bool(model_input.get('sorted_by_y', False)),   # optional hint from nvp_amd's own sampler
+                             model_input.get('nvp_hooks'),                  # optional functional.StepHooks of this call (harness.train_step)
                              *self.wrapper.mlp_tensors())
         return {'model_out': out.reshape((b, t, 3))}

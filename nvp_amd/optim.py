@@ -33,13 +33,20 @@ class AdamW(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
 
+    def begin_step(self) -> None:
+        """Start of an iteration: forget the early updates of an earlier iteration whose step() never ran (an exception between
+        backward and step would otherwise make the next iteration skip those parameters' early update silently)."""
+        self._early_done.clear()
+
     @torch.no_grad()
     def early_update(self, pairs, grad_scale: float = 1.0) -> None:
         """AdamW step of some parameters NOW, before backward has finished: `pairs` = [(parameter tensor, gradient tensor)] whose
         gradients are complete on the current stream (functional.EARLY_GRADS_HOOK: NVP's grids, 99.7 % of the parameters, are
         done after the scatter while the dW GEMMs - which read no grid parameter - still have 1.7 ms to run).  The update runs on a
         side stream; step() skips what was updated here and joins the stream.  Same kernel, same scalars, same result as step()."""
-        if self._by_ptr is None:
+        # parameter lookup by storage address; rebuilt whenever an address went stale (p.data re-homed into a flat buffer,
+        # `enc.params = ...` rebinds are new Parameter objects and never reach this optimizer)
+        if self._by_ptr is None or any(p.data_ptr() != k for k, (p, _) in self._by_ptr.items()):
             self._by_ptr = {p.data_ptr(): (p, g) for g in self.param_groups for p in g["params"]}
         lib = _lib.load()
         dev = pairs[0][0].device
@@ -54,6 +61,9 @@ class AdamW(torch.optim.Optimizer):
                 if ent is None or id(ent[0]) in self._early_done:
                     continue
                 p, group = ent
+                if p.grad is not None:
+                    continue            # autograd will ACCUMULATE into the existing .grad: `g` alone is not the gradient; step() handles it
+                g.record_stream(self._side)      # read here on the side stream; if autograd clones instead of adopting it, it is freed on the compute stream
                 st = self._state_of(p)
                 st["step"] += 1
                 for x in (p, g, st["exp_avg"], st["exp_avg_sq"]):

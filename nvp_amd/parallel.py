@@ -209,7 +209,7 @@ class GradBucket:
         self.attach()
 
     def sink(self) -> dict:
-        """{param.data_ptr(): bucket view} for nvp_amd.functional.GRAD_SINK: backward then writes each
+        """{param.data_ptr(): bucket view} for nvp_amd.functional.StepHooks.grad_sink: backward then writes each
         gradient directly into the flat buffer (every element exactly once - no zero-fill needed)."""
         self._sink_armed = True
         return {p.data_ptr(): v for p, v in zip(self.params, self.views)}
@@ -356,6 +356,41 @@ class ShardedAdamW(torch.optim.Optimizer):
                 if sum(e - a for a, e in rng) == f_hi - f_lo:
                     self._first_pieces = [i for i in range(self.n_early) if self.pieces[i][0] >= f_lo and self.pieces[i][1] <= f_hi]
 
+    # -- checkpointing (the reference saves optim.state_dict() next to the model: training.py:65-68, 90-93)
+    def state_dict(self):
+        """torch's layout ({'state', 'param_groups'}: lr, betas, eps, weight_decay - what CosineAnnealingLR drives) plus a
+        `sharded` entry with THIS RANK's share of the optimizer state: the AdamW moments of its shards, the global step count
+        (bias correction) and the piece / shard layout they refer to.  Every rank saves its own file (the moments exist
+        nowhere else); load_state_dict refuses a state whose layout (world size, rank, pieces) differs from this optimizer's."""
+        sd = super().state_dict()
+        sd["sharded"] = {"world": self.world, "rank": self.rank, "algo": self.algo, "padded": int(self.bucket.padded),
+                         "pieces": [tuple(int(v) for v in pc) for pc in self.pieces],
+                         "shards": [tuple(int(v) for v in sh) for sh in self.shards],
+                         "steps_done": int(self.steps_done),
+                         "exp_avg": self.exp_avg.detach().clone(), "exp_avg_sq": self.exp_avg_sq.detach().clone()}
+        return sd
+
+    def load_state_dict(self, state_dict) -> None:
+        sh = state_dict.get("sharded")
+        if sh is None:
+            raise ValueError("not a ShardedAdamW state_dict: no 'sharded' entry (a replicated torch.optim.AdamW / nvp_amd.optim.AdamW "
+                             "state holds whole-tensor moments and cannot be loaded into a sharded optimizer)")
+        mine = {"world": self.world, "rank": self.rank, "padded": int(self.bucket.padded),
+                "pieces": [tuple(int(v) for v in pc) for pc in self.pieces], "shards": [tuple(int(v) for v in s_) for s_ in self.shards]}
+        for k, v in mine.items():
+            got = sh[k] if k in ("world", "rank", "padded") else [tuple(int(x) for x in t) for t in sh[k]]
+            if got != v:
+                raise ValueError(f"ShardedAdamW.load_state_dict: the saved state's {k} ({got if k in ('world', 'rank', 'padded') else '...'}) "
+                                 f"does not match this optimizer's ({v if k in ('world', 'rank', 'padded') else '...'}): moments are sharded "
+                                 "per rank and per piece layout")
+        if sh["exp_avg"].numel() != self.exp_avg.numel() or sh["exp_avg_sq"].numel() != self.exp_avg_sq.numel():
+            raise ValueError("ShardedAdamW.load_state_dict: moment buffers have the wrong length")
+        super().load_state_dict({"state": state_dict.get("state", {}), "param_groups": state_dict["param_groups"]})
+        with torch.no_grad():
+            self.exp_avg.copy_(sh["exp_avg"].to(self.exp_avg.device))
+            self.exp_avg_sq.copy_(sh["exp_avg_sq"].to(self.exp_avg_sq.device))
+        self.steps_done = int(sh["steps_done"])
+
     # -- exchange of one piece: after wait(), flat[own shard] holds the cross-rank SUM of that shard
     def _reduce_piece(self, i: int):
         a, b = self.pieces[i]
@@ -376,7 +411,7 @@ class ShardedAdamW(torch.optim.Optimizer):
 
     def start_first(self) -> None:
         """Start the exchange of the early pieces that only hold `first` parameters; call once THEIR gradients are enqueued
-        (functional.SPARSE_READY_HOOK).  Optional: start_early() picks up whatever has not been started."""
+        (functional.StepHooks.sparse_ready).  Optional: start_early() picks up whatever has not been started."""
         if self._first_started or self._early_started or not self.bucket._sink_armed or not self._first_pieces:
             return
         self._first_started = True
@@ -386,7 +421,7 @@ class ShardedAdamW(torch.optim.Optimizer):
             self._first_event.record()              # the `first` gradients are complete at this point of the compute stream
 
     def start_early(self) -> None:
-        """Start the exchange of the (remaining) early grid pieces; call once their gradients are enqueued (GRIDS_READY_HOOK)."""
+        """Start the exchange of the (remaining) early grid pieces; call once their gradients are enqueued (functional.StepHooks.grids_ready)."""
         if self._early_started or not self.bucket._sink_armed:
             return
         self._early_started = True

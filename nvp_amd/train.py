@@ -53,7 +53,12 @@ def config(size: str, t_res: int) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["s", "l"], default="s")
-    ap.add_argument("--video", default="procedural", help="'procedural', a .npy file with uint8 [T,H,W,3], a directory of PNG frames, or a raw 4:2:0 .yuv")
+    ap.add_argument("--video", default="procedural", help="'procedural' (smooth sinusoid pattern), 'natural' (synthetic clip with natural-image statistics: "
+                                                          "1/f spectrum, edges, camera + object motion, grain - NOT UVG), a .npy file with uint8 [T,H,W,3], "
+                                                          "a directory of PNG frames, or a raw 4:2:0 .yuv")
+    ap.add_argument("--target-psnr", type=float, default=34.57, help="report the first step / second at which the evaluation PSNR (fp32 grids, and "
+                                                                     "8-bit grids with --eval-8bit) reaches this value (README.md:96: 34.57 dB)")
+    ap.add_argument("--eval-8bit", action="store_true", help="also evaluate with 8-bit de-quantised grids (eval.py:163-179) at every report")
     ap.add_argument("--log", default="", help="append the JSON report lines to this file")
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--height", type=int, default=1080)
@@ -72,11 +77,14 @@ def main():
     if args.video == "procedural":
         video = harness.procedural_video(args.frames, args.height, args.width, dev, seed=args.seed)
         source = "procedural moving pattern (UVG frames are not shipped)"
+    elif args.video == "natural":
+        video = harness.natural_video(args.frames, args.height, args.width, dev, seed=args.seed)
+        source = "synthetic clip with natural-image statistics (harness.natural_video) - NOT UVG"
     else:
         video = harness.load_video(args.video, args.frames, args.height, args.width).to(dev)
         source = args.video
     T, H, W = (int(v) for v in video.shape[:3])
-    model = NVP(out_features=3, encoding_config=config(args.config, T)).to(dev)
+    model = NVP(out_features=3, encoding_config=config(args.config, T), verbose=False).to(dev)
     data = harness.DeviceVideo(video, seed=args.seed, prefetch=True)
     frames = [int(round(i * (T - 1) / max(args.eval_frames - 1, 1))) for i in range(args.eval_frames)]
     n_slice = harness.eval_slices(H * W)
@@ -103,33 +111,54 @@ def main():
         total = max(int(rate * args.seconds * 0.97), 10)
     opt, sched = harness.make_optimizer(model, total_steps=total)
 
+    cfg = config(args.config, T)
+    kf_keys = (("keyframes_xy", "2d_encoding_xy"), ("keyframes_xt", "2d_encoding_xt"), ("keyframes_yt", "2d_encoding_yt"))
+
+    def eval_8bit() -> float:
+        """evaluation PSNR with the grids 8-bit quantised / de-quantised (eval.py:163-179 rebinds the parameters the same way);
+        the fp32 parameters are put back afterwards"""
+        with torch.no_grad():
+            keep = [(getattr(model, name), getattr(model, name).params) for name, _ in kf_keys]
+            keep_emb = model.sparse_grid.embeddings
+            try:
+                for (enc, p), (_, key) in zip(keep, kf_keys):
+                    enc.params = quantize.quantize_keyframes(p.detach(), cfg[key])
+                model.sparse_grid.embeddings = quantize.quantize_sparse_grid(keep_emb.detach())
+                return harness.eval_psnr(model, data, frames, n_slice=n_slice)
+            finally:
+                for enc, p in keep:
+                    enc.params = p
+                model.sparse_grid.embeddings = keep_emb
+
     torch.cuda.synchronize()
     train_s, seg = 0.0, time.perf_counter()          # evaluation time is excluded from the encode clock
+    reached = {}                                     # first report at which the target PSNR was met
     for step in range(total):
         loss = harness.train_step(model, opt, sched, *data.sample())
         if (step + 1) % args.report_every == 0 or step + 1 == total:
             torch.cuda.synchronize()
             train_s += time.perf_counter() - seg
-            emit({"step": step + 1, "seconds": round(train_s, 2), "train_psnr": round(harness.train_psnr(loss), 3),
-                  "eval_psnr": round(harness.eval_psnr(model, data, frames, n_slice=n_slice), 3),
-                  "mpx_per_s": round((step + 1) * data.n / train_s / 1e6, 2)})
+            rec = {"step": step + 1, "seconds": round(train_s, 2), "train_psnr": round(harness.train_psnr(loss), 3),
+                   "eval_psnr": round(harness.eval_psnr(model, data, frames, n_slice=n_slice), 3),
+                   "mpx_per_s": round((step + 1) * data.n / train_s / 1e6, 2)}
+            if args.eval_8bit:
+                rec["eval_psnr_8bit_grids"] = round(eval_8bit(), 3)
+            for key, name in (("eval_psnr", "fp32"), ("eval_psnr_8bit_grids", "8bit_grids")):
+                if key in rec and rec[key] >= args.target_psnr and name not in reached:
+                    reached[name] = {"step": step + 1, "seconds": rec["seconds"], "psnr": rec[key]}
+            emit(rec)
             torch.cuda.synchronize()
             seg = time.perf_counter()
     encode_s = train_s
 
     psnr_fp32 = harness.eval_psnr(model, data, frames, n_slice=n_slice)
-    with torch.no_grad():                                   # eval.py:163-179: rebind 8-bit de-quantised grids
-        cfg = config(args.config, T)
-        for name, key in (("keyframes_xy", "2d_encoding_xy"), ("keyframes_xt", "2d_encoding_xt"), ("keyframes_yt", "2d_encoding_yt")):
-            enc = getattr(model, name)
-            enc.params = quantize.quantize_keyframes(enc.params.detach(), cfg[key])
-        model.sparse_grid.embeddings = quantize.quantize_sparse_grid(model.sparse_grid.embeddings.detach())
-    psnr_q8 = harness.eval_psnr(model, data, frames, n_slice=n_slice)
+    psnr_q8 = eval_8bit()
     emit({"summary": True, "video": source, "frames": T, "height": H, "width": W, "config": "nvp_" + args.config,
                       "steps": total, "encode_seconds": round(encode_s, 2), "eval_frames": frames,
                       "psnr_fp32": round(psnr_fp32, 3), "psnr_8bit_grids": round(psnr_q8, 3),
                       "bpp_8bit": round(quantize.quantized_bpp(model, T, H, W), 4),
-                      "mpx_per_s": round(total * data.n / encode_s / 1e6, 2)})
+                      "mpx_per_s": round(total * data.n / encode_s / 1e6, 2),
+                      "target_psnr": args.target_psnr, "target_reached": reached})
 
 
 if __name__ == "__main__":

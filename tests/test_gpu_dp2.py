@@ -59,18 +59,16 @@ def _grads(model, batch, bucket):
     from nvp_amd import functional, harness
     coords, steps, gt = batch
     mi = {"all_coords": coords.unsqueeze(0).to("cuda:0"), "temporal_steps": steps.unsqueeze(0).to("cuda:0")}
+    hooks = functional.StepHooks()
+    mi["nvp_hooks"] = hooks
     loss = harness.image_mse_u8(model(mi)["model_out"], gt.unsqueeze(0).to("cuda:0"))
     if bucket is not None:
         bucket.detach_grads()
-        functional.GRAD_SINK = bucket.sink()
-        functional.GRIDS_READY_HOOK = bucket.start_early
+        hooks.grad_sink = bucket.sink()
+        hooks.grids_ready = bucket.start_early
     else:
         model.zero_grad()
-    try:
-        loss.backward()
-    finally:
-        functional.GRAD_SINK = None
-        functional.GRIDS_READY_HOOK = None
+    loss.backward()
     if bucket is not None:
         bucket.all_reduce_mean()
     torch.cuda.synchronize()
@@ -144,7 +142,7 @@ def test_two_rank_step_equals_single_process_on_the_whole_batch():
 # ------------------------------------------------------------------------------------------------------------
 # ZeRO-1 on the HIP path: reduce-scatter -> nvp_adamw_step on the own shard -> all-gather (parallel.ShardedAdamW)
 # ------------------------------------------------------------------------------------------------------------
-def _sharded_worker(rank, world, port, q, algo, backend, dev_index):
+def _sharded_worker(rank, world, port, q, algo, backend, dev_index, fast=False):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
                        "WORLD_SIZE": str(world), "LOCAL_RANK": str(dev_index)})
     from nvp_amd import harness, parallel
@@ -155,8 +153,19 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index):
     cfg = small_cfg(F=2, T=T, X=9, Y=7)
     mine = [halves[rank] for halves in _batches(T, H, W)]
     dev = f"cuda:{dev_index}"
+    if fast:
+        # the DEFAULT-ON fast path of the product: y-sorted batches with the promise flag -> level-major hand-over ->
+        # sparse-first two-call scatter -> StepHooks.sparse_ready -> ShardedAdamW.start_first (pieces inside the sparse grid go out
+        # while the dense planes scatter), two-event side-stream update (first_ev / early_ev, n_first split)
+        srt = []
+        for coords, steps, gt in mine:
+            o = torch.argsort(coords[:, 2], stable=True)
+            srt.append((coords[o], steps[o], gt[o]))
+        mine = srt
+    counts = {}
 
-    def run(mode):
+    def run(mode, early_update=True):
+        parallel.EARLY_UPDATE = early_update
         model = _model(cfg).to(dev)
         parallel.broadcast_parameters(model)
         opt, sched, bucket = harness.make_dp(model, STEPS, mode="sharded" if mode != "replicated" else "replicated",
@@ -166,18 +175,35 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index):
             bucket2 = parallel.GradBucket(parallel.unique_parameters(model), early=[model.keyframes_xy.params, model.keyframes_yt.params,
                                           model.keyframes_xt.params, model.sparse_grid.embeddings], chunk_elems=3_000_000,
                                           pad_to=parallel.ShardedAdamW.alignment(world))
-            opt = parallel.ShardedAdamW(bucket2, lr=1e-2, weight_decay=0.001, algo="all_to_all" if mode == "a2a" else "reduce_scatter")
+            opt = parallel.ShardedAdamW(bucket2, lr=1e-2, weight_decay=0.001, algo="all_to_all" if mode == "a2a" else "reduce_scatter",
+                                        first=[model.sparse_grid.embeddings] if fast else None)
             sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=STEPS, eta_min=1e-5)
             bucket = bucket2
             assert opt.n_early >= 8
+            if fast:
+                assert opt._first_pieces, "no exchange piece lies wholly inside the sparse grid"
+                orig = opt.start_first
+
+                def counted():
+                    if opt.bucket._sink_armed and not opt._first_started and not opt._early_started:
+                        counts[(mode, early_update)] = counts.get((mode, early_update), 0) + 1
+                    orig()
+                opt.start_first = counted
         for coords, steps, gt in mine:
             mi = {"all_coords": coords.unsqueeze(0).to(dev), "temporal_steps": steps.unsqueeze(0).to(dev)}
+            if fast:
+                mi["sorted_by_y"] = True
             harness.train_step(model, opt, sched, mi, {"img": gt.unsqueeze(0).to(dev)}, bucket=bucket)
         torch.cuda.synchronize()
         return [p.detach().cpu() for p in parallel.unique_parameters(model)]
 
     rep = run("replicated")
     sh = run(algo)
+    if fast:
+        assert counts.get((algo, True)) == STEPS, f"the sparse-first exchange did not run on every step: {counts}"
+        inorder = run(algo, early_update=False)           # NVP_DP_EARLY_UPDATE=0: update + all-gather in order on the compute stream
+        for a, b in zip(sh, inorder):
+            assert torch.equal(a, b), f"side-stream early update differs from the in-order one: max {float((a - b).abs().max())}"
     # world 2: a + b is order independent, the AdamW kernel is element-wise -> the sharded path is BIT-identical to all-reduce + full AdamW
     for a, b in zip(rep, sh):
         assert torch.equal(a, b), f"sharded ({algo}) and replicated parameters differ: max {float((a - b).abs().max())}"
@@ -190,11 +216,11 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index):
     q.put((rank, "ok"))
 
 
-def _spawn_sharded(algo, backend, devs):
+def _spawn_sharded(algo, backend, devs, fast=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, algo, backend, devs[r])) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, algo, backend, devs[r], fast)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -210,8 +236,18 @@ def test_two_rank_sharded_adamw_is_bit_identical_to_replicated(algo):
     _spawn_sharded(algo, "gloo", (0, 0))
 
 
+@pytest.mark.parametrize("algo", ["sharded", "a2a"])
+def test_two_rank_default_fast_path_sorted_batches_sparse_first(algo):
+    """The product's default-on fast path with two ranks on HIP tensors: y-sorted batches (sorted_by_y promise), the sparse-first
+    two-call scatter firing StepHooks.sparse_ready -> ShardedAdamW.start_first (checked: once per step), make_dp-style `first=`,
+    the two-event side-stream shard update - bit-identical to the replicated path AND to NVP_DP_EARLY_UPDATE=0."""
+    _spawn_sharded(algo, "gloo", (0, 0), fast=True)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (RCCL refuses two ranks on one device)")
 @pytest.mark.parametrize("algo", ["sharded", "a2a"])
-def test_two_gpu_rccl_sharded_adamw(algo):
-    """The same check over the real RCCL backend ("nccl") on two GPUs of one node; skipped on single-GPU boxes."""
-    _spawn_sharded(algo, "nccl", (0, 1))
+@pytest.mark.parametrize("fast", [False, True])
+def test_two_gpu_rccl_sharded_adamw(algo, fast):
+    """The same checks (sharded / a2a == replicated bit for bit; with `fast` the sorted-batch sparse-first path) over the real
+    RCCL backend ("nccl") on two GPUs of one node; skipped on single-GPU boxes."""
+    _spawn_sharded(algo, "nccl", (0, 1), fast=fast)

@@ -318,6 +318,123 @@ def test_operand_split_scaling_properties(D):
             q.grad = None
 
 
+@pytest.mark.parametrize("layer,unit", [(0, 17), (1, 70), (2, 127)])
+def test_kink_pixel_gradient_is_one_of_the_two_admissible_values(layer, unit):
+    """Every other gradient test stays away from LeakyReLU kinks (util_parity._away_from_kinks: at a pre-activation within
+    rounding of 0 the slope jumps 0.01 -> 1, so summation order legitimately decides which slope a unit gets).  This test goes
+    there on purpose: ONE pixel of the batch is placed so that modulator unit (layer, unit) has pre-activation 0 to within a few
+    1e-8 (bisection in float64).  At that pixel the function has exactly two one-sided derivatives; the HIP backward pass - the
+    latent gradient of every pixel and ALL fourteen parameter gradients, consistently - must equal one of the two float64
+    evaluations (slope forced to 1, or to 0.01, at that one unit), to the usual gradient tolerance, and not something else
+    (half-applied masks between the chain and the dW kernels, garbage from a sign test on the wrong stream...)."""
+    import torch.nn.functional as Fn
+    from nvp_amd import modulation
+    D, n, kp = 114, 64, 5
+    torch.manual_seed(40 + layer)
+    net = modulation.SirenNet(dim_in=1, dim_hidden=128, dim_out=3, num_layers=3, w0_initial=30.)
+    wrapper = modulation.SirenWrapper(net, latent_dim=D)
+    gen = torch.Generator().manual_seed(9)
+    lat = torch.randn(n, D, generator=gen) * 0.3
+    steps = torch.rand(n, 1, generator=gen)
+    up = torch.randn(n, 3, generator=gen) * 1e-2
+    Wm = [wrapper.modulator.layers[k][0].weight.detach().double() for k in range(3)]
+    bm = [wrapper.modulator.layers[k][0].bias.detach().double() for k in range(3)]
+    Ws = [net.layers[k].weight.detach().double() for k in range(3)] + [net.last_layer.weight.detach().double()]
+    bs = [net.layers[k].bias.detach().double() for k in range(3)] + [net.last_layer.bias.detach().double()]
+
+    def preacts(z):
+        h, ps = None, []
+        for k in range(3):
+            ps.append(Fn.linear(z if k == 0 else torch.cat((h, z), dim=1), Wm[k], bm[k]))
+            h = Fn.leaky_relu(ps[-1], 0.01)
+        return ps
+
+    def place_on_kink(zrow):
+        """move one pixel along a fixed direction until p[layer][unit] changes sign, then bisect (float64)"""
+        direction = Wm[0][unit if layer == 0 else 3].clone()
+        direction /= direction.norm()
+        f = lambda t: float(preacts(zrow + t * direction)[layer][0, unit])      # noqa: E731
+        f0, lo, hi = f(0.0), None, None
+        for t in [s_ * m for m in np.linspace(0.05, 6.0, 120) for s_ in (1.0, -1.0)]:
+            if f(t) * f0 < 0:
+                lo, hi = 0.0, t
+                break
+        if lo is None:
+            return None
+        for _ in range(80):
+            mid = 0.5 * (lo + hi)
+            if f(mid) * f0 > 0:
+                lo = mid
+            else:
+                hi = mid
+        return (zrow + 0.5 * (lo + hi) * direction).float()
+
+    # the kink pixel on the kink, every OTHER pre-activation of the batch (incl. the kink pixel's other units) away from 0:
+    # rows that violate that are redrawn (a handful of the 24 576 pre-activations land within 1e-4 of 0 by chance)
+    for attempt in range(200):
+        row = place_on_kink(lat[kp:kp + 1].double())
+        if row is not None:
+            lat[kp] = row[0]
+        ps = preacts(lat.double())
+        near = torch.stack([p.abs() < 1e-4 for p in ps])            # [3, n, 128]
+        near[layer, kp, unit] = False
+        bad = torch.nonzero(near.any(dim=0).any(dim=1)).flatten().tolist()
+        if row is None and kp not in bad:
+            bad.append(kp)
+        if not bad:
+            break
+        for i in bad:
+            lat[i] = torch.randn(D, generator=gen) * 0.3
+    else:
+        raise AssertionError("could not build a batch with exactly one kink")
+    z = lat.double()
+    ps = preacts(z)
+    assert abs(float(ps[layer][kp, unit])) < 2e-6, "the pixel did not land on the kink"       # fp32 rounding of the latent moves p by ~1e-7
+    others = torch.cat([p.abs().flatten() for p in ps])
+    assert int((others < 1e-4).sum()) == 1, "another unit sits at a kink too: the two-candidate argument would not hold"
+
+    def grads64(slope):
+        zz = z.clone().requires_grad_(True)
+        prm = [t.clone().requires_grad_(True) for t in Wm + bm + Ws + bs]
+        W_m, b_m, W_s, b_s = prm[0:3], prm[3:6], prm[6:10], prm[10:14]
+        h, hs = None, []
+        for k in range(3):
+            p_ = Fn.linear(zz if k == 0 else torch.cat((h, zz), dim=1), W_m[k], b_m[k])
+            h = Fn.leaky_relu(p_, 0.01)
+            if k == layer:                                  # the one-sided derivative: value s*p (= 0 to rounding), slope s
+                forced = torch.zeros_like(h, dtype=torch.bool)
+                forced[kp, unit] = True
+                h = torch.where(forced, slope * p_, h)
+            hs.append(h)
+        st = steps.double()
+        x = torch.sin(30.0 * Fn.linear(st, W_s[0], b_s[0])) * hs[0]            # modulation.py:83-92
+        x = torch.sin(Fn.linear(x, W_s[1], b_s[1])) * hs[1]
+        x = torch.sin(Fn.linear(x, W_s[2], b_s[2])) * hs[2]
+        rgb = Fn.linear(x, W_s[3], b_s[3])
+        rgb.backward(up.double())
+        return rgb.detach(), [zz.grad] + [t.grad for t in prm]
+
+    rgb64, g_hi = grads64(1.0)
+    _, g_lo = grads64(0.01)
+    sep = max(relerr_max(a.numpy(), b.numpy()) for a, b in zip(g_hi, g_lo))
+    assert sep > 1e-3, f"the two one-sided gradients do not differ enough to tell them apart ({sep})"
+
+    wrapper = wrapper.to(dev())
+    lat_d = lat.to(dev()).requires_grad_(True)
+    out = wrapper(coords=steps.to(dev()), latent=lat_d)
+    assert float((out.detach().cpu().double() - rgb64).abs().max()) <= RGB_TOL
+    out.backward(up.to(dev()))
+    mod, nt = wrapper.modulator, wrapper.net
+    got = [lat_d.grad] + [mod.layers[k][0].weight.grad for k in range(3)] + [mod.layers[k][0].bias.grad for k in range(3)] \
+        + [nt.layers[k].weight.grad for k in range(3)] + [nt.last_layer.weight.grad] + [nt.layers[k].bias.grad for k in range(3)] + [nt.last_layer.bias.grad]
+    errs = []
+    for cand in (g_hi, g_lo):
+        errs.append(max(relerr_max(a.detach().cpu().numpy(), b.numpy()) for a, b in zip(got, cand)))
+    report("kink_pixel", layer=layer, unit=unit, preact=float(ps[layer][kp, unit]), err_slope_1=errs[0], err_slope_001=errs[1], separation=sep)
+    assert min(errs) < GRAD_TOL_MAX, (f"at the kink the HIP gradients match neither one-sided derivative: vs slope 1 {errs[0]:.2e}, "
+                                      f"vs slope 0.01 {errs[1]:.2e} (the two differ by {sep:.2e})")
+
+
 def test_e2e_minus_keyframes_golden_and_trajectory():
     """[stand-in keyframe columns | SparseGrid] -> SirenWrapper -> mse, grads at step 0 and
     the 3-step AdamW + cosine loss trajectory captured from the reference (row H ordering)."""
@@ -480,12 +597,9 @@ def test_sorted_batch_hint_is_bit_identical_and_scatter_is_deterministic():
 
     def sparse_ready():
         seen["calls"] = seen.get("calls", 0) + 1
-    functional.SPARSE_READY_HOOK = sparse_ready
-    try:
-        model.zero_grad(set_to_none=True)
-        (model({"all_coords": coords, "temporal_steps": steps, "sorted_by_y": True})["model_out"] * w).sum().backward()
-    finally:
-        functional.SPARSE_READY_HOOK = None
+    model.zero_grad(set_to_none=True)
+    hooks = functional.StepHooks(sparse_ready=sparse_ready)        # this call's own hooks (harness.train_step does the same)
+    (model({"all_coords": coords, "temporal_steps": steps, "sorted_by_y": True, "nvp_hooks": hooks})["model_out"] * w).sum().backward()
     assert seen.get("calls") == 1, "the split scatter path did not run (level-major hand-over off?)"
     split = [p.grad for p in (model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings)]
     for a, b in zip(grads[1], split):
@@ -717,8 +831,8 @@ def test_psnr_at_equal_steps_matches_oracle(seed):
     product's own AdamW kernel, plus the full-frame evaluation PSNR of the final parameters.
 
     Each run also trains the oracle started <= 1 ulp away from itself: two fp32 trainings of this model drift apart whatever
-    computes them (sine layers with w0 = 30 amplify rounding differences), and the HIP-vs-oracle gap must not exceed twice that
-    envelope (measured on MI355X: gap 0.008-0.013 dB, envelope 0.006-0.011 dB, signed final differences -0.008 ... +0.011 dB: no
+    computes them (sine layers with w0 = 30 amplify rounding differences); that envelope is REPORTED next to the gap
+    (measured on MI355X: gap 0.008-0.013 dB, envelope 0.006-0.011 dB, signed final differences -0.008 ... +0.011 dB: no
     systematic sign - profiles/r02_parity_report.jsonl; against a float64 training the HIP path is closer than the fp32 oracle,
     profiles/r02_psnr_bisect_f64_f32_hip.txt).  12 of the 16 keyframe levels (0.36 M cells per
     plane instead of 4.6 M) keep the three CPU trainings of the checker affordable; the 16-level model is covered by
@@ -732,11 +846,10 @@ def test_psnr_at_equal_steps_matches_oracle(seed):
     report("psnr_equal_steps", seed=seed, n_levels=12, steps=steps_total, gap30=max(gap[:30]), gap=max(gap), envelope=max(env),
            final_hip_minus_oracle=pg[-1] - pa[-1], final_1ulp_minus_oracle=pb[-1] - pa[-1],
            eval_hip_minus_oracle=ev_g - ev_a, eval_1ulp_minus_oracle=ev_b - ev_a, final_psnr=pa[-1])
-    assert max(gap[:30]) <= 0.02, f"train-PSNR gap over the first 30 steps {max(gap[:30]):.4f} dB"
-    # +-0.02 dB (measured 0.008-0.013 dB); should a run drift further, it must at least stay inside twice the drift of the
-    # oracle against its own 1-ulp twin on the same batches
-    assert max(gap) <= max(0.02, 2.0 * max(env)), f"train-PSNR gap {max(gap):.4f} dB over {steps_total} steps (1-ulp envelope {max(env):.4f} dB)"
-    assert abs(ev_g - ev_a) <= max(0.02, 2.0 * abs(ev_b - ev_a)), f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
+    # north_star: +-0.02 dB, UNCONDITIONAL (measured 0.007-0.011 dB train, 0.001-0.004 dB eval).  The oracle's drift against its
+    # own 1-ulp twin on the same batches is reported next to it (envelope), it does not widen the bound.
+    assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB over {steps_total} steps (1-ulp envelope {max(env):.4f} dB)"
+    assert abs(ev_g - ev_a) <= 0.02, f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
 
 
 def test_psnr_at_equal_steps_full_levels():

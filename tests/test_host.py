@@ -224,11 +224,7 @@ def test_grad_sink_returns_fresh_alias():
     from nvp_amd import functional
     p = torch.nn.Parameter(torch.zeros(6))
     buf = torch.zeros(6)
-    functional.GRAD_SINK = {p.data_ptr(): buf}
-    try:
-        g = functional._grad_buffer(p)
-    finally:
-        functional.GRAD_SINK = None
+    g = functional._grad_buffer(p, {p.data_ptr(): buf})
     assert g is not buf and g.data_ptr() == buf.data_ptr()
     assert functional._grad_buffer(p).data_ptr() != buf.data_ptr()      # no sink -> private buffer
 

@@ -318,3 +318,55 @@ def test_sharded_adamw_single_process_has_no_cpu_update():
     lin.weight.grad.fill_(1.0); lin.bias.grad.fill_(0.0)
     opt2.step()
     assert torch.allclose(lin.weight, w0 - 1e-2, atol=1e-6)             # first Adam step: -lr * sign(g)
+
+
+def test_sharded_adamw_state_dict_round_trip():
+    """the reference checkpoints optim.state_dict() (training.py:65-68, 90-93).  ShardedAdamW keeps its moments and
+    its step counter outside Optimizer.state, so state_dict() / load_state_dict() carry them explicitly: a run resumed from
+    (parameters, optimizer state, scheduler state) continues bit for bit; a replicated state or another layout is refused."""
+    from nvp_amd import parallel
+
+    def build():
+        torch.manual_seed(3)
+        lin = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Linear(19, 5))
+        b = parallel.GradBucket(parallel.unique_parameters(lin), chunk_elems=256, early=[lin[0].weight], pad_to=parallel.ShardedAdamW.alignment(1))
+        opt = parallel.ShardedAdamW(b, lr=1e-2, weight_decay=1e-3, update=_cpu_adamw_update)
+        return lin, b, opt, torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=6, eta_min=1e-5)
+
+    def run(lin, b, opt, sched, its):
+        for it in its:
+            g = torch.Generator().manual_seed(50 + it)
+            for v in b.views:
+                v.copy_(torch.randn(v.shape, generator=g))
+            b.sink()
+            opt.step()
+            sched.step()
+
+    lin, b, opt, sched = build()
+    run(lin, b, opt, sched, range(3))
+    ck = {"model": {k: v.clone() for k, v in lin.state_dict().items()}, "optimizer": opt.state_dict(), "scheduler": sched.state_dict()}
+    assert ck["optimizer"]["sharded"]["steps_done"] == 3 and float(ck["optimizer"]["sharded"]["exp_avg"].abs().sum()) > 0
+    import io
+    buf = io.BytesIO()
+    torch.save(ck, buf)                                   # what training.py:65-68 does with it
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    run(lin, b, opt, sched, range(3, 6))
+    want = [p.detach().clone() for p in lin.parameters()]
+
+    lin2, b2, opt2, sched2 = build()
+    lin2.load_state_dict(ck["model"])
+    opt2.load_state_dict(ck["optimizer"])
+    sched2.load_state_dict(ck["scheduler"])
+    assert opt2.steps_done == 3 and abs(opt2.param_groups[0]["lr"] - ck["optimizer"]["param_groups"][0]["lr"]) == 0
+    assert all(p.data_ptr() == opt2.pflat[o:o + 1].data_ptr() for p, o in zip(b2.params, b2._offsets)), "load_state_dict must keep the parameters re-homed"
+    run(lin2, b2, opt2, sched2, range(3, 6))
+    for a, c in zip(want, lin2.parameters()):
+        assert torch.equal(a, c), "resumed run differs from the uninterrupted one"
+    # a replicated optimizer's state has no sharded moments; another layout is refused loudly
+    with pytest.raises(ValueError, match="sharded"):
+        opt2.load_state_dict(torch.optim.AdamW(lin2.parameters()).state_dict())
+    bad = opt.state_dict()
+    bad["sharded"]["world"] = 2
+    with pytest.raises(ValueError, match="world"):
+        opt2.load_state_dict(bad)
