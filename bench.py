@@ -97,9 +97,22 @@ B3_STAGES = ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
 PEAK_HBM = 8.0e12
 
 
-def cpu_baseline(n_sample: int, reps: int = 1):
-    """Oracle fwd+bwd (incl. dense grid grads, as the reference's autograd does) on the host: one warm-up
-    evaluation + `reps` timed ones of a 262 144-pixel sample (~15 s each on the GPU box's 128 threads)."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_sample: int, reps: int = 3):
+    """the oracle's fwd+bwd (incl. the dense grid gradients, as the reference's autograd produces
+    them; optimizer excluded) on this host's cores, 1 warm-up + `reps` timed evaluations.  A full N = 1 245 184 step takes
+    more than 60 s here, so the sample is N/8 = 155 648 pixels of the same batch distribution and the rate is quoted per
+    pixel of the sample (= the linear extrapolation to N; it flatters the CPU slightly where costs do not shrink with the
+    sample: zero-filling and accumulating the 543 MB of dense gradients)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nvp_oracle as O
     cfg = CONFIG_NVP_S
@@ -121,10 +134,77 @@ def cpu_baseline(n_sample: int, reps: int = 1):
         dt = time.perf_counter() - t0
         if it > 0:
             times.append(dt)
-    best = min(times)
-    return {"value": n_sample / best / 1e6, "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_sample} px of the same batch distribution, full nvp_s parameters (135.8M fp32), "
-                      f"fwd+bwd incl. dense grid grads, best of {reps}, {best:.2f} s/step"}
+    times.sort()
+    med = times[len(times) // 2]
+    rate = lambda t: round(n_sample / t / 1e6, 6)      # noqa: E731
+    return {"value": rate(med), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "min": rate(times[-1]), "median": rate(med), "max": rate(times[0]),
+            "seconds_per_sample_step": [round(t, 3) for t in times], "extrapolated_seconds_per_full_step": round(med * N_PX / n_sample, 1),
+            "cpu": cpu_model(),
+            "sample": f"{n_sample} px (N/{N_PX // n_sample}) of the same batch distribution, full nvp_s parameters (135.8M fp32), fwd+bwd incl. "
+                      f"dense grid grads, optimizer excluded; 1 warm-up + {reps} timed, value = median; linear extrapolation to "
+                      f"N = {N_PX}: {med * N_PX / n_sample:.1f} s/step"}
+
+
+def eval_bench(args, dev):
+    """Inference throughput of the reference's evaluation loop (eval.py:219-259) on the HIP path: whole 1080p frames of
+    BASELINE.json configs[1] through harness.render_frame - the reference's slicing (100 slices of 20 736 pixels per frame,
+    eval.py:233-239) and one slice per frame (same pixels, same results: the path is per-pixel), each plain and with
+    --t_interp 2 (SparseGrid.forward_inter, sparsegrid.py:76-156).  Forward-only kernels: the gather and the MLP chain without
+    its five saved streams.  One JSON line; `value` = frames/s of the plain, one-slice run."""
+    from nvp_amd import _lib, functional, harness
+    from nvp_amd.modules import NVP
+    wl = WORKLOADS[args.config]
+    F = wl["F"]
+    T, H, W = wl["video"]
+    torch.manual_seed(0)
+    model = NVP(out_features=3, encoding_config=make_cfg(F, T), verbose=False).to(dev)
+    FLOP_PX, BYTES_PX = work_per_pixel(F)
+    D, R = 57 * F, (57 * F + 3) // 4 * 4
+    bytes_fwd = {"nvp_encode_fwd": BYTES_PX["nvp_encode_fwd"], "nvp_mlp_fwd": 4 * R + 4 + 12}       # inference: latent + step in, RGB out
+    products = int(_lib.load().nvp_mlp_mfma_products())
+    pk_mlp = PEAK_MFMA_16 / products if products > 1 else PEAK_MFMA_F32
+    n_frames = max(args.steps, 1)
+    runs = {}
+    for name, n_slice, t_interp in (("plain_1slice", 1, False), ("plain_100slices", 100, False), ("t_interp2_1slice", 1, True),
+                                    ("t_interp2_100slices", 100, True)):
+        nfr = T * 2 if t_interp else T
+        frames = [int(round(i * (nfr - 2) / max(n_frames - 1, 1))) for i in range(n_frames)]       # (the last t_interp frame is the NaN frame)
+        for f in frames[:max(args.warmup, 1)]:
+            harness.render_frame(model, f, T, (H, W), nfr, t_interp, n_slice)
+        functional.TIMER = functional.KernelTimer()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in frames:
+            harness.render_frame(model, f, T, (H, W), nfr, t_interp, n_slice)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        k = functional.TIMER.summary()
+        functional.TIMER = None
+        per_frame = {kk: round(v[0] * v[1] / n_frames, 4) for kk, v in k.items()}
+        px = (H * W // n_slice) * n_slice
+        st = {}
+        for kk, ms in per_frame.items():
+            e = {"ms_per_frame": ms}
+            if kk in bytes_fwd:
+                e["hbm_frac"] = round(bytes_fwd[kk] * px / (ms * 1e-3) / PEAK_HBM, 4)
+            if kk == "nvp_mlp_fwd":
+                e["mfma_frac"] = round(FLOP_PX[kk] * px / (ms * 1e-3) / pk_mlp, 4)
+            st[kk] = e
+        runs[name] = {"frames_per_s": round(n_frames / dt, 2), "mpx_per_s": round(n_frames * px / dt / 1e6, 1), "ms_per_frame": round(dt / n_frames * 1e3, 3),
+                      "kernel_ms_per_frame": round(sum(per_frame.values()), 3), "stages": st}
+    head = runs["plain_1slice"]
+    dom = max(head["stages"], key=lambda kk: head["stages"][kk]["ms_per_frame"])
+    hb, mf = head["stages"][dom].get("hbm_frac", 0.0), head["stages"][dom].get("mfma_frac", 0.0)
+    line = {"metric": "frames/sec inference, whole 1080p frames (eval.py:219-259)" if args.config != "4k" else "frames/sec inference, whole 4K frames (eval.py:219-259)",
+            "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": 1, "steps": n_frames, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_frame"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["label"] + f", {H * W} pixels per frame, random-init parameters, forward only", "mode": "eval"},
+            "roofline": {"kernel": dom, "bound": "hbm" if hb >= mf else "mfma", "frac": max(hb, mf), "ms_per_launch": head["stages"][dom]["ms_per_frame"],
+                         "achieved": round((bytes_fwd[dom] if hb >= mf else FLOP_PX[dom]) * H * W / (head["stages"][dom]["ms_per_frame"] * 1e-3) / (1e9 if hb >= mf else 1e12), 1),
+                         "peak": PEAK_HBM / 1e9 if hb >= mf else round(pk_mlp / 1e12, 1), "unit": "GB/s" if hb >= mf else "TFLOP/s", "traffic": None},
+            "runs": runs, "cpu_baseline": None}
+    print(json.dumps(line))
 
 
 def main():
@@ -133,9 +213,15 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=262144)
+    ap.add_argument("--cpu-sample", type=int, default=N_PX // 8)
     ap.add_argument("--config", choices=list(WORKLOADS), default="s",
                     help="s = BASELINE.json configs[1] (the headline line); l = configs[2] (nvp_l, 1080p x 300); 4k = configs[3] (nvp_l, 4K x 300)")
+    ap.add_argument("--mode", choices=["train", "eval"], default="train",
+                    help="train = the headline line (full optimisation steps); eval = inference throughput of the reference's evaluation "
+                         "loop (eval.py:219-259): whole frames through harness.render_frame, plain and with --t_interp 2")
+    ap.add_argument("--no-isolate", action="store_true",
+                    help="N = 1: skip the second timed pass with every side stream off (sampler prefetch, scatter presort / weight packing, "
+                         "early AdamW), whose per-stage times are recorded beside the overlapped ones as 'isolated'")
     ap.add_argument("--dp", choices=["auto", "sharded", "a2a", "replicated"], default=os.environ.get("NVP_DP_MODE", "auto"),
                     help="N > 1 gradient exchange: sharded = reduce-scatter + sharded AdamW + all-gather (ZeRO-1), a2a = the same with the "
                          "one-hop all_to_all exchange, replicated = chunked all-reduce + full AdamW; auto = time 3 untimed steps of each "
@@ -157,6 +243,8 @@ def main():
     dev = torch.device("cuda", local)
     _lib.load()
 
+    if args.mode == "eval":
+        return eval_bench(args, dev)
     torch.manual_seed(0)                       # identical parameters on every rank
     wl = WORKLOADS[args.config]
     F = wl["F"]
@@ -171,7 +259,7 @@ def main():
     data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank,   # rank-offset sampler seed
                                sort_by_y=os.environ.get("NVP_BENCH_UNSORTED", "0") != "1",
                                prefetch=os.environ.get("NVP_SAMPLER_PREFETCH", "1") != "0")   # next batch drawn on a side stream: -0.05 ms (eight interleaved 40-step runs: 7.42-7.44 vs 7.47-7.49)
-    total = args.steps + args.warmup
+    total = args.warmup + 2 * args.steps       # cosine horizon: warm-up + the timed pass + the isolated pass
     multi = world > 1 or os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1"
 
     def make_state(mode):
@@ -219,6 +307,23 @@ def main():
             dt_ = float(tt)
         return dt_, loss_
 
+    def verify_replicas(what):
+        """N > 1: every rank must hold bit-identical parameters after a step (same SUM on every rank, element-wise AdamW).  A
+        scheme that lets the replicas diverge produces a throughput number for a broken training: refuse to report it."""
+        if world <= 1:
+            return
+        ps = parallel.unique_parameters(model)
+        chk = torch.stack([p.detach().double().sum() for p in ps] + [p.detach().double().abs().sum() for p in ps])
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        bad = [r for r in range(world) if not torch.equal(allc[r], allc[0])]
+        if bad:
+            if rank == 0:
+                print(f"bench.py: replicas DIVERGED under '{what}' (ranks {bad} differ from rank 0 after identical steps): no result line", file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+
     # ---- exchange scheme (N > 1): chosen by measurement, before the warm-up, on untimed steps
     mode, tune = args.dp, None
     if multi and mode == "auto":
@@ -228,6 +333,7 @@ def main():
             one_step(st)                                  # first steps of a scheme allocate / connect (RCCL sets channels up lazily
             one_step(st)                                  # per collective and message size: seen as one 400-ms step)
             tune[cand] = round(timed(st, 3)[0] / 3 * 1e3, 3)
+            verify_replicas(cand)                         # 5 steps of this scheme over RCCL: the replicas must still be identical
             del st
             torch.cuda.empty_cache()
         mode = min(tune, key=tune.get)
@@ -235,11 +341,31 @@ def main():
 
     for _ in range(args.warmup):
         one_step(state)
+    verify_replicas(mode + " (after the warm-up)")
 
     functional.TIMER = functional.KernelTimer()
     dt, loss = timed(state, args.steps, record=True)
     kernels = functional.TIMER.summary()
     functional.TIMER = None
+    # ---- second pass, N = 1: the same steps with every side stream OFF, so that each stage's HIP-event span is that stage alone
+    # (in the default pass the grids' AdamW, the scatter's coordinate-only kernels, the weight packing and the sampler run
+    # underneath the gather / scatter / dW stages and stretch their spans: not reproducible from a kernel trace to better than +-8 %)
+    isolated = None
+    if world == 1 and not multi and not args.no_isolate and args.steps > 0:
+        keep = (harness.EARLY_ADAMW, functional.SIDE_WORK, data._side)
+        harness.EARLY_ADAMW, functional.SIDE_WORK = False, False
+        torch.cuda.synchronize()
+        data._side, data._next = None, None
+        try:
+            for _ in range(2):
+                one_step(state)
+            functional.TIMER = functional.KernelTimer()
+            dt_iso, _ = timed(state, args.steps)
+            isolated = {"ms_per_step": round(dt_iso / args.steps * 1e3, 3), "kernels": functional.TIMER.summary()}
+        finally:
+            functional.TIMER = None
+            harness.EARLY_ADAMW, functional.SIDE_WORK, data._side = keep
+    verify_replicas(mode + " (after the timed steps)")
     post_ms = sum(a.elapsed_time(b) for a, b in post_bwd) / max(len(post_bwd), 1)
     post_all = [post_ms]
     if world > 1:
@@ -257,8 +383,9 @@ def main():
         # bench.py cannot collect counters itself, so it reports the committed measurement if present.
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.config == "s":
+        if os.path.exists(tpath):
             traffic = json.load(open(tpath))
+            traffic = traffic.get(args.config, traffic if (args.config == "s" and "nvp_mlp_fwd" in traffic) else {})
         dom = max(kms, key=kms.get) if kms else None
         products = int(_lib.load().nvp_mlp_mfma_products())         # 3: fp16 x 2 split, 6: bf16 x 3 split, 1: fp32 MFMA
         pk_mlp = PEAK_MFMA_16 / products if products > 1 else PEAK_MFMA_F32
@@ -295,6 +422,18 @@ def main():
                         "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
                 if dom in FLOP_PX:
                     roof["mfma_frac"] = st["mfma_frac"]
+        iso_line = None
+        if isolated is not None:
+            ikms = {k: round(v[0] * v[1] / max(args.steps, 1), 4) for k, v in isolated["kernels"].items()}
+            iso_line = {"what": "same workload, second timed pass with every side stream off (NVP_EARLY_ADAMW=0 NVP_SCATTER_PRESORT=0 "
+                                "NVP_SAMPLER_PREFETCH=0 equivalents): each stage's span is that stage alone; the step is longer",
+                        "ms_per_step": isolated["ms_per_step"], "kernels_ms": ikms,
+                        "stages": {k: price(k, ms) for k, ms in ikms.items() if k in FLOP_PX or k in BYTES_PX}}
+            if roof is not None and roof["kernel"] in iso_line["stages"]:
+                st = iso_line["stages"][roof["kernel"]]
+                iso_line["roofline"] = {"kernel": roof["kernel"], "bound": roof["bound"], "unit": roof["unit"], "peak": roof["peak"],
+                                        "achieved": st["achieved_gbs"] if roof["bound"] == "hbm" else st["achieved_tflops"],
+                                        "frac": st["hbm_frac"] if roof["bound"] == "hbm" else st["mfma_frac"], "ms_per_launch": ikms[roof["kernel"]]}
         hot_ms = sum(kms.values())
         n_params = sum(p.numel() for p in parallel.unique_parameters(model))
         exchange = {"replicated": "chunked all-reduce (grid grads async under the dW GEMMs) + AdamW on every rank",
@@ -320,6 +459,7 @@ def main():
             "stages": stages,
             "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
             "final_loss": float(loss),
+            "isolated": iso_line,
         }
         if multi:
             # what a rank spends between the end of backward and the end of the optimizer: exposed gradient exchange + its share

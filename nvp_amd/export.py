@@ -49,7 +49,7 @@ def keyframe_planes(params: torch.Tensor, cfg: dict):
     """-> (images[d][l] uint8 [res, res], mins[d][l], maxs[d][l]) for one 2D keyframe grid (flat `params`)."""
     dim = int(cfg["n_features_per_level"])
     res, off = level_geometry(cfg)
-    feats = params.detach().float().cpu().reshape(-1, dim)
+    feats = params.detach().float().reshape(-1, dim)          # quantised where the parameters live; only the uint8 planes travel to the host
     if feats.shape[0] != off[-1]:
         raise ValueError("params length does not match the encoding_config")
     images, mins, maxs = [], [], []
@@ -58,7 +58,7 @@ def keyframe_planes(params: torch.Tensor, cfg: dict):
         for l, r in enumerate(res):
             x = feats[off[l]:off[l + 1], d]
             lo, hi = torch.min(x), torch.max(x)
-            images[d].append(_q8(x, lo, hi).reshape(r, r).numpy())
+            images[d].append(_q8(x, lo, hi).reshape(r, r).cpu().numpy())
             mins[d].append(float(lo)); maxs[d].append(float(hi))
     return images, mins, maxs
 
@@ -75,12 +75,12 @@ def keyframes_from_planes(images, mins, maxs) -> torch.Tensor:
 
 def sparse_planes(emb: torch.Tensor):
     """-> (frames[d] uint8 [T, X, Y], mins[d], maxs[d]) for the sparse grid `[T, X, Y, F]`."""
-    e = emb.detach().float().cpu()
+    e = emb.detach().float()
     frames, mins, maxs = [], [], []
     for d in range(e.shape[3]):
         x = e[:, :, :, d]
         lo, hi = torch.min(x), torch.max(x)
-        frames.append(_q8(x, lo, hi).numpy())
+        frames.append(_q8(x, lo, hi).cpu().numpy())
         mins.append(float(lo)); maxs.append(float(hi))
     return frames, mins, maxs
 

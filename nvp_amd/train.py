@@ -58,6 +58,8 @@ def main():
                                                           "a directory of PNG frames, or a raw 4:2:0 .yuv")
     ap.add_argument("--target-psnr", type=float, default=34.57, help="report the first step / second at which the evaluation PSNR (fp32 grids, and "
                                                                      "8-bit grids with --eval-8bit) reaches this value (README.md:96: 34.57 dB)")
+    ap.add_argument("--natural-alpha", type=float, default=None, help="--video natural: spectral slope of the scene texture (amplitude ~ 1/f^alpha)")
+    ap.add_argument("--natural-grain", type=float, default=None, help="--video natural: per-frame Gaussian grain, in 8-bit levels")
     ap.add_argument("--eval-8bit", action="store_true", help="also evaluate with 8-bit de-quantised grids (eval.py:163-179) at every report")
     ap.add_argument("--log", default="", help="append the JSON report lines to this file")
     ap.add_argument("--frames", type=int, default=600)
@@ -78,8 +80,9 @@ def main():
         video = harness.procedural_video(args.frames, args.height, args.width, dev, seed=args.seed)
         source = "procedural moving pattern (UVG frames are not shipped)"
     elif args.video == "natural":
-        video = harness.natural_video(args.frames, args.height, args.width, dev, seed=args.seed)
-        source = "synthetic clip with natural-image statistics (harness.natural_video) - NOT UVG"
+        kw = {k: v for k, v in (("alpha", args.natural_alpha), ("grain", args.natural_grain)) if v is not None}
+        video = harness.natural_video(args.frames, args.height, args.width, dev, seed=args.seed, **kw)
+        source = "synthetic clip with natural-image statistics (harness.natural_video" + (f", {kw}" if kw else "") + ") - NOT UVG"
     else:
         video = harness.load_video(args.video, args.frames, args.height, args.width).to(dev)
         source = args.video

@@ -197,7 +197,14 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index, fast=False):
         torch.cuda.synchronize()
         return [p.detach().cpu() for p in parallel.unique_parameters(model)]
 
+    def replicas_identical(params, what):
+        chk = torch.stack([p.double().sum() for p in params] + [p.double().abs().sum() for p in params])
+        gathered = [torch.zeros_like(chk if backend != "nccl" else chk.to(dev)) for _ in range(world)]
+        dist.all_gather(gathered, chk.to(dev) if backend == "nccl" else chk)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), f"ranks diverged ({what})"
+
     rep = run("replicated")
+    replicas_identical(rep, "replicated: chunked all-reduce + full AdamW on every rank")
     sh = run(algo)
     if fast:
         assert counts.get((algo, True)) == STEPS, f"the sparse-first exchange did not run on every step: {counts}"
