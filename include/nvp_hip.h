@@ -50,8 +50,10 @@ extern "C" {
 #define NVP_SCATTER_PRESORTED 32   /* nvp_encode_bwd: nvp_encode_bwd_presort already ran on this workspace (same n, levels, flags) */
 #define NVP_SCATTER_DENSE_ONLY 16  /* ... only the three keyframe gradients.  Two calls (sparse first: 80 % of the gradient bytes) let a
                                       data-parallel host start exchanging the sparse grid's gradient while the dense planes scatter. */
-#define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: the scatter skips one radix sort,
-                                      the gather stages the xy / yt grid rows of a pixel run in LDS */
+#define NVP_COORDS_SORTED_BY_Y 1   /* caller guarantees coords[:,2] is non-decreasing: the scatter skips the y counting sort (the batch
+                                      order IS the xy / yt planes' sorted order); the gather gets row locality from it, and - only in
+                                      builds / runs with NVP_ENCODE_LDS=1, off by default because it measured slower - stages the
+                                      xy / yt grid rows of a pixel run in LDS */
 
 /* nvp_levels.flags: arithmetic variant of the dense grid (the tiny-cuda-nn fork the reference installs,
  * README.md:30-32, is absent from /root/reference, so the points where published tiny-cuda-nn and a plain
@@ -138,9 +140,9 @@ int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, i
  * coords [N,3] -> PTM4 latent zt [ntiles][rows/4][32][4], rows = nvp_latent_rows(D),
  * D = sum_p L_p*F_p + 9*F_s, row order xy | yt | xt | sparse (modules.py:69,78).
  * temporal_interp != 0 selects forward_inter for the sparse part (modules.py:72-73).
- * flags: NVP_COORDS_SORTED_BY_Y if coords[:,2] is non-decreasing - the xy and yt planes (whose grid ROW is indexed by y) are
- * then read through LDS: each 256-pixel run stages the <= 3 grid rows per level it touches with coalesced loads
- * (nvp_amd/csrc/encode_fwd_lds.hip); results are bit-identical with and without the flag. */
+ * flags: NVP_COORDS_SORTED_BY_Y if coords[:,2] is non-decreasing.  The default gather kernel only profits from the locality; the
+ * opt-in LDS-staged variant (environment NVP_ENCODE_LDS=1, nvp_amd/csrc/encode_fwd_lds.hip: each 256-pixel run stages the <= 3
+ * grid rows per level it touches with coalesced loads) needs the flag.  Results are bit-identical with and without it. */
 int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, const float* kf_xt,
                    const float* emb, float* zt, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
@@ -167,9 +169,9 @@ typedef struct nvp_scatter_lm {
 } nvp_scatter_lm;
 int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                            const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, nvp_scatter_lm* out, void* stream);
-/* Optional early start: everything the scatter derives from the coordinates alone (sort keys, the planes' sorted orders, the sparse
- * grid's row table: a dozen small latency-bound kernels, ~0.26 ms back to back) on `stream` - typically a side stream, underneath
- * the backward chain kernel.  Order the streams with an event, then call nvp_encode_bwd with NVP_SCATTER_PRESORTED on the same
+/* Optional early start: everything the scatter derives from the coordinates alone (sort keys, the counting sorts that give the
+ * planes' sorted orders, every plane's per-level row tables, the sparse grid's order and row table: a dozen small latency-bound
+ * kernels) on `stream` - typically a side stream, underneath the gather kernel.  Order the streams with an event, then call nvp_encode_bwd with NVP_SCATTER_PRESORTED on the same
  * workspace; `flags` as for nvp_encode_bwd.  Bit-identical gradients. */
 int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                            const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream);

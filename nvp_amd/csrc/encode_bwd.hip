@@ -7,7 +7,8 @@
 // nvp_s) therefore costs ~25 ms.  This file replaces it by a deterministic scheme:
 //
 //  1. sort the batch's pixels by the row coordinate of each plane (y for the xy and yt planes,
-//     x for the xt plane) - two 1.2 M-key radix sorts (rocPRIM);
+//     x for the xt plane) - hand-written counting sorts on small integer keys (the sum over the levels of the
+//     row index: 13-14 bits, monotone for every level at once; csort_* below);
 //  2. permute: coordinates and the per-level latent gradients are rewritten in sorted order,
 //     level-major, so every later access is a coalesced stream; the same pass finds
 //     max|dz|, which fixes the fixed-point scale;
@@ -29,7 +30,6 @@
 // max|dz| (fp32 carries 24), so the scatter is more accurate than an fp32 atomic chain.
 #include <cstring>
 #include "grid_math.h"
-#include <rocprim/rocprim.hpp>
 
 #pragma clang fp contract(off)
 
@@ -113,40 +113,41 @@ void make_plan(Plan& P, const nvp_levels* lv[3], int64_t n) {
 
 // ------------------------------------------------------------------------------------------
 struct Ws {                      // workspace carve (byte offsets)
-    size_t keys_in[2], keys_out[2], iota, order[2], cs[3], dzs[3], rowstart[3], dzmax, slabs, sort_tmp, total;
-    size_t skey_in, skey_out, sorder, srowstart, sdzmax;      // sparse grid
-    size_t sort_tmp_bytes;
+    size_t keys[2], order[2], cs[3], dzs[3], rowstart[3], dzmax, slabs, total;
+    size_t kstart[2], kcursor[2];                             // counting sorts of the two dense keys: exclusive starts, scatter cursors
+    size_t skey, sorder, srowstart, scursor, sdzmax;         // sparse grid
+    int nkeys[2];                                             // key ranges of the two dense sorts (y key, x key)
 };
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// key(c) = sum over the levels of clamp(row_l(c), 0, res_l + 1): its range
+int key_range(const nvp_levels* a, const nvp_levels* b) {
+    int r = 1;
+    for (int l = 0; l < a->n_levels; ++l) r += a->res[l] + 1;
+    if (b) for (int l = 0; l < b->n_levels; ++l) r += b->res[l] + 1;
+    return r;
+}
+
 int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape* sh, int64_t n) {
     size_t o = 0;
-    for (int k = 0; k < 2; ++k) { W.keys_in[k] = o; o = align_up(o + n * 4); }
-    for (int k = 0; k < 2; ++k) { W.keys_out[k] = o; o = align_up(o + n * 4); }
-    W.iota = o; o = align_up(o + n * 4);
+    W.nkeys[0] = key_range(lv[0], lv[1]);          // y: rows of the xy AND the yt plane
+    W.nkeys[1] = key_range(lv[2], nullptr);        // x: rows of the xt plane
+    for (int k = 0; k < 2; ++k) { W.keys[k] = o; o = align_up(o + n * 4); }
     for (int k = 0; k < 2; ++k) { W.order[k] = o; o = align_up(o + n * 4); }
+    for (int k = 0; k < 2; ++k) { W.kstart[k] = o; o = align_up(o + ((size_t)W.nkeys[k] + 1) * 4); }
+    for (int k = 0; k < 2; ++k) { W.kcursor[k] = o; o = align_up(o + ((size_t)W.nkeys[k] + 1) * 4); }
     for (int p = 0; p < 3; ++p) { W.cs[p] = o; o = align_up(o + n * 8); }
     for (int p = 0; p < 3; ++p) { W.dzs[p] = o; o = align_up(o + (size_t)n * lv[p]->n_levels * lv[p]->n_features * 4); }
     for (int p = 0; p < 3; ++p) { W.rowstart[p] = o; o = align_up(o + (size_t)P.rs_total[p] * 4); }
     W.dzmax = o; o += kMaxSlots * 4;
     W.sdzmax = o; o = align_up(o + kMaxSlots * 4);             // adjacent to dzmax: nvp_encode_bwd_prepare zeroes both with one memset
-    W.slabs = o; o = align_up(o + (size_t)P.slab_floats * 4);
-    W.skey_in = o; o = align_up(o + n * 4);
-    W.skey_out = o; o = align_up(o + n * 4);
+    W.slabs = o; o = align_up(o + (size_t)P.slab_floats * 8);  // int64 fixed-point partial tables
+    W.skey = o; o = align_up(o + n * 4);
     W.sorder = o; o = align_up(o + n * 4);
-    W.srowstart = o; o = align_up(o + ((size_t)sh->t_res * sh->x_res + 1) * 4);
-    size_t tmp = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp, (const float*)nullptr, (float*)nullptr, (const int*)nullptr,
-                                             (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
-    if (e != hipSuccess) return (int)e;
-    size_t tmp2 = 0;
-    e = rocprim::radix_sort_pairs(nullptr, tmp2, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
-                                  (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0);
-    if (e != hipSuccess) return (int)e;
-    if (tmp2 > tmp) tmp = tmp2;
-    W.sort_tmp_bytes = tmp;
-    W.sort_tmp = o; o = align_up(o + tmp);
+    const size_t nsk = (size_t)sh->t_res * sh->x_res + 1;
+    W.srowstart = o; o = align_up(o + nsk * 4);
+    W.scursor = o; o = align_up(o + nsk * 4);
     W.total = o;
     return 0;
 }
@@ -154,29 +155,101 @@ int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape*
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int row_of(float c1, float scale, int flags) { return (int)floorf(nvp_grid_pos(c1, scale, flags)); }
 
+// Sort keys.  The scatter needs the pixels of a plane ordered so that the grid ROW index is non-decreasing at EVERY level;
+// ordering by the row coordinate itself does that, but a float key costs four 8-bit radix passes.  key(c) = sum over the levels
+// of row_l(c) is a non-decreasing step function of c that steps exactly where some level's row index steps, so equal keys
+// mean equal rows at every level (ties may sit in any order: the fixed-point accumulation is exact, hence order-independent) -
+// and it has 13-14 bits: ONE counting-sort pass.  Rows are clamped to [0, res + 1]; coordinates outside [0, 1] keep a valid (if
+// arbitrary) order.  kx: the xt plane's key (rows indexed by x); ky (only for batches that do not arrive y-sorted): rows of the
+// xy and of the yt plane, both indexed by y.
 // cs_xy / cs_yt (optional): the (dim0, dim1) coordinate pairs of the xy and yt planes in batch order - what the permute pass
 // would write for them when their sorted order is the identity (NVP_DZ_PLANES_READY).
-// kx: the sort key of the xt plane.  The scatter needs the pixels ordered so that the grid ROW index is non-decreasing at EVERY
-// level; ordering by x itself does that, but costs four 8-bit radix passes over the float's 32 bits.  key(x) = sum over the levels
-// of row_l(x) is a non-decreasing step function that steps exactly where some level's row index steps, so equal keys mean equal
-// rows at every level (ties may sit in any order: the fixed-point accumulation does not depend on it) - and it has ~14 bits: two
-// passes.  Rows are clamped to [0, res + 1]; coordinates outside [0, 1] keep a valid (if arbitrary) order, as before.
-__global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ coords, float* __restrict__ ky, unsigned* __restrict__ kx,
-                                                   int* __restrict__ iota, float2* __restrict__ cs_xy, float2* __restrict__ cs_yt,
-                                                   nvp_levels lvx, int64_t n) {
+__global__ __launch_bounds__(256) void keys_kernel(const float* __restrict__ coords, unsigned* __restrict__ ky, unsigned* __restrict__ kx,
+                                                   float2* __restrict__ cs_xy, float2* __restrict__ cs_yt,
+                                                   nvp_levels lv0, nvp_levels lv1, nvp_levels lvx, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float t = coords[i * 3], x = coords[i * 3 + 1], y = coords[i * 3 + 2];
     unsigned key = 0u;
     for (int l = 0; l < lvx.n_levels; ++l) key += (unsigned)min(max(row_of(x, lvx.scale[l], lvx.flags), 0), lvx.res[l] + 1);
     kx[i] = key;
-    ky[i] = y;
-    iota[i] = (int)i;
+    if (ky) {
+        key = 0u;
+        for (int l = 0; l < lv0.n_levels; ++l) key += (unsigned)min(max(row_of(y, lv0.scale[l], lv0.flags), 0), lv0.res[l] + 1);
+        for (int l = 0; l < lv1.n_levels; ++l) key += (unsigned)min(max(row_of(y, lv1.scale[l], lv1.flags), 0), lv1.res[l] + 1);
+        ky[i] = key;
+    }
     if (cs_xy) { cs_xy[i] = make_float2(x, y); cs_yt[i] = make_float2(t, y); }
 }
 
+// ---- counting sort on small integer keys (replaces three library radix sorts) --------------------------------------------------
+// keys in [0, nkeys).  Three launches: histogram (cnt[] zeroed by the caller), exclusive scan (start[k] = first sorted position
+// whose key is >= k, k in [0, nkeys] - which IS the row table the sparse grid's band kernel needs - plus a copy as scatter cursors),
+// scatter (order[pos] = pixel).  The order among equal keys is whatever the atomics make it: every consumer accumulates in exact
+// integer arithmetic, so the gradients do not depend on it (the slabs of split levels are int64 for that reason).
+constexpr int kCsortLdsBins = 16384;             // histograms up to this many bins are privatised in LDS (64 KB)
+constexpr int kCsortChunk = 8192;                // keys per workgroup
+
+__global__ __launch_bounds__(256) void csort_hist_kernel(const unsigned* __restrict__ keys, unsigned* __restrict__ cnt, int64_t n, int nkeys) {
+    extern __shared__ unsigned h[];
+    const int64_t i0 = (int64_t)blockIdx.x * kCsortChunk;
+    const int64_t i1 = min(n, i0 + kCsortChunk);
+    if (nkeys <= kCsortLdsBins) {
+        for (int k = threadIdx.x; k < nkeys; k += 256) h[k] = 0u;
+        __syncthreads();
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) atomicAdd(&h[min(keys[i], (unsigned)(nkeys - 1))], 1u);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nkeys; k += 256) { const unsigned v = h[k]; if (v) atomicAdd(&cnt[k], v); }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) atomicAdd(&cnt[min(keys[i], (unsigned)(nkeys - 1))], 1u);
+    }
+}
+
+// one workgroup: start[k] = sum of cnt[0..k), k in [0, nkeys]; cursor = copy of start; cnt is read, not modified
+__global__ __launch_bounds__(1024) void csort_scan_kernel(const unsigned* cnt, int* __restrict__ start, unsigned* cursor, int nkeys) {
+    __shared__ unsigned part[1024];
+    const int t = threadIdx.x;
+    const int per = (nkeys + 1023) / 1024;
+    const int k0 = min(nkeys, t * per), k1 = min(nkeys, k0 + per);
+    unsigned s = 0u;
+    for (int k = k0; k < k1; ++k) s += cnt[k];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {           // Hillis-Steele inclusive scan of the 1024 partial sums
+        const unsigned v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = part[t] - s;                    // exclusive prefix of this thread's chunk
+    for (int k = k0; k < k1; ++k) {
+        const unsigned c = cnt[k];
+        start[k] = (int)run; cursor[k] = run;
+        run += c;
+    }
+    if (t == 1023) { start[nkeys] = (int)part[1023]; cursor[nkeys] = part[1023]; }
+}
+
+__global__ __launch_bounds__(256) void csort_scatter_kernel(const unsigned* __restrict__ keys, unsigned* __restrict__ cursor, int* __restrict__ order, int64_t n, int nkeys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned pos = atomicAdd(&cursor[min(keys[i], (unsigned)(nkeys - 1))], 1u);
+    order[pos] = (int)i;
+}
+
+// cnt aliases `cursor` for the histogram phase (the scan reads cnt and overwrites it in place, element by element, after reading it)
+int csort(const unsigned* keys, int64_t n, int nkeys, int* start, unsigned* cursor, int* order, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(cursor, 0, ((size_t)nkeys + 1) * 4, s);
+    if (e != hipSuccess) return (int)e;
+    const unsigned nb = (unsigned)((n + kCsortChunk - 1) / kCsortChunk);
+    hipLaunchKernelGGL(csort_hist_kernel, dim3(nb), dim3(256), nkeys <= kCsortLdsBins ? (size_t)nkeys * 4 : 0, s, keys, cursor, n, nkeys);
+    hipLaunchKernelGGL(csort_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)cursor, start, cursor, nkeys);
+    hipLaunchKernelGGL(csort_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, cursor, order, n, nkeys);
+    return 0;
+}
+
 struct PermArgs {
-    const int* order[3];      // sorted->pixel id, per plane
+    const int* order[3];      // sorted->pixel id, per plane (nullptr: identity - the batch arrives in that plane's order)
     float2* cs[3];
     float* dzs[3];
     int col0[3], nlev[3];
@@ -222,7 +295,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
         const int64_t p = p0 + pix;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < n) {
-            const int id = order[p];
+            const int id = order ? order[p] : (int)p;
             if (q <= qmax) v = reinterpret_cast<const float4*>(dz + (int64_t)id * dz_stride + A.col0[plane])[q];
             if (plane == 2 && 4 * q < A.scols) {       // the sparse columns follow this plane's segment in the same row
                 const float4 sv = reinterpret_cast<const float4*>(dz + (int64_t)id * dz_stride + A.scol0)[q];
@@ -239,7 +312,7 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
     for (int pix = t; pix < PIX; pix += 256) {
         const int64_t p = p0 + pix;
         if (p < n) {
-            const int id = order[p];
+            const int id = order ? order[p] : (int)p;
             const float* c = coords + (int64_t)id * 3;
             A.cs[plane][p] = make_float2(c[A.c0[plane]], c[A.c1[plane]]);
             float* dst = A.dzs[plane];
@@ -265,15 +338,18 @@ __global__ __launch_bounds__(256) void permute_kernel(const float* __restrict__ 
 }
 
 struct RowArgs {
-    const float2* cs[3];
+    const int* order[3];      // sorted->pixel id per plane (nullptr: identity)
+    int col[3];               // coordinate column that indexes the plane's grid ROW (dim 1 of the plane): y, y, x
     int* rowstart[3];
     nvp_levels lv[3];
     int rs_off[3][NVP_MAX_LEVELS];
     int rs_total[3];
 };
 
-// rowstart[level][r] = first sorted position whose row index at that level is >= r  (r in [0, res])
-__global__ __launch_bounds__(256) void rowstart_kernel(RowArgs A, int64_t n) {
+// rowstart[level][r] = first sorted position whose row index at that level is >= r  (r in [0, res]).  Coordinate-only: it
+// searches the batch's coordinates through the plane's order, so it runs with the sorts (nvp_encode_bwd_presort), not behind the
+// permute pass.
+__global__ __launch_bounds__(256) void rowstart_kernel(const float* __restrict__ coords, RowArgs A, int64_t n) {
     const int plane = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= A.rs_total[plane]) return;
@@ -282,25 +358,32 @@ __global__ __launch_bounds__(256) void rowstart_kernel(RowArgs A, int64_t n) {
     const int r = idx - A.rs_off[plane][l];
     const float scale = A.lv[plane].scale[l];
     const int flags = A.lv[plane].flags;
-    const float2* cs = A.cs[plane];
+    const int* order = A.order[plane];
+    const float* c1 = coords + A.col[plane];
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (row_of(cs[mid].y, scale, flags) >= r) hi = mid; else lo = mid + 1;
+        const int64_t id = order ? order[mid] : mid;
+        if (row_of(c1[id * 3], scale, flags) >= r) hi = mid; else lo = mid + 1;
     }
     A.rowstart[plane][idx] = (int)lo;
 }
 
-// value * 2^k as a signed 64-bit integer (|value * 2^k| < 2^41 by the choice of k: max|dz| * 2^k < 2^(62 - headroom), headroom >= 21).
-// The band kernels are VALU-bound on this conversion (478 M of them per step), so it is built from what the hardware converts
-// natively: t = v 2^k (exact, v_ldexp_f32) is cut into hi = trunc(t 2^-20) (|hi| < 2^21: v_cvt_i32_f32) and lo = t - hi 2^20
-// (one exact fma, |lo| < 2^20, rounded to nearest even) - 11 instructions instead of the 23 of a hand-rolled mantissa shift.
-// NVP_TO_FIXED_SHIFT=1 selects that earlier formulation (round-half-up in magnitude; differs from this one only on exact ties).
-#ifndef NVP_TO_FIXED_SHIFT
-#define NVP_TO_FIXED_SHIFT 0
+// value * 2^k as a signed 64-bit integer, rounded to nearest even (|value * 2^k| < 2^41 by the choice of k: max|dz| * 2^k <
+// 2^(62 - headroom), headroom >= 21).  The band kernels are VALU-bound on this conversion (478 M of them per step), so it is three
+// instructions: d = fma(double(v), 2^k, 1.5 * 2^52) lands in the binade [2^52, 2^53), whose 52 mantissa bits ARE the integer
+// (two's complement around the bias); the bias 0x4338000000000000 has a zero low word, so removing it is one 32-bit subtraction
+// on the high word.  Bit-identical to the earlier formulations (NVP_TO_FIXED=1: ldexp / trunc / fma / two 32-bit conversions,
+// 11 instructions; =2: the hand-rolled mantissa shift, 23, round-half-up in magnitude: differs on exact ties only) - checked
+// exhaustively on the host for 4e7 random (v, k) pairs and by the gradient tests.
+#ifndef NVP_TO_FIXED
+#define NVP_TO_FIXED 0
 #endif
-__device__ __forceinline__ long long to_fixed(float v, int k) {
-#if NVP_TO_FIXED_SHIFT
+struct FixedScale { double s; int k; };
+__device__ __forceinline__ FixedScale fixed_scale(int k) { FixedScale f; f.k = k; f.s = __longlong_as_double((long long)(1023 + k) << 52); return f; }
+__device__ __forceinline__ long long to_fixed(float v, const FixedScale& fs) {
+#if NVP_TO_FIXED == 2
+    const int k = fs.k;
     const unsigned b = __float_as_uint(v);
     const int e = (b >> 23) & 0xff;
     const unsigned m = (b & 0x7fffffu) | (e ? 0x800000u : 0u);
@@ -312,10 +395,14 @@ __device__ __forceinline__ long long to_fixed(float v, int k) {
         q = rs > 24 ? 0 : (long long)((m + (1u << (rs - 1))) >> rs);
     }
     return (b >> 31) ? -q : q;
-#else
+#elif NVP_TO_FIXED == 1
+    const int k = fs.k;
     const float th = truncf(ldexpf(v, k - 20));
     const float lo = __builtin_fmaf(th, -1048576.0f, ldexpf(v, k));
     return ((long long)(int)th << 20) + (long long)__float2int_rn(lo);
+#else
+    const double d = __builtin_fma((double)v, fs.s, 6755399441055744.0);
+    return __double_as_longlong(d) - 0x4338000000000000LL;
 #endif
 }
 
@@ -326,10 +413,25 @@ struct BandArgs {
     const float* dzs[3];
     const int* rowstart[3];
     float* grad[3];
-    float* slabs;
+    long long* slabs;
     const unsigned* dzmax;
     int headroom_bits;
 };
+
+// fixed-point exponent from the max|dz| slots: k such that n contributions of magnitude <= max|dz| fit 2^62
+__device__ __forceinline__ void scale_from_slots(const unsigned* __restrict__ slots, int headroom_bits, int* s_k, bool* s_poison) {
+    if (threadIdx.x < 64) {
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < kMaxSlots; i += 64) m = max(m, slots[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        if (threadIdx.x == 0) {
+            const int e = (int)((m >> 23) & 0xff) - 127;            // floor(log2 max|dz|); m == 0 -> -127
+            *s_k = 62 - headroom_bits - (e + 1);
+            *s_poison = m >= 0x7f800000u;                           // an Inf / NaN latent gradient somewhere in the batch
+        }
+    }
+}
 
 template <int F>
 __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t n) {
@@ -355,24 +457,14 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     const int entries = (r1 - r0) * res * F;
 
     for (int i = threadIdx.x; i < entries; i += kBandThreads) tab[i] = 0ull;
-    if (threadIdx.x < 64) {
-        // fixed-point scale from max|dz| (kMaxSlots candidates, 4 per lane)
-        unsigned m = 0;
-        for (int i = threadIdx.x; i < kMaxSlots; i += 64) m = max(m, A.dzmax[i]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (threadIdx.x == 0) {
-            const int e = (int)((m >> 23) & 0xff) - 127;            // floor(log2 max|dz|); m == 0 -> -127
-            s_k = 62 - A.headroom_bits - (e + 1);
-            s_poison = m >= 0x7f800000u;                            // an Inf / NaN latent gradient somewhere in the batch
-        }
-    }
+    scale_from_slots(A.dzmax, A.headroom_bits, &s_k, &s_poison);
     __syncthreads();
-    const int k = s_k;
+    const FixedScale fs = fixed_scale(s_k);
     const int lflags = A.lv[plane].flags;
 
-    // ---- sorted pixel ranges that can touch rows [r0, r1): rows iy in [r0-2, r1-1], plus the
-    //      wrap-around of the last two rows into rows 0/1 (cell index is taken mod res^2)
+    // ---- sorted pixel ranges that can touch rows [r0, r1): rows iy in [r0-2, r1-1] (iy, iy + 1, and iy + 2 when the dim-0
+    //      corner i0 + 1 == res wraps into the next row), plus the wrap-around of the last two rows into rows 0/1 (the cell
+    //      index is taken mod res^2)
     const int* rs = A.rowstart[plane] + L.rs_off;
     const int loA = rs[max(r0 - 2, 0)], hiA = rs[r1];
     int loW = 0, hiW = 0;
@@ -383,6 +475,8 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
 
     const float2* cs = A.cs[plane];
     const float* dz = A.dzs[plane] + (int64_t)level * n * F;
+    const int span = (r1 - r0) * res;
+    const int base = r0 * res;
     for (int kk = kb + threadIdx.x; kk < ke; kk += kBandThreads) {
         const int p = kk < lenA ? loA + kk : loW + (kk - lenA);
         const float2 c = cs[p];
@@ -390,27 +484,44 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
         bool any = false;
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
-        if (!any) continue;
-        const NvpBilerp bl = nvp_bilerp_setup(c.x, c.y, scale, res, lflags);
+        // cells first: most of the visits of a one-row band (3 rows visited, 2 touched) end here, before any weight or
+        // conversion is computed
+        const float p0 = nvp_grid_pos(c.x, scale, lflags), p1 = nvp_grid_pos(c.y, scale, lflags);
+        const float f0 = floorf(p0), f1 = floorf(p1);
+        const int i0 = (int)f0, i1 = (int)f1;
+        int off[4];
+        bool hit = false;
 #pragma unroll
         for (int cnr = 0; cnr < 4; ++cnr) {
-            const int off = bl.cell[cnr] - r0 * res;      // row test: cell in [r0*res, r1*res)
-            if (off < 0 || off >= (r1 - r0) * res) continue;
-            const float w = bl.w[cnr];
+            off[cnr] = nvp_grid_cell(i0, i1, cnr & 1, cnr >> 1, res, lflags) - base;      // row test: cell in [r0*res, r1*res)
+            hit |= (unsigned)off[cnr] < (unsigned)span;
+        }
+        if (!any || !hit) continue;
+        const float w0 = __fsub_rn(p0, f0), w1 = __fsub_rn(p1, f1);
+        const float u0 = __fsub_rn(1.0f, w0), u1 = __fsub_rn(1.0f, w1);
+        const float w[4] = {__fmul_rn(u0, u1), __fmul_rn(w0, u1), __fmul_rn(u0, w1), __fmul_rn(w0, w1)};      // == nvp_bilerp_setup
+#pragma unroll
+        for (int cnr = 0; cnr < 4; ++cnr) {
+            if ((unsigned)off[cnr] >= (unsigned)span) continue;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const long long q = to_fixed(w * g[f], k);
-                atomicAdd(&tab[off * F + f], (unsigned long long)q);
+                const long long q = to_fixed(__fmul_rn(w[cnr], g[f]), fs);
+                atomicAdd(&tab[off[cnr] * F + f], (unsigned long long)q);
             }
         }
     }
     __syncthreads();
 
-    // ---- flush: exclusive bands go straight to the gradient, split bands to their slab
-    const double inv = ldexp(1.0, -k);
+    // ---- flush: exclusive bands go straight to the gradient; split bands keep their exact int64 sums in a slab (the order of
+    //      the pixels among equal sort keys - hence which split sees which pixel - must not show in the result)
+    if (L.slab_off >= 0) {
+        long long* dst = A.slabs + L.slab_off + (int64_t)split * res * res * F + (int64_t)r0 * res * F;
+        for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = (long long)tab[i];
+        return;
+    }
+    const double inv = ldexp(1.0, -s_k);
     const int64_t lvl_off = (int64_t)A.lv[plane].offset[level] * F;
-    float* dst = (L.slab_off < 0) ? A.grad[plane] + lvl_off + (int64_t)r0 * res * F
-                                  : A.slabs + L.slab_off + (int64_t)split * res * res * F + (int64_t)r0 * res * F;
+    float* dst = A.grad[plane] + lvl_off + (int64_t)r0 * res * F;
     if (s_poison) {          // non-finite dz: the reference's index_put / atomics would carry NaN / Inf; fixed point cannot, so say so loudly
         for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = __uint_as_float(0x7fc00000u);
         return;
@@ -422,11 +533,17 @@ struct ReduceArgs {
     Plan plan;
     nvp_levels lv[3];
     float* grad[3];
-    const float* slabs;
+    const long long* slabs;
+    const unsigned* dzmax;
+    int headroom_bits;
 };
 
-// grid.y enumerates the (plane, level) pairs that were split
+// grid.y enumerates the (plane, level) pairs that were split: exact int64 sum over the splits, one conversion
 __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceArgs A) {
+    __shared__ int s_k;
+    __shared__ bool s_poison;
+    scale_from_slots(A.dzmax, A.headroom_bits, &s_k, &s_poison);
+    __syncthreads();
     int want = blockIdx.y, plane = -1, level = -1;
     for (int p = 0; p < 3 && plane < 0; ++p)
         for (int l = 0; l < A.lv[p].n_levels; ++l)
@@ -436,11 +553,13 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceArgs A) {
     const int F = A.lv[plane].n_features;
     const int64_t cells = (int64_t)A.lv[plane].res[level] * A.lv[plane].res[level] * F;
     float* dst = A.grad[plane] + (int64_t)A.lv[plane].offset[level] * F;
-    const float* src = A.slabs + L.slab_off;
+    const long long* src = A.slabs + L.slab_off;
+    const double inv = ldexp(1.0, -s_k);
+    const bool poison = s_poison;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int sp = 0; sp < L.splits; ++sp) s += src[(int64_t)sp * cells + i];
-        dst[i] = s;
+        long long sum = 0;
+        for (int sp = 0; sp < L.splits; ++sp) sum += src[(int64_t)sp * cells + i];
+        dst[i] = poison ? __uint_as_float(0x7fc00000u) : (float)((double)sum * inv);
     }
 }
 
@@ -463,18 +582,7 @@ __global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restric
     keys[i] = (unsigned)(nvp_nearest_idx(c[0], sh.t_res) * sh.x_res + nvp_nearest_idx(c[1], sh.x_res));
 }
 
-// srowstart[k] = first sorted position whose key is >= k, k in [0, T*X]
-__global__ __launch_bounds__(256) void sparse_rowstart_kernel(const unsigned* __restrict__ keys_sorted, int* __restrict__ rowstart, int nkeys, int64_t n) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k > nkeys) return;
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys_sorted[mid] >= (unsigned)k) hi = mid; else lo = mid + 1;
-    }
-    rowstart[k] = (int)lo;
-}
-
+// rowstart[k] = first sorted position whose key is >= k, k in [0, T*X]: the counting sort's exclusive starts (csort_scan_kernel)
 __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
                                                                      const int* __restrict__ order, const int* __restrict__ rowstart,
                                                                      const unsigned* __restrict__ dzmax, float* __restrict__ demb,
@@ -487,37 +595,35 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
     const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
     const int entries = (r1 - r0) * sh.y_res * F;
     for (int i = threadIdx.x; i < entries; i += kSparseThreads) tab[i] = 0ull;
-    if (threadIdx.x < 64) {
-        unsigned m = 0;
-        for (int i = threadIdx.x; i < kMaxSlots; i += 64) m = max(m, dzmax[i]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        if (threadIdx.x == 0) { s_k = 62 - headroom_bits - ((int)((m >> 23) & 0xff) - 127 + 1); s_poison = m >= 0x7f800000u; }
-    }
+    scale_from_slots(dzmax, headroom_bits, &s_k, &s_poison);
     __syncthreads();
-    const int k = s_k;
+    const FixedScale fs = fixed_scale(s_k);
     const int lo = rowstart[t * sh.x_res + max(r0 - 1, 0)];
     const int hi = rowstart[t * sh.x_res + min(r1, sh.x_res - 1) + 1];
-    // one work unit = (pixel, patch cell): 9 units per pixel
-    const int units = (hi - lo) * 9;
+    // one work unit = (pixel, x-row of its 3x3 patch): 3 units per pixel, each owning three y-neighbours = 3F consecutive floats
+    // of the pixel's latent-gradient row
+    const int units = (hi - lo) * 3;
     for (int u = threadIdx.x; u < units; u += kSparseThreads) {
-        const int p = lo + u / 9, cell9 = u - (u / 9) * 9;
-        const int id = order[p];
+        const int q = u / 3, i = u - q * 3;
+        const int id = order[lo + q];
         const float* c = coords + (int64_t)id * 3;
-        const int xi = nvp_nearest_idx(c[1], sh.x_res), yi = nvp_nearest_idx(c[2], sh.y_res);
-        const int i = cell9 / 3, j = cell9 - i * 3;
+        const int xi = nvp_nearest_idx(c[1], sh.x_res);
         const int vx = min(max(xi + i - 1, 0), sh.x_res - 1);
         if (vx < r0 || vx >= r1) continue;
-        const int vy = min(max(yi + j - 1, 0), sh.y_res - 1);
-        const float* g = dz + (int64_t)id * dz_stride + col0 + cell9 * F;
-        unsigned long long* dst = tab + ((vx - r0) * sh.y_res + vy) * F;
-        for (int f = 0; f < F; ++f) {
-            const float v = g[f];
-            if (v != 0.f) atomicAdd(dst + f, (unsigned long long)to_fixed(v, k));
+        const int yi = nvp_nearest_idx(c[2], sh.y_res);
+        const float* g = dz + (int64_t)id * dz_stride + col0 + 3 * i * F;
+        unsigned long long* row = tab + (vx - r0) * sh.y_res * F;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int vy = min(max(yi + j - 1, 0), sh.y_res - 1);
+            for (int f = 0; f < F; ++f) {
+                const float v = g[j * F + f];
+                if (v != 0.f) atomicAdd(row + vy * F + f, (unsigned long long)to_fixed(v, fs));
+            }
         }
     }
     __syncthreads();
-    const double inv = ldexp(1.0, -k);
+    const double inv = ldexp(1.0, -s_k);
     float* out = demb + (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
     if (s_poison) {
         for (int i = threadIdx.x; i < entries; i += kSparseThreads) out[i] = __uint_as_float(0x7fc00000u);
@@ -536,50 +642,47 @@ bool levels_ok(const nvp_levels* lv) {
 }
 
 // Everything the scatter derives from the COORDINATES alone: sort keys, the xt plane's order (and the y order for unsorted
-// batches), the sparse grid's (t, x) order and row table.  A dozen small latency-bound kernels (~0.26 ms back to back) that a host
-// can run early on a side stream - underneath the backward chain kernel - through nvp_encode_bwd_presort.
-int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, int flags, hipStream_t s) {
-    float* ky = (float*)(ws + W.keys_in[0]);
-    unsigned* kx = (unsigned*)(ws + W.keys_in[1]);
-    int* iota = (int*)(ws + W.iota);
+// batches), every plane's per-level row tables, the sparse grid's (t, x) order and row table.  A dozen small latency-bound kernels
+// that a host can run early on a side stream - underneath the gather kernel - through nvp_encode_bwd_presort.
+int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s) {
+    unsigned* ky = (unsigned*)(ws + W.keys[0]);
+    unsigned* kx = (unsigned*)(ws + W.keys[1]);
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;
-    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, ky, kx, iota,
-                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr, *lv[2], n);
-    int kx_bits = 1;
+    hipLaunchKernelGGL(keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, y_sorted ? (unsigned*)nullptr : ky, kx,
+                       planes_ready ? (float2*)(ws + W.cs[0]) : (float2*)nullptr, planes_ready ? (float2*)(ws + W.cs[1]) : (float2*)nullptr,
+                       *lv[0], *lv[1], *lv[2], n);
+    int rc = 0;
+    if (!y_sorted)                                 // otherwise the batch already arrives in ascending y: identity order
+        rc = csort(ky, n, W.nkeys[0], (int*)(ws + W.kstart[0]), (unsigned*)(ws + W.kcursor[0]), (int*)(ws + W.order[0]), s);
+    if (rc) return rc;
+    rc = csort(kx, n, W.nkeys[1], (int*)(ws + W.kstart[1]), (unsigned*)(ws + W.kcursor[1]), (int*)(ws + W.order[1]), s);
+    if (rc) return rc;
+    // per-level row tables of the three planes (binary searches over the coordinates in each plane's order)
     {
-        int64_t kmax = 0;
-        for (int l = 0; l < lv[2]->n_levels; ++l) kmax += lv[2]->res[l] + 1;
-        while (((int64_t)1 << kx_bits) <= kmax && kx_bits < 32) ++kx_bits;
+        RowArgs RA;
+        int rs_max = 0;
+        const int ord[3] = {0, 0, 1}, col[3] = {2, 2, 1};
+        for (int p = 0; p < 3; ++p) {
+            RA.order[p] = (ord[p] == 0 && y_sorted) ? (const int*)nullptr : (const int*)(ws + W.order[ord[p]]);
+            RA.col[p] = col[p];
+            RA.rowstart[p] = (int*)(ws + W.rowstart[p]);
+            RA.lv[p] = *lv[p];
+            for (int l = 0; l < lv[p]->n_levels; ++l) RA.rs_off[p][l] = P.lp[p][l].rs_off;
+            RA.rs_total[p] = P.rs_total[p];
+            if (P.rs_total[p] > rs_max) rs_max = P.rs_total[p];
+        }
+        hipLaunchKernelGGL(rowstart_kernel, dim3((rs_max + 255) / 256, 3), dim3(256), 0, s, coords, RA, n);
     }
-    size_t tmp = W.sort_tmp_bytes;
-    if (!y_sorted) {                               // otherwise the batch already arrives in ascending y: identity order
-        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const float*)(ws + W.keys_in[0]), (float*)(ws + W.keys_out[0]),
-                                                 (const int*)iota, (int*)(ws + W.order[0]), (size_t)n, 0, 32, s);
-        if (e != hipSuccess) return (int)e;
-    }
-    {
-        hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp, (const unsigned*)kx, (unsigned*)(ws + W.keys_out[1]),
-                                                 (const int*)iota, (int*)(ws + W.order[1]), (size_t)n, 0, kx_bits, s);
-        if (e != hipSuccess) return (int)e;
-    }
-    unsigned* sk_in = (unsigned*)(ws + W.skey_in);
-    unsigned* sk_out = (unsigned*)(ws + W.skey_out);
-    hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk_in, n, *sh);
-    const int nkeys = sh->t_res * sh->x_res;
-    int end_bit = 1;
-    while (((int64_t)1 << end_bit) < nkeys && end_bit < 32) ++end_bit;
-    size_t tmp2 = W.sort_tmp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs((void*)(ws + W.sort_tmp), tmp2, (const unsigned*)sk_in, sk_out, (const int*)iota, (int*)(ws + W.sorder), (size_t)n, 0, end_bit, s);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(sparse_rowstart_kernel, dim3((nkeys + 1 + 255) / 256), dim3(256), 0, s, (const unsigned*)sk_out, (int*)(ws + W.srowstart), nkeys, n);
-    return 0;
+    unsigned* sk = (unsigned*)(ws + W.skey);
+    hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk, n, *sh);
+    // the counting sort's exclusive starts are the sparse row table
+    return csort(sk, n, sh->t_res * sh->x_res, (int*)(ws + W.srowstart), (unsigned*)(ws + W.scursor), (int*)(ws + W.sorder), s);
 }
 
 template <int F>
 int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
                const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s) {
-    int* iota = (int*)(ws + W.iota);
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     // xy / yt latent gradients already level-major in ws AND the sparse columns' max|dz| already in its slots (chain kernel)
     const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;
@@ -597,7 +700,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     if (scols > 16 * F) return NVP_ERR_UNSUPPORTED;            // the sparse columns are scanned by the xt plane's own lanes
     const bool presorted = (flags & NVP_SCATTER_PRESORTED) != 0;      // nvp_encode_bwd_presort already ran on this workspace
     if (!presorted) {
-        int rc0 = presort(coords, n, lv, sh, ws, W, flags, s);
+        int rc0 = presort(coords, n, lv, sh, ws, W, P, flags, s);
         if (rc0) return rc0;
     }
 
@@ -612,7 +715,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         int c = 0;
         const int c0[3] = {1, 0, 0}, c1[3] = {2, 2, 1}, ord[3] = {0, 0, 1};
         for (int p = 0; p < 3; ++p) {
-            PA.order[p] = (ord[p] == 0 && y_sorted) ? (const int*)iota : (const int*)(ws + W.order[ord[p]]);
+            PA.order[p] = (ord[p] == 0 && y_sorted) ? (const int*)nullptr : (const int*)(ws + W.order[ord[p]]);
             PA.cs[p] = (float2*)(ws + W.cs[p]);
             PA.dzs[p] = (float*)(ws + W.dzs[p]);
             PA.col0[p] = c; PA.nlev[p] = lv[p]->n_levels; PA.c0[p] = c0[p]; PA.c1[p] = c1[p];
@@ -624,18 +727,6 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         hipLaunchKernelGGL((permute_kernel<F>), dim3((unsigned)((n + PermCfg<F>::PIX - 1) / PermCfg<F>::PIX), 3 - PA.plane0), dim3(256),
                            (size_t)PermCfg<F>::PIX * PermCfg<F>::STRIDE * sizeof(float), s, coords, dz, dz_stride, PA, (unsigned*)(ws + W.dzmax), n);
 
-        RowArgs RA;
-        int rs_max = 0;
-        for (int p = 0; p < 3; ++p) {
-            RA.cs[p] = (const float2*)(ws + W.cs[p]);
-            RA.rowstart[p] = (int*)(ws + W.rowstart[p]);
-            RA.lv[p] = *lv[p];
-            for (int l = 0; l < lv[p]->n_levels; ++l) RA.rs_off[p][l] = P.lp[p][l].rs_off;
-            RA.rs_total[p] = P.rs_total[p];
-            if (P.rs_total[p] > rs_max) rs_max = P.rs_total[p];
-        }
-        hipLaunchKernelGGL(rowstart_kernel, dim3((rs_max + 255) / 256, 3), dim3(256), 0, s, RA, n);
-
         BandArgs BA;
         BA.plan = P;
         float* grads[3] = {g0, g1, g2};
@@ -646,7 +737,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
             BA.rowstart[p] = (const int*)(ws + W.rowstart[p]);
             BA.grad[p] = grads[p];
         }
-        BA.slabs = (float*)(ws + W.slabs);
+        BA.slabs = (long long*)(ws + W.slabs);
         BA.dzmax = (const unsigned*)(ws + W.dzmax);
         BA.headroom_bits = headroom_bits;
         hipLaunchKernelGGL((band_kernel<F>), dim3(P.total_blocks), dim3(kBandThreads), (size_t)P.entries * 8, s, BA, n);
@@ -655,7 +746,9 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
             ReduceArgs R;
             R.plan = P;
             for (int p = 0; p < 3; ++p) { R.lv[p] = *lv[p]; R.grad[p] = grads[p]; }
-            R.slabs = (const float*)(ws + W.slabs);
+            R.slabs = (const long long*)(ws + W.slabs);
+            R.dzmax = (const unsigned*)(ws + W.dzmax);
+            R.headroom_bits = headroom_bits;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(64, P.reduce_items), dim3(256), 0, s, R);
         }
         return 0;
@@ -743,7 +836,7 @@ int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_
     int rc = carve(W, P, lv, sh, n);
     if (rc) return rc;
     if ((int64_t)W.total > workspace_bytes) return NVP_ERR_BADARG;
-    return presort(coords, n, lv, sh, (char*)workspace, W, flags, (hipStream_t)stream);
+    return presort(coords, n, lv, sh, (char*)workspace, W, P, flags, (hipStream_t)stream);
 }
 
 // dz: row-major latent gradient [>= n][dz_stride] (columns xy | yt | xt | sparse).

@@ -150,7 +150,8 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index, fast=False):
     if backend == "nccl":
         torch.cuda.set_device(dev_index)
     T, H, W = 8, 32, 32
-    cfg = small_cfg(F=2, T=T, X=9, Y=7)
+    # fast: a sparse grid large enough (8 M elements) for whole 3 M-element exchange pieces to lie inside it
+    cfg = small_cfg(F=2, T=100, X=200, Y=200) if fast else small_cfg(F=2, T=T, X=9, Y=7)
     mine = [halves[rank] for halves in _batches(T, H, W)]
     dev = f"cuda:{dev_index}"
     if fast:

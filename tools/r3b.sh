@@ -2,7 +2,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-NVP_PARITY_REPORT=1 timeout 1500 python -m pytest tests -m gpu -x -q --timeout 900 > gpurun_out/r3b_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/r3b_pytest.log
+NVP_PARITY_REPORT=1 timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/r3b_pytest.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/r3b_pytest.log
 tail -5 gpurun_out/r3b_pytest.log
 python bench.py --steps 20 --warmup 5 > gpurun_out/r3b_bench.json 2> gpurun_out/r3b_bench.err; tail -c 600 gpurun_out/r3b_bench.json
 python bench.py --mode eval --steps 8 --warmup 2 > gpurun_out/r3b_bench_eval.json 2> gpurun_out/r3b_bench_eval.err; cat gpurun_out/r3b_bench_eval.json | head -c 3000
