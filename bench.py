@@ -71,6 +71,7 @@ def work_per_pixel(F: int):
     """Algorithmic work per pixel (SURVEY.md 8d / DESIGN.md): GEMM MACs x 2 only; gather / scatter bytes."""
     D = 57 * F
     flop = {
+        "nvp_encode_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),   # fused gather + forward MLP: the MLP's MACs
         "nvp_mlp_fwd": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),          # 219 648 (F = 2)
         "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 2 * 128 * 128 + 2 * 128 * 128 + 3 * 128),              # dX of every layer but SIREN 0
         "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),       # dW: same MACs as fwd
@@ -81,6 +82,8 @@ def work_per_pixel(F: int):
         "nvp_encode_fwd": 12 + (192 + 9) * 4 * F + 4 * D,
         # scatter: coords 12 + latent-grad read 4D + the same cells read-modify-written once
         "nvp_encode_bwd": 12 + 4 * D + (192 + 9) * 4 * F,
+        # fused forward (training): coords + step in, the gathered cells, latent written once (for dW), five saved streams + RGB out
+        "nvp_encode_mlp_fwd": 12 + 4 + (192 + 9) * 4 * F + 4 * R + 5 * 512 + 12,
         # MLP stages: the activation / gradient streams they must move (128 rows x 4 B each; weights are L2-resident)
         "nvp_mlp_fwd": 4 * R + 4 + 5 * 512 + 12,                    # latent + step in, h0 h1 h2 q1 q2 + RGB out
         "nvp_mlp_bwd_dx": 12 + 4 + 5 * 512 + 5 * 512 + 80 + 4 * R,  # drgb + step + 5 saved streams in; dp0-2 dq1-2, tile records, latent gradient out
@@ -93,7 +96,7 @@ PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 PEAK_MFMA_16 = 2516.6e12        # bf16 / fp16 dense peak (32x32x16 forms)
 # stages that run on split-operand 16-bit MFMA: forward, backward chain and dW GEMMs (latents <= 256 rows); their
 # peak in fp32-equivalent FLOP is the 16-bit dense peak / the products issued per fp32 product (3: fp16 x 2 split, 6: bf16 x 3)
-B3_STAGES = ("nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
+B3_STAGES = ("nvp_encode_mlp_fwd", "nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
 PEAK_HBM = 8.0e12
 
 
@@ -161,7 +164,9 @@ def eval_bench(args, dev):
     model = NVP(out_features=3, encoding_config=make_cfg(F, T), verbose=False).to(dev)
     FLOP_PX, BYTES_PX = work_per_pixel(F)
     D, R = 57 * F, (57 * F + 3) // 4 * 4
-    bytes_fwd = {"nvp_encode_fwd": BYTES_PX["nvp_encode_fwd"], "nvp_mlp_fwd": 4 * R + 4 + 12}       # inference: latent + step in, RGB out
+    bytes_fwd = {"nvp_encode_fwd": BYTES_PX["nvp_encode_fwd"], "nvp_mlp_fwd": 4 * R + 4 + 12,       # inference: latent + step in, RGB out
+                 "nvp_encode_mlp_fwd": 12 + 4 + (192 + 9) * 4 * F + 12}                               # fused: coords + step + cells in, RGB out
+    FLOP_PX = dict(FLOP_PX)
     products = int(_lib.load().nvp_mlp_mfma_products())
     pk_mlp = PEAK_MFMA_16 / products if products > 1 else PEAK_MFMA_F32
     n_frames = max(args.steps, 1)
@@ -188,7 +193,7 @@ def eval_bench(args, dev):
             e = {"ms_per_frame": ms}
             if kk in bytes_fwd:
                 e["hbm_frac"] = round(bytes_fwd[kk] * px / (ms * 1e-3) / PEAK_HBM, 4)
-            if kk == "nvp_mlp_fwd":
+            if kk in ("nvp_mlp_fwd", "nvp_encode_mlp_fwd"):
                 e["mfma_frac"] = round(FLOP_PX[kk] * px / (ms * 1e-3) / pk_mlp, 4)
             st[kk] = e
         runs[name] = {"frames_per_s": round(n_frames / dt, 2), "mpx_per_s": round(n_frames * px / dt / 1e6, 1), "ms_per_frame": round(dt / n_frames * 1e3, 3),

@@ -147,6 +147,19 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
                    const float* emb, float* zt, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                    const nvp_sparse_shape* sh, int temporal_interp, int32_t flags, void* stream);
+/* ---- R11 in ONE launch: coordinates -> RGB (modules.py:57-84; nvp_amd/csrc/mlp_fwd_b3.hip + encode_tile.h) ----------------
+ * The grid lookups run INSIDE the forward MLP's waves: each wave gathers the latent tile of its 32 pixels straight into LDS (same
+ * arithmetic as nvp_encode_fwd: the latent is bit-identical) and runs the seven layers on it, so the latent is never read back from
+ * HBM and the separate gather launch disappears.  `saved` != NULL (training): the five activation streams are saved as by nvp_mlp_fwd
+ * AND the latent is written once to `zt` (PTM4, as nvp_encode_fwd would have) because the weight-gradient GEMMs read it; `saved` ==
+ * NULL (inference): `zt` may be NULL, nothing but RGB is written.  Supported (nvp_encode_mlp_fwd_supported() != 0) when all four
+ * grids have 2 or 4 features per level, every plane contributes a multiple of 8 latent rows and the latent has <= 144 rows
+ * (config_nvp_s); otherwise call nvp_encode_fwd + nvp_mlp_fwd.  packed_fwd: nvp_mlp_pack_fwd's output. */
+int32_t nvp_encode_mlp_fwd_supported(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh);
+int nvp_encode_mlp_fwd(const float* coords, const float* steps, const float* kf_xy, const float* kf_yt, const float* kf_xt,
+                       const float* emb, const nvp_mlp_params* p, const float* packed_fwd, float* rgb, float* saved, float* zt,
+                       int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                       const nvp_sparse_shape* sh, int temporal_interp, void* stream);
 /* R3 + R6 fused: latent gradient -> gradients of the four grids (nvp_amd/csrc/encode_bwd.hip).
  * dz: ROW-MAJOR [>= N][dz_stride] latent gradient as written by nvp_mlp_bwd_dx (columns
  * xy | yt | xt | sparse).  d_kf_* and d_emb: every element is OVERWRITTEN (deterministic

@@ -75,6 +75,9 @@ SIGNATURES = {
     "nvp_sparse3x3_inter_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
     "nvp_encode_fwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), C.c_int, _i32, _vp],
+    "nvp_encode_mlp_fwd_supported": [C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],
+    "nvp_encode_mlp_fwd": [_p, _p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
+                           C.POINTER(SparseShape), C.c_int, _vp],
     "nvp_encode_bwd": [_p, _p, _i32, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), _vp, _i64, _i32, _vp],
     "nvp_encode_bwd_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],
@@ -104,7 +107,7 @@ SIGNATURES = {
 _RESTYPES = {
     "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64,
     "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
-    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32, "nvp_mlp_mfma_products": _i32,
+    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32, "nvp_mlp_mfma_products": _i32, "nvp_encode_mlp_fwd_supported": _i32,
 }
 
 _lib: Optional[C.CDLL] = None

@@ -13,7 +13,7 @@ SRCS="encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r m
 # build_lib OUT.so OBJDIR "extra flags"
 build_lib() {
   local out=$1 objdir=$2 extra=$3
-  local FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed ${NVP_EXTRA_FLAGS:-} $extra"
+  local FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-constant-logical-operand ${NVP_EXTRA_FLAGS:-} $extra"
   local OBJS=() PIDS=() NAMES=()
   mkdir -p "$objdir"
   # a change of flags invalidates every object of that directory

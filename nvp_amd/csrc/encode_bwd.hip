@@ -48,6 +48,7 @@ constexpr int kLdsEntries = NVP_BAND_ENTRIES;   // target int64 entries per tabl
 constexpr int kMaxLdsEntries = 20000;           // 160 KB
 constexpr int kTargetVisits = 16384;          // pixel visits per band workgroup
 constexpr int kMaxSlots = 256;                // dzmax slots
+constexpr int kScanTile = 4096;               // counting-sort scan: bins per workgroup (256 threads x 16 consecutive bins)
 
 struct LevelPlan {
     int first_block;     // first blockIdx of this (plane, level)
@@ -116,6 +117,7 @@ struct Ws {                      // workspace carve (byte offsets)
     size_t keys[2], order[2], cs[3], dzs[3], rowstart[3], dzmax, slabs, total;
     size_t kstart[2], kcursor[2];                             // counting sorts of the two dense keys: exclusive starts, scatter cursors
     size_t skey, sorder, srowstart, scursor, sdzmax;         // sparse grid
+    size_t tsum;                                              // per-tile sums of the counting sorts' scans (shared: the sorts run one after the other)
     int nkeys[2];                                             // key ranges of the two dense sorts (y key, x key)
 };
 
@@ -148,6 +150,7 @@ int carve(Ws& W, const Plan& P, const nvp_levels* lv[3], const nvp_sparse_shape*
     const size_t nsk = (size_t)sh->t_res * sh->x_res + 1;
     W.srowstart = o; o = align_up(o + nsk * 4);
     W.scursor = o; o = align_up(o + nsk * 4);
+    W.tsum = o; o = align_up(o + (nsk / kScanTile + 2) * 4 + ((size_t)(W.nkeys[0] > W.nkeys[1] ? W.nkeys[0] : W.nkeys[1]) / kScanTile + 2) * 4);
     W.total = o;
     return 0;
 }
@@ -205,29 +208,45 @@ __global__ __launch_bounds__(256) void csort_hist_kernel(const unsigned* __restr
     }
 }
 
-// one workgroup: start[k] = sum of cnt[0..k), k in [0, nkeys]; cursor = copy of start; cnt is read, not modified
-__global__ __launch_bounds__(1024) void csort_scan_kernel(const unsigned* cnt, int* __restrict__ start, unsigned* cursor, int nkeys) {
-    __shared__ unsigned part[1024];
-    const int t = threadIdx.x;
-    const int per = (nkeys + 1023) / 1024;
-    const int k0 = min(nkeys, t * per), k1 = min(nkeys, k0 + per);
+// exclusive scan of the counts in two launches: per-tile sums (tiles of 4096 bins), then every tile adds the sums of the tiles
+// before it (<= a few dozen values, summed redundantly) to its own scan.  start[k] = sum of cnt[0..k), k in [0, nkeys];
+// cursor = the same values (cnt aliases cursor: a thread overwrites only elements it has read itself).
+
+__global__ __launch_bounds__(256) void csort_tilesum_kernel(const unsigned* __restrict__ cnt, unsigned* __restrict__ tsum, int nkeys) {
+    __shared__ unsigned part[4];
+    const int k0 = blockIdx.x * kScanTile + threadIdx.x * 16;
     unsigned s = 0u;
-    for (int k = k0; k < k1; ++k) s += cnt[k];
-    part[t] = s;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (k0 + u < nkeys) ? cnt[k0 + u] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += (unsigned)__shfl_xor((int)s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {           // Hillis-Steele inclusive scan of the 1024 partial sums
-        const unsigned v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (threadIdx.x == 0) tsum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void csort_scan_kernel(const unsigned* cnt, const unsigned* __restrict__ tsum, int* __restrict__ start, unsigned* cursor, int nkeys) {
+    __shared__ unsigned wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    unsigned base = 0u;
+    for (int b = 0; b < (int)blockIdx.x; ++b) base += tsum[b];        // <= nkeys / 4096 values
+    const int k0 = blockIdx.x * kScanTile + t * 16;
+    unsigned c[16], s = 0u;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { c[u] = (k0 + u < nkeys) ? cnt[k0 + u] : 0u; s += c[u]; }
+    unsigned incl = s;                                                // inclusive scan of the per-thread sums within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned v = (unsigned)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned run = base + incl - s;
+    for (int w2 = 0; w2 < wv; ++w2) run += wsum[w2];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (k0 + u < nkeys) { start[k0 + u] = (int)run; cursor[k0 + u] = run; }
+        run += c[u];
     }
-    unsigned run = part[t] - s;                    // exclusive prefix of this thread's chunk
-    for (int k = k0; k < k1; ++k) {
-        const unsigned c = cnt[k];
-        start[k] = (int)run; cursor[k] = run;
-        run += c;
-    }
-    if (t == 1023) { start[nkeys] = (int)part[1023]; cursor[nkeys] = part[1023]; }
+    if (k0 <= nkeys - 1 && nkeys - 1 < k0 + 16) { start[nkeys] = (int)run; cursor[nkeys] = run; }      // the thread that owns the last bin: run == n
 }
 
 __global__ __launch_bounds__(256) void csort_scatter_kernel(const unsigned* __restrict__ keys, unsigned* __restrict__ cursor, int* __restrict__ order, int64_t n, int nkeys) {
@@ -238,12 +257,14 @@ __global__ __launch_bounds__(256) void csort_scatter_kernel(const unsigned* __re
 }
 
 // cnt aliases `cursor` for the histogram phase (the scan reads cnt and overwrites it in place, element by element, after reading it)
-int csort(const unsigned* keys, int64_t n, int nkeys, int* start, unsigned* cursor, int* order, hipStream_t s) {
+int csort(const unsigned* keys, int64_t n, int nkeys, int* start, unsigned* cursor, unsigned* tsum, int* order, hipStream_t s) {
     hipError_t e = hipMemsetAsync(cursor, 0, ((size_t)nkeys + 1) * 4, s);
     if (e != hipSuccess) return (int)e;
     const unsigned nb = (unsigned)((n + kCsortChunk - 1) / kCsortChunk);
     hipLaunchKernelGGL(csort_hist_kernel, dim3(nb), dim3(256), nkeys <= kCsortLdsBins ? (size_t)nkeys * 4 : 0, s, keys, cursor, n, nkeys);
-    hipLaunchKernelGGL(csort_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)cursor, start, cursor, nkeys);
+    const unsigned nt = (unsigned)((nkeys + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL(csort_tilesum_kernel, dim3(nt), dim3(256), 0, s, (const unsigned*)cursor, tsum, nkeys);
+    hipLaunchKernelGGL(csort_scan_kernel, dim3(nt), dim3(256), 0, s, (const unsigned*)cursor, (const unsigned*)tsum, start, cursor, nkeys);
     hipLaunchKernelGGL(csort_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, cursor, order, n, nkeys);
     return 0;
 }
@@ -462,14 +483,15 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     const FixedScale fs = fixed_scale(s_k);
     const int lflags = A.lv[plane].flags;
 
-    // ---- sorted pixel ranges that can touch rows [r0, r1): rows iy in [r0-2, r1-1] (iy, iy + 1, and iy + 2 when the dim-0
-    //      corner i0 + 1 == res wraps into the next row), plus the wrap-around of the last two rows into rows 0/1 (the cell
-    //      index is taken mod res^2)
+    // ---- sorted pixel ranges that can touch rows [r0, r1): rows iy in [r0-1, r1-1] (a pixel touches iy and iy + 1), the
+    //      row r0-2 for the few pixels whose dim-0 corner i0 + 1 == res wraps into the next row (checked on the coordinates
+    //      alone, before anything else is loaded), plus the wrap-around of the last two rows into rows 0/1 (the cell index
+    //      is taken mod res^2)
     const int* rs = A.rowstart[plane] + L.rs_off;
-    const int loA = rs[max(r0 - 2, 0)], hiA = rs[r1];
+    const int loX = rs[max(r0 - 2, 0)], loA = rs[max(r0 - 1, 0)], hiA = rs[r1];
     int loW = 0, hiW = 0;
     if (r0 < 2) { loW = max(rs[max(res - 2, 0)], hiA); hiW = (int)n; if (loW > hiW) loW = hiW; }   // rows 0 and 1 receive the wrap
-    const int lenA = hiA - loA, lenT = lenA + (hiW - loW);
+    const int lenX = loA - loX, lenA = hiA - loA, lenT = lenX + lenA + (hiW - loW);
     const int kb = (int)(((long long)lenT * split) / L.splits);
     const int ke = (int)(((long long)lenT * (split + 1)) / L.splits);
 
@@ -478,17 +500,18 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     const int span = (r1 - r0) * res;
     const int base = r0 * res;
     for (int kk = kb + threadIdx.x; kk < ke; kk += kBandThreads) {
-        const int p = kk < lenA ? loA + kk : loW + (kk - lenA);
+        const bool extra = kk < lenX;
+        const int p = extra ? loX + kk : (kk < lenX + lenA ? loA + (kk - lenX) : loW + (kk - lenX - lenA));
         const float2 c = cs[p];
+        const float p0 = nvp_grid_pos(c.x, scale, lflags), p1 = nvp_grid_pos(c.y, scale, lflags);
+        const float f0 = floorf(p0), f1 = floorf(p1);
+        const int i0 = (int)f0, i1 = (int)f1;
+        if (extra && ((lflags & NVP_GRID_CLAMP) || i0 + 1 < res)) continue;      // row r0-2 only reaches row r0 through the wrap
         float g[F];
         bool any = false;
 #pragma unroll
         for (int f = 0; f < F; ++f) { g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
-        // cells first: most of the visits of a one-row band (3 rows visited, 2 touched) end here, before any weight or
-        // conversion is computed
-        const float p0 = nvp_grid_pos(c.x, scale, lflags), p1 = nvp_grid_pos(c.y, scale, lflags);
-        const float f0 = floorf(p0), f1 = floorf(p1);
-        const int i0 = (int)f0, i1 = (int)f1;
+        // cells first: a visit that touches no row of this band ends here, before any weight or conversion is computed
         int off[4];
         bool hit = false;
 #pragma unroll
@@ -582,54 +605,99 @@ __global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restric
     keys[i] = (unsigned)(nvp_nearest_idx(c[0], sh.t_res) * sh.x_res + nvp_nearest_idx(c[1], sh.x_res));
 }
 
-// rowstart[k] = first sorted position whose key is >= k, k in [0, T*X]: the counting sort's exclusive starts (csort_scan_kernel)
+// rowstart[k] = first sorted position whose key is >= k, k in [0, T*X]: the counting sort's exclusive starts (csort_scan_kernel).
+// One work item = (t, band of x rows): ~50 pixels.  An item's life is a chain of four dependent loads (row table -> order ->
+// coordinates -> latent gradient) in front of a few microseconds of LDS work, so the workgroups are PERSISTENT and software-
+// pipelined: while an item's table is flushed to the gradient (and zeroed for the next item in the same pass), the next item's
+// chain is already in flight into registers (two (pixel, patch x-row) units per thread; the rare item with more falls back to
+// loading in place).
+template <int F>
+struct SparseUnit { int row, yi; bool on; float g[3 * F]; };
+
+template <int F>
 __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
                                                                      const int* __restrict__ order, const int* __restrict__ rowstart,
                                                                      const unsigned* __restrict__ dzmax, float* __restrict__ demb,
-                                                                     nvp_sparse_shape sh, int rows_per_band, int bands, int headroom_bits) {
+                                                                     nvp_sparse_shape sh, int rows_per_band, int bands, int n_items, int headroom_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ int s_k;
     __shared__ bool s_poison;
-    const int F = sh.n_features;
-    const int t = blockIdx.x / bands, band = blockIdx.x - t * bands;
-    const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
-    const int entries = (r1 - r0) * sh.y_res * F;
-    for (int i = threadIdx.x; i < entries; i += kSparseThreads) tab[i] = 0ull;
     scale_from_slots(dzmax, headroom_bits, &s_k, &s_poison);
+    const int max_entries = rows_per_band * sh.y_res * F;
+    for (int i = threadIdx.x; i < max_entries; i += kSparseThreads) tab[i] = 0ull;
     __syncthreads();
     const FixedScale fs = fixed_scale(s_k);
-    const int lo = rowstart[t * sh.x_res + max(r0 - 1, 0)];
-    const int hi = rowstart[t * sh.x_res + min(r1, sh.x_res - 1) + 1];
-    // one work unit = (pixel, x-row of its 3x3 patch): 3 units per pixel, each owning three y-neighbours = 3F consecutive floats
-    // of the pixel's latent-gradient row
-    const int units = (hi - lo) * 3;
-    for (int u = threadIdx.x; u < units; u += kSparseThreads) {
-        const int q = u / 3, i = u - q * 3;
-        const int id = order[lo + q];
+    const double inv = ldexp(1.0, -s_k);
+    const bool poison = s_poison;
+
+    SparseUnit<F> un[2];
+    int lo_n = 0, hi_n = 0;
+    auto unit_load = [&](SparseUnit<F>& u, int p, int i, int r0, int r1) {
+        const int id = order[p];
         const float* c = coords + (int64_t)id * 3;
         const int xi = nvp_nearest_idx(c[1], sh.x_res);
         const int vx = min(max(xi + i - 1, 0), sh.x_res - 1);
-        if (vx < r0 || vx >= r1) continue;
-        const int yi = nvp_nearest_idx(c[2], sh.y_res);
-        const float* g = dz + (int64_t)id * dz_stride + col0 + 3 * i * F;
-        unsigned long long* row = tab + (vx - r0) * sh.y_res * F;
+        u.on = vx >= r0 && vx < r1;
+        u.row = vx - r0;
+        u.yi = nvp_nearest_idx(c[2], sh.y_res);
+        if (u.on) {
+            const float* g = dz + (int64_t)id * dz_stride + col0 + 3 * i * F;
+#pragma unroll
+            for (int e = 0; e < 3 * F; ++e) u.g[e] = g[e];
+        }
+    };
+    auto unit_apply = [&](const SparseUnit<F>& u) {
+        if (!u.on) return;
+        unsigned long long* row = tab + u.row * sh.y_res * F;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int vy = min(max(yi + j - 1, 0), sh.y_res - 1);
+            const int vy = min(max(u.yi + j - 1, 0), sh.y_res - 1);
+#pragma unroll
             for (int f = 0; f < F; ++f) {
-                const float v = g[j * F + f];
+                const float v = u.g[j * F + f];
                 if (v != 0.f) atomicAdd(row + vy * F + f, (unsigned long long)to_fixed(v, fs));
             }
         }
+    };
+    auto prefetch = [&](int item) {
+        const int t = item / bands, band = item - t * bands;
+        const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
+        lo_n = rowstart[t * sh.x_res + max(r0 - 1, 0)];
+        hi_n = rowstart[t * sh.x_res + min(r1, sh.x_res - 1) + 1];
+        const int units = (hi_n - lo_n) * 3;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int u = threadIdx.x + kSparseThreads * s2;
+            un[s2].on = false;
+            if (u < units) { const int q = u / 3; unit_load(un[s2], lo_n + q, u - q * 3, r0, r1); }
+        }
+    };
+
+    int item = blockIdx.x;
+    if (item < n_items) prefetch(item);
+    for (; item < n_items; item += gridDim.x) {
+        const int t = item / bands, band = item - t * bands;
+        const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
+        const int entries = (r1 - r0) * sh.y_res * F;
+        const int lo = lo_n, units = (hi_n - lo_n) * 3;
+        unit_apply(un[0]);
+        unit_apply(un[1]);
+        for (int u = threadIdx.x + 2 * kSparseThreads; u < units; u += kSparseThreads) {      // rare: more than 512 units
+            SparseUnit<F> x;
+            const int q = u / 3;
+            unit_load(x, lo + q, u - q * 3, r0, r1);
+            unit_apply(x);
+        }
+        __syncthreads();
+        if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);          // in flight during the flush
+        float* out = demb + (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
+        for (int i = threadIdx.x; i < entries; i += kSparseThreads) {
+            const long long v = (long long)tab[i];
+            tab[i] = 0ull;                                                          // ready for the next item
+            out[i] = poison ? __uint_as_float(0x7fc00000u) : (float)((double)v * inv);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const double inv = ldexp(1.0, -s_k);
-    float* out = demb + (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
-    if (s_poison) {
-        for (int i = threadIdx.x; i < entries; i += kSparseThreads) out[i] = __uint_as_float(0x7fc00000u);
-        return;
-    }
-    for (int i = threadIdx.x; i < entries; i += kSparseThreads) out[i] = (float)((double)(long long)tab[i] * inv);
 }
 
 bool levels_ok(const nvp_levels* lv) {
@@ -654,9 +722,9 @@ int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_s
                        *lv[0], *lv[1], *lv[2], n);
     int rc = 0;
     if (!y_sorted)                                 // otherwise the batch already arrives in ascending y: identity order
-        rc = csort(ky, n, W.nkeys[0], (int*)(ws + W.kstart[0]), (unsigned*)(ws + W.kcursor[0]), (int*)(ws + W.order[0]), s);
+        rc = csort(ky, n, W.nkeys[0], (int*)(ws + W.kstart[0]), (unsigned*)(ws + W.kcursor[0]), (unsigned*)(ws + W.tsum), (int*)(ws + W.order[0]), s);
     if (rc) return rc;
-    rc = csort(kx, n, W.nkeys[1], (int*)(ws + W.kstart[1]), (unsigned*)(ws + W.kcursor[1]), (int*)(ws + W.order[1]), s);
+    rc = csort(kx, n, W.nkeys[1], (int*)(ws + W.kstart[1]), (unsigned*)(ws + W.kcursor[1]), (unsigned*)(ws + W.tsum), (int*)(ws + W.order[1]), s);
     if (rc) return rc;
     // per-level row tables of the three planes (binary searches over the coordinates in each plane's order)
     {
@@ -677,7 +745,7 @@ int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_s
     unsigned* sk = (unsigned*)(ws + W.skey);
     hipLaunchKernelGGL(sparse_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, coords, sk, n, *sh);
     // the counting sort's exclusive starts are the sparse row table
-    return csort(sk, n, sh->t_res * sh->x_res, (int*)(ws + W.srowstart), (unsigned*)(ws + W.scursor), (int*)(ws + W.sorder), s);
+    return csort(sk, n, sh->t_res * sh->x_res, (int*)(ws + W.srowstart), (unsigned*)(ws + W.scursor), (unsigned*)(ws + W.tsum), (int*)(ws + W.sorder), s);
 }
 
 template <int F>
@@ -765,8 +833,20 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         int rows = sentries / (sh->y_res * sh->n_features);
         if (rows > sh->x_res) rows = sh->x_res;
         const int bands = (sh->x_res + rows - 1) / rows;
-        hipLaunchKernelGGL(sparse_band_kernel, dim3((unsigned)(sh->t_res * bands)), dim3(kSparseThreads), (size_t)sentries * 8, s,
-                           coords, dz, dz_stride, scol0, (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, headroom_bits + 2);
+        const int n_items = sh->t_res * bands;
+        // persistent workgroups: as many as fit the chip at once (LDS: 160 KB / table, at most 8 per CU of 256 CUs)
+        int per_cu = (int)((160 * 1024) / ((size_t)sentries * 8 + 64));
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        const int grid = n_items < 256 * per_cu ? n_items : 256 * per_cu;
+        const size_t lds = (size_t)rows * sh->y_res * sh->n_features * 8;
+        switch (sh->n_features) {
+#define NVP_SPARSE_CASE(FF) case FF: hipLaunchKernelGGL((sparse_band_kernel<FF>), dim3((unsigned)grid), dim3(kSparseThreads), lds, s, coords, dz, dz_stride, scol0, \
+                           (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, n_items, headroom_bits + 2); break;
+            NVP_SPARSE_CASE(1) NVP_SPARSE_CASE(2) NVP_SPARSE_CASE(4) NVP_SPARSE_CASE(8)
+#undef NVP_SPARSE_CASE
+            default: return NVP_ERR_UNSUPPORTED;
+        }
         return 0;
     };
 

@@ -424,6 +424,263 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
     }
 }
 
+// ---- grouped jobs: every operand stream of a (modulator layer k, SIREN layer k) pair is staged ONCE per workgroup -----------------
+// The seven GEMM jobs share operands: dp_k feeds dp_k x h_{k-1} and dp_k x z, h_{k-1} feeds dp_k x h_{k-1} and (as x_{k-1} = sin(.) h_{k-1})
+// dq_k x x_{k-1}.  As separate 256-thread jobs every stream is fetched once per job that uses it (7.5 KB per pixel requested
+// against 4.56 KB of distinct streams; PMC: 8.8 GB per step), and the stage is bound by exactly those bytes.  Here ONE 768-thread
+// workgroup per pixel chunk owns the three jobs of layer k (k = 1, 2):
+//     waves 0-3: dp_k x h_{k-1}      waves 4-7: dp_k x z      waves 8-11: dq_k x x_{k-1}
+// and stages the four streams they need (dp_k, dq_k, h_{k-1} [+ q_{k-1}, steps], z) once into five LDS tiles (the x tile is built
+// from the h float4 a thread holds anyway): 2.0 / 2.5 KB per pixel for k = 1 / 2.  Each wave owns a 64 x 64 sub-block exactly as
+// in mlp_dw_kernel - same fragments, same MFMA order, same running block scales (the scale of an operand depends on the tiles
+// seen so far, not on who staged them) - so the results are BIT-identical to the per-job kernel's.  dp_0 x z stays a plain job.
+// Twelve waves share one 90 KiB single-buffered tile set (one workgroup per CU, three waves per SIMD like the plain jobs).
+struct DwGroupArgs {
+    const float* a1;          // dp_k   (PTM4, 128 rows)
+    const float* a2;          // dq_k
+    const float* h;           // h_{k-1}
+    const float* q;           // q_{k-1} (K == 2)
+    const float* z;           // latent (PTM4, z_rows rows, d valid)
+    const float* steps;
+    const float* sir0_wp;     // SIREN layer 0 weight / bias (K == 1 rebuilds x_0 from them)
+    const float* sir0_bp;
+    int z_rows, d;
+    int ld_mod;               // 128 + d
+    int64_t w_h, w_z, w_x;    // offsets inside a partial: W_mod[k][:, 0], W_mod[k][:, 128], W_sir[k]
+    int64_t b_mod, b_sir;
+    int64_t total;
+};
+
+constexpr int kGroupThreads = 768;
+constexpr int kGroupItems = 6;                 // float4 items per thread and tile: 4 streams x 1024 / 768, rounded up
+
+template <int K>
+struct GroupStage {
+    float4 v[kGroupItems];
+    float4 q[K == 2 ? 2 : 1];                  // q_{k-1} of this thread's (at most two) h items
+};
+
+// item e = 768 it + tid of a tile: stream e >> 10 (wave-uniform: the boundaries are multiples of 256), float4 e & 1023 of that stream's tile
+template <int K>
+__device__ __forceinline__ void group_load(GroupStage<K>& s, const DwGroupArgs& A, int64_t t, int tid, int nvalid) {
+#pragma unroll
+    for (int it = 0; it < kGroupItems; ++it) {
+        const int e = kGroupThreads * it + tid;
+        const int sid = e >> 10, f = e & 1023;
+        // the streams an iteration can meet are known at compile time (boundaries at multiples of 256): it 0: dp; 1: dp, dq;
+        // 2: dq, h; 3: h; 4: z; 5: z (threads 0-255 only)
+        if (it <= 1 && sid == 0) s.v[it] = reinterpret_cast<const float4*>(A.a1)[t * 1024 + f];
+        if ((it == 1 || it == 2) && sid == 1) s.v[it] = reinterpret_cast<const float4*>(A.a2)[t * 1024 + f];
+        if ((it == 2 || it == 3) && sid == 2) {
+            s.v[it] = reinterpret_cast<const float4*>(A.h)[t * 1024 + f];
+            if (K == 2) s.q[it == 3 ? 1 : 0] = reinterpret_cast<const float4*>(A.q)[t * 1024 + f];
+        }
+        if (it >= 4 && sid == 3) s.v[it] = reinterpret_cast<const float4*>(A.z)[t * (A.z_rows >> 2) * 32 + min(f, nvalid - 1)];     // zeroed past the end when written
+    }
+}
+
+// tiles in LDS: [dp | dq | h | x | z]; mx[5]: running maxima (bit patterns) of the five tiles, raised with ds_max_u32
+template <int K>
+__device__ __forceinline__ void group_write(float* __restrict__ lds, unsigned* __restrict__ mx, const unsigned (&run)[5], const GroupStage<K>& s,
+                                            const DwGroupArgs& A, const float* __restrict__ tab, int64_t t, int64_t n, int tid, int lane, int nvalid) {
+    float sp = 0.f;
+    if (K == 1) sp = A.steps[min(t * 32 + (tid & 31), n - 1)];       // px = f & 31 = tid & 31 (768 and 1024 are multiples of 32)
+#pragma unroll
+    for (int it = 0; it < kGroupItems; ++it) {
+        const int e = kGroupThreads * it + tid;
+        const int sid = e >> 10, f = e & 1023;
+        if (sid > 3) continue;                      // it == 5, threads 256..767: nothing left
+        const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
+        const float4 v = s.v[it];
+        unsigned m = 0u, m2 = 0u;
+        if ((it == 2 || it == 3) && sid == 2) {
+            float* lh = lds + 2 * kTileFloats;
+            float* lx = lds + 3 * kTileFloats;
+            lh[o] = v.x; lh[o + kRowStride] = v.y; lh[o + 2 * kRowStride] = v.z; lh[o + 3 * kRowStride] = v.w;
+            float xv[4];
+            const float hv[4] = {v.x, v.y, v.z, v.w};
+            if (K == 2) {                            // x_1 = sin(q_1) * h_1            (modulation.py:88-90)
+                const float4 qq = s.q[it == 3 ? 1 : 0];
+                const float qv[4] = {qq.x, qq.y, qq.z, qq.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xv[c] = nvp_sin(qv[c]) * hv[c];
+            } else {                                 // x_0 = sin(30 (w s + c)) * h_0
+                const int row = 4 * (f >> 5);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xv[c] = nvp_sin(30.0f * __fmaf_rn(sp, tab[row + c], tab[NVP_H + row + c])) * hv[c];
+            }
+            lx[o] = xv[0]; lx[o + kRowStride] = xv[1]; lx[o + 2 * kRowStride] = xv[2]; lx[o + 3 * kRowStride] = xv[3];
+            if (NVP_SPLIT_H2) { m = __float_as_uint(absmax_f4(0.f, v)); m2 = __float_as_uint(absmax_f4(0.f, make_float4(xv[0], xv[1], xv[2], xv[3]))); }
+        } else {
+            float* l = lds + (sid == 3 ? 4 : sid) * kTileFloats;
+            const bool ok = sid != 3 || f < nvalid;
+            l[o] = ok ? v.x : 0.f; l[o + kRowStride] = ok ? v.y : 0.f; l[o + 2 * kRowStride] = ok ? v.z : 0.f; l[o + 3 * kRowStride] = ok ? v.w : 0.f;
+            if (NVP_SPLIT_H2 && ok) m = __float_as_uint(absmax_f4(0.f, v));
+        }
+#if NVP_SPLIT_H2
+        // the tile maxima only matter when they raise a running maximum: a wave-uniform test, then one LDS atomic per wave
+        const int slot = sid == 3 ? 4 : sid;
+        if (__any(m > run[slot])) { const unsigned w = wave_umax(m); if (lane == 0) atomicMax(&mx[slot], w); }
+        if (sid == 2 && __any(m2 > run[3])) { const unsigned w = wave_umax(m2); if (lane == 0) atomicMax(&mx[3], w); }
+#endif
+        __builtin_amdgcn_sched_barrier(0);           // one item at a time: keeps the sine temporaries from piling up
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(kGroupThreads, 1) void mlp_dw_group_kernel(DwGroupArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [dp | dq | h | x | z] tiles, 5 running maxima, (K == 1) SIREN-0 table
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wall = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform
+    const int job = wall >> 2, w = wall & 3;                             // 0: dp x h, 1: dp x z, 2: dq x x
+    const int i = lane & 31, h = lane >> 5;
+    const int wr = w >> 1, wc = w & 1;
+    const int chunk = blockIdx.x;
+    const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
+    const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
+    float* part = partials + (int64_t)chunk * A.total;
+    unsigned* mx = reinterpret_cast<unsigned*>(lds + 5 * kTileFloats);
+    float* tab = lds + 5 * kTileFloats + 8;
+    const int nvalid = min(1024, (A.z_rows >> 2) * 32);
+    if (tid < 8) mx[tid] = __float_as_uint(kTinyMax);
+    if (K == 1 && tid < NVP_H) { tab[tid] = A.sir0_wp[tid]; tab[NVP_H + tid] = A.sir0_bp[tid]; }
+    __syncthreads();
+
+    const int ta = job == 2 ? 1 : 0;                                     // A tile of this wave's job
+    const int tb = job == 0 ? 2 : (job == 1 ? 4 : 3);                    // B tile
+    const float* la = lds + ta * kTileFloats;
+    const float* lb = lds + tb * kTileFloats;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
+    float bsum0 = 0.f, bsum1 = 0.f;
+    const bool want_bias = job != 1 && wc == 0;
+
+    GroupStage<K> st;
+    unsigned run[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) run[u] = __float_as_uint(kTinyMax);
+    if (t0 < t1) {
+        group_load<K>(st, A, t0, tid, nvalid);
+        group_write<K>(lds, mx, run, st, A, tab, t0, n, tid, lane, nvalid);
+    }
+    PxScale qa = px_scale(kTinyMax), qb = qa;
+    float curS = qa.s * qb.s, curU = qa.u * qb.u;
+    __syncthreads();
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        if (more) group_load<K>(st, A, t + 1, tid, nvalid);
+#if NVP_DW_B3
+        {
+            if (NVP_SPLIT_H2) {
+#pragma unroll
+                for (int u = 0; u < 5; ++u) run[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)mx[u]);
+                qa = px_scale(__uint_as_float(run[ta])); qb = px_scale(__uint_as_float(run[tb]));
+                const float S = qa.s * qb.s;
+                if (S != curS) {                     // wave-uniform: a tile raised a running maximum
+                    const float ratio = S * curU;   // <= 1, a power of two
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[r][c] *= ratio;
+                    curS = S; curU = qa.u * qb.u;
+                }
+            }
+            float fa[16], fb[2][16];
+            read_frag(fa, la, 64 * wr + i, h);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) read_frag(fb[c], lb, 64 * wc + 32 * c + i, h);
+            BOp pb[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float x[8] = {fb[c][8 * s2], fb[c][8 * s2 + 1], fb[c][8 * s2 + 2], fb[c][8 * s2 + 3],
+                                        fb[c][8 * s2 + 4], fb[c][8 * s2 + 5], fb[c][8 * s2 + 6], fb[c][8 * s2 + 7]};
+                    split8(x, qb.s, pb[c][s2]);
+                }
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                if (r2 == 1) read_frag(fa, la, 64 * wr + 32 + i, h);
+                if (want_bias) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { if (r2 == 0) bsum0 += fa[k]; else bsum1 += fa[k]; }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float x[8] = {fa[8 * s2], fa[8 * s2 + 1], fa[8 * s2 + 2], fa[8 * s2 + 3], fa[8 * s2 + 4], fa[8 * s2 + 5], fa[8 * s2 + 6], fa[8 * s2 + 7]};
+                    BOp pa;
+                    split8(x, qa.s, pa);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) mac_parts(acc[r2][c], pa.p, pb[c][s2]);
+                }
+            }
+        }
+#else
+        {
+            float fa[16], fb[2][16];
+            read_frag(fa, la, 64 * wr + i, h);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) read_frag(fb[c], lb, 64 * wc + 32 * c + i, h);
+            if (want_bias) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) bsum0 += fa[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[0][0] = nvp_mfma(fa[k], fb[0][k], acc[0][0]);
+                acc[0][1] = nvp_mfma(fa[k], fb[1][k], acc[0][1]);
+            }
+            read_frag(fa, la, 64 * wr + 32 + i, h);
+            if (want_bias) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) bsum1 += fa[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[1][0] = nvp_mfma(fa[k], fb[0][k], acc[1][0]);
+                acc[1][1] = nvp_mfma(fa[k], fb[1][k], acc[1][1]);
+            }
+        }
+#endif
+        __syncthreads();                            // everyone finished reading the tiles
+        if (more) group_write<K>(lds, mx, run, st, A, tab, t + 1, n, tid, lane, nvalid);
+        __syncthreads();
+    }
+
+    {
+        const int ncols = job == 1 ? A.d : NVP_H;
+        const int64_t woff = job == 0 ? A.w_h : (job == 1 ? A.w_z : A.w_x);
+        const int ld = job == 2 ? NVP_H : A.ld_mod;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = 64 * wc + 32 * c + i;
+            if (col < ncols) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 64 * wr + 32 * r2 + nvp_frag_row(r, h);
+                        part[woff + (int64_t)row * ld + col] = (NVP_DW_B3 && NVP_SPLIT_H2) ? acc[r2][c][r] * curU : acc[r2][c][r];
+                    }
+            }
+        }
+        if (want_bias) {
+            bsum0 += __shfl_xor(bsum0, 32);
+            bsum1 += __shfl_xor(bsum1, 32);
+            if (h == 0) {
+                const int64_t boff = job == 0 ? A.b_mod : A.b_sir;
+                part[boff + 64 * wr + i] = bsum0;
+                part[boff + 64 * wr + 32 + i] = bsum1;
+            }
+        }
+    }
+}
+
 // Sum the per-tile small-gradient records of one pixel chunk into that chunk's partial (the chain kernel
 // wrote one kRecFloats record per 32-pixel tile into stream 3 of `dy`).  Thread = one record element:
 // consecutive threads read consecutive floats of a record, tiles are visited in order -> deterministic.
@@ -537,6 +794,10 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // HBM once instead of once per launch (PMC: 8.0 GB per step against 5.7 GB of distinct operand streams).  Bit-identical;
     // measured SLOWER (1.87 vs 1.71 ms): the plain jobs run on the heavier instantiation.  OFF by default.
     static const bool one_launch = [] { const char* e = getenv("NVP_DW_ONE_LAUNCH"); return e && e[0] == '1'; }();
+    // NVP_DW_GROUP (environment, read once; default 1): layers 1 and 2 run as GROUPED workgroups that stage every operand stream once
+    // (mlp_dw_group_kernel); only dp_0 x z stays a plain job.  0: the seven per-job workgroups (bit-identical results).
+    static const bool group_on = [] { const char* e = getenv("NVP_DW_GROUP"); return !(e && e[0] == '0'); }();
+    const bool group = group_on && d <= 128 && !merge && !one_launch;
     if (one_launch && n0 + n1 <= 12) {
         for (int j = 0; j < n0; ++j) P1.job[n1++] = P0.job[j];
         n0 = 0;
@@ -545,6 +806,27 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     P0.n_jobs = n0; P2.n_jobs = n2; P1.n_jobs = n1;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
+    if (group) {
+        // dp_0 x z as the one remaining plain job, then the two grouped launches
+        DwArgs Q0 = P0;
+        Q0.n_jobs = 1;                              // job 0 of P0 is (k = 0, c0 = 0): dp_0 x z with the bias
+        const size_t lds0 = ((NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
+        hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks), dim3(256), lds0, (hipStream_t)stream, Q0, partials, n, ntiles, tiles_per_chunk, n_chunks);
+        NVP_LAUNCH_CHECK();
+        for (int k = 1; k <= 2; ++k) {
+            DwGroupArgs G;
+            G.a1 = dy + (int64_t)k * act; G.a2 = dy + (int64_t)(3 + k) * act;
+            G.h = saved + (int64_t)(k - 1) * act; G.q = saved + 3 * act;
+            G.z = zt; G.z_rows = rows; G.d = d; G.steps = steps; G.sir0_wp = p->sir_w[0]; G.sir0_bp = p->sir_b[0];
+            G.ld_mod = NVP_H + d; G.w_h = P.mod_w[k]; G.w_z = P.mod_w[k] + NVP_H; G.w_x = P.sir_w[k];
+            G.b_mod = P.mod_b[k]; G.b_sir = P.sir_b[k]; G.total = P.total;
+            const size_t ldsg = (5 * kTileFloats + 8 + 2 * NVP_H) * sizeof(float);
+            if (k == 1) hipLaunchKernelGGL((mlp_dw_group_kernel<1>), dim3(n_chunks), dim3(kGroupThreads), ldsg, (hipStream_t)stream, G, partials, n, ntiles, tiles_per_chunk);
+            else hipLaunchKernelGGL((mlp_dw_group_kernel<2>), dim3(n_chunks), dim3(kGroupThreads), ldsg, (hipStream_t)stream, G, partials, n, ntiles, tiles_per_chunk);
+            NVP_LAUNCH_CHECK();
+        }
+        n0 = n2 = n1 = 0;                           // nothing left for the per-job launches
+    }
     // GEMM launches: plain jobs, merged jobs (512 threads, three LDS tiles per buffer), transform jobs; plus the record sums
     // tile buffers (the kernel places the tile maxima and the table behind them), 4 kMxW maxima
     const size_t lds_bytes = (2 * 2 * kTileFloats + 4 * kMxW + 2 * NVP_H) * sizeof(float);
@@ -554,7 +836,7 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     NVP_LAUNCH_CHECK();
     if (n2) hipLaunchKernelGGL((mlp_dw_kernel<0, 2>), dim3(n_chunks * n2), dim3(512), lds_bytes2, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
-    hipLaunchKernelGGL((mlp_dw_kernel<1, 1>), dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    if (n1) hipLaunchKernelGGL((mlp_dw_kernel<1, 1>), dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     hipLaunchKernelGGL(dw_records_kernel, dim3(n_chunks, (kRecFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy + 3 * act, partials,
                        ntiles, tiles_per_chunk, P.total, P.last_w, P.last_b, P.sir_w[0], P.sir_b[0]);

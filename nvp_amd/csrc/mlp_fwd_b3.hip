@@ -11,7 +11,9 @@
 #ifndef NVP_SPLIT_ASM
 #define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
 #endif
+#include <cstring>
 #include "mlp_b3.h"
+#include "encode_tile.h"      // in-wave tile gather (FMA contraction off inside, restored after)
 
 #ifndef NVP_B3_ZUNROLL
 #define NVP_B3_ZUNROLL 1        // straight-line latent chain for the 8-step (nvp_s) case: 1.854 vs 1.879 ms
@@ -117,11 +119,14 @@ __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __re
     }
 }
 
-template <bool SAVE>
-__global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float* __restrict__ zt, const float* __restrict__ steps,
+// GF = 0: the latent tile is staged from the tensor `zt` a gather kernel wrote.  GF = 2 / 4 (= features per level): the wave
+// GATHERS its tile itself (encode_tile.h) - `zt` is then an OUTPUT, written only when SAVE (the dW GEMMs of the backward pass
+// read it) and may be null otherwise.
+template <bool SAVE, int GF>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __restrict__ zt, const float* __restrict__ steps,
                                                                     nvp_mlp_params p, const unsigned* __restrict__ packed,
                                                                     float* __restrict__ rgb, float* __restrict__ saved,
-                                                                    int64_t n, int64_t ntiles, int d) {
+                                                                    int64_t n, int64_t ntiles, int d, NvpTileEnc enc) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #ifndef NVP_FWD_SYNC
@@ -149,12 +154,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
     float4* z = zlds + wv * zl4;
     const int z4 = (nvp_rows4(d) / 4) * 32;
     const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
-    float mz = stage_z_absmax(z, zg, min(z4, zl4), lane);     // per-pixel max |z|: the latent's share of the operand scale
+    float mz;                                                 // per-pixel max |z|: the latent's share of the operand scale
+    if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
+    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (NVP_SPLIT_H2) {
-        for (int idx = zl4 + lane; idx < z4; idx += 64) mz = absmax_f4(mz, zg[idx]);      // wide latents: the rows the LDS tile does not hold
+        if (GF == 0) for (int idx = zl4 + lane; idx < z4; idx += 64) mz = absmax_f4(mz, zg[idx]);      // wide latents: the rows the LDS tile does not hold
         mz = fmaxf(mz, __shfl_xor(mz, 32));
     }
     const int rg_end = nvp_rows4(d) / 4;
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
         const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
         bias_b3(hm, w, ps.s, lane);
         chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
-        chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
+        if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
         lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
             bias_b3(acc, w, ps.s, lane);
             chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
             chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
-            chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
+            if (GF == 0) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
             lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(const float*
 
 }  // namespace
 
-// called by nvp_mlp_fwd (mlp_fwd.hip) when NVP_FWD_B3 is on and the latent has <= 128 rows
+// called by nvp_mlp_fwd (mlp_fwd.hip) when NVP_FWD_B3 is on and the latent has <= 256 rows
 int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_params* p, const float* packed_fwd,
                           float* rgb, float* saved, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
@@ -275,10 +282,66 @@ int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_par
     const int zs = nvp_fwd_layout_b3(d).zs;
     const size_t lds = (size_t)kWaves * (zs < kB3ZLdsSteps ? zs : kB3ZLdsSteps) * 4 * 32 * sizeof(float4);      // 64 KB (nvp_s), 72 KB (nvp_l)
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_fwd);
+    NvpTileEnc none;
+    memset(&none, 0, sizeof(none));
+    float* z = const_cast<float*>(zt);
     if (saved)
-        hipLaunchKernelGGL(mlp_fwd_b3_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d);
+        hipLaunchKernelGGL((mlp_fwd_b3_kernel<true, 0>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, z, steps, *p, pk, rgb, saved, n, ntiles, d, none);
     else
-        hipLaunchKernelGGL(mlp_fwd_b3_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d);
+        hipLaunchKernelGGL((mlp_fwd_b3_kernel<false, 0>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, z, steps, *p, pk, rgb, saved, n, ntiles, d, none);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- R11 fused: coordinates -> RGB in ONE kernel (the gather runs inside the forward MLP's waves) --------------------------------
+// Supported when the whole latent fits the wave's LDS tile (<= 144 rows: config_nvp_s) and the grids have 2 or 4 features per level,
+// every plane's rows start on a row-group boundary; nvp_encode_mlp_fwd_supported() tells a host.
+static bool fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, int* d_out) {
+    if (!NVP_FWD_B3 || !lv_xy || !lv_yt || !lv_xt || !sh) return false;
+    const int F = lv_xy->n_features;
+    if (!(F == 2 || F == 4) || lv_yt->n_features != F || lv_xt->n_features != F || sh->n_features != F || sh->y_res < 3) return false;
+    const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
+    int d = 0;
+    for (int q = 0; q < 3; ++q) {
+        if (lv[q]->flags != kTileFlags) return false;        // the in-wave gather is compiled for the default arithmetic variant
+        if (lv[q]->n_levels < 1 || lv[q]->n_levels > NVP_MAX_LEVELS || (lv[q]->n_levels * F) % 8) return false;     // an even number of row-groups per plane
+        d += lv[q]->n_levels * F;
+    }
+    d += 9 * F;
+    if (nvp_fwd_layout_b3(d).zs > kB3ZLdsSteps) return false;
+    if (d_out) *d_out = d;
+    return true;
+}
+
+extern "C" int32_t nvp_encode_mlp_fwd_supported(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh) {
+    return fused_ok(lv_xy, lv_yt, lv_xt, sh, nullptr) ? 1 : 0;
+}
+
+extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const float* kf_xy, const float* kf_yt, const float* kf_xt,
+                                  const float* emb, const nvp_mlp_params* p, const float* packed_fwd, float* rgb, float* saved, float* zt,
+                                  int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                                  const nvp_sparse_shape* sh, int temporal_interp, void* stream) {
+    int d = 0;
+    if (!fused_ok(lv_xy, lv_yt, lv_xt, sh, &d) || temporal_interp) return NVP_ERR_UNSUPPORTED;
+    if (!coords || !steps || !kf_xy || !kf_yt || !kf_xt || !emb || !p || !packed_fwd || !rgb || n < 0) return NVP_ERR_BADARG;
+    if (saved && !zt) return NVP_ERR_BADARG;          // training: the latent is an output too (the dW GEMMs read it)
+    if (n == 0) return 0;
+    NvpTileEnc e;
+    e.lv[0] = *lv_xy; e.lv[1] = *lv_yt; e.lv[2] = *lv_xt; e.sh = *sh;
+    e.kf[0] = kf_xy; e.kf[1] = kf_yt; e.kf[2] = kf_xt; e.emb = emb; e.coords = coords;
+    int col = 0;
+    for (int q = 0; q < 3; ++q) { e.col0[q] = col; col += e.lv[q].n_levels * e.lv[q].n_features; }
+    e.col0[3] = col;
+    e.rows = nvp_rows4(d);
+    const int64_t ntiles = nvp_ntiles(n);
+    dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    const size_t lds = (size_t)kWaves * nvp_fwd_layout_b3(d).zs * 4 * 32 * sizeof(float4);
+    const unsigned* pk = reinterpret_cast<const unsigned*>(packed_fwd);
+    const int F = lv_xy->n_features;
+#define NVP_FUSED_LAUNCH(SV, GF) hipLaunchKernelGGL((mlp_fwd_b3_kernel<SV, GF>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d, e)
+    if (saved) { if (F == 2) NVP_FUSED_LAUNCH(true, 2); else NVP_FUSED_LAUNCH(true, 4); }
+    else { if (F == 2) NVP_FUSED_LAUNCH(false, 2); else NVP_FUSED_LAUNCH(false, 4); }
+#undef NVP_FUSED_LAUNCH
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -101,6 +101,10 @@ AUTO_SORT_MIN = int(os.environ.get("NVP_AUTO_SORT_MIN", "65536"))
 # and for tests; off by default because the sync would serialise the training loop.
 CHECK_SORTED = os.environ.get("NVP_CHECK_SORTED", "0") == "1"
 
+# NVP.forward in ONE launch: the grid lookups run inside the forward MLP's waves (nvp_encode_mlp_fwd; config_nvp_s-sized latents).
+# NVP_FUSED_FWD=0 keeps the two-kernel path (gather kernel -> latent in HBM -> MLP kernel); RGB and gradients are bit-identical.
+FUSED_FWD = os.environ.get("NVP_FUSED_FWD", "1") != "0"
+
 # For y-sorted batches the backward chain hands the xy / yt planes' latent gradients to the scatter in its own level-major
 # layout (nvp_encode_bwd_prepare / NVP_DZ_PLANES_READY): 2/3 of the scatter's permute pass disappear.  NVP_DZ_LEVEL_MAJOR=0 keeps
 # the row-major hand-over for every plane (bit-identical gradients either way).
@@ -363,7 +367,9 @@ class NVPFused(torch.autograd.Function):
         if need_grad and not y_sorted and not temporal_interp and AUTO_SORT_MIN > 0 and n >= AUTO_SORT_MIN:
             order = torch.argsort(coords[:, 2])
             coords, steps, y_sorted = coords[order], steps[order], True
-        zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32)
+        fused = bool(n) and FUSED_FWD and not temporal_interp and bool(lib.nvp_encode_mlp_fwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh)))
+        # the latent tensor: an intermediate of the two-kernel path; with the fused forward it only exists for the backward pass
+        zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32) if (need_grad or not fused) else None
         # Scatter workspace, allocated here when a backward pass will follow: (a) for y-sorted batches the backward chain writes the
         # xy / yt planes' latent gradients straight into the scatter's level-major buffers, (b) everything the scatter derives from
         # the COORDINATES alone (sort keys, orders, the sparse row table: a dozen small latency-bound kernels, ~0.26 ms back to
@@ -419,11 +425,27 @@ class NVPFused(torch.autograd.Function):
                     ev = torch.cuda.Event()
                     ev.record()
                     ctx.packed_bwd = (pk_b, ev)
-        if n:
-            L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
-                                       C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
-                                       1 if temporal_interp else 0, L.COORDS_SORTED_BY_Y if y_sorted else 0, L.stream_ptr()), "nvp_encode_fwd")
-        rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad, packed=packed_fwd)
+        if fused:
+            # one launch: every wave of the forward MLP gathers its own latent tile into LDS; the latent tensor is written only
+            # when a backward pass will read it (dW GEMMs)
+            pstruct = L.mlp_params_struct(mlp)
+            if packed_fwd is not None:
+                packed, ev = packed_fwd
+                torch.cuda.current_stream(dev).wait_event(ev)
+            else:
+                packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
+                L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
+            rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+            saved = torch.empty((5, L.ntiles(n), L.HIDDEN, L.TILE), device=dev, dtype=torch.float32) if need_grad else None
+            L.check(_call("nvp_encode_mlp_fwd", lib.nvp_encode_mlp_fwd, L.ptr(coords), L.ptr(steps), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb),
+                          C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), L.ptr(zt) if need_grad else None, n,
+                          C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh), 1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_mlp_fwd")
+        else:
+            if n:
+                L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
+                                           C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
+                                           1 if temporal_interp else 0, L.COORDS_SORTED_BY_Y if y_sorted else 0, L.stream_ptr()), "nvp_encode_fwd")
+            rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad, packed=packed_fwd)
         if need_grad:
             if temporal_interp:
                 raise NotImplementedError("temporal_interp=True is an inference-only path (reference eval.py --t_interp)")

@@ -1101,7 +1101,7 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     """The alternative kernels kept behind environment switches (read once per process by libnvp_hip.so) - the LDS-staged gather
     (NVP_ENCODE_LDS=1), the workgroup-shared weight ring of the forward chain (NVP_MLP_RING_FWD=1), the per-wave backward
     chain (NVP_MLP_RING_BWD=0), the merged dW jobs (NVP_DW_MERGE=1), the row-major latent-gradient hand-over to the scatter
-    (NVP_DZ_LEVEL_MAJOR=0), all dW jobs in one launch (NVP_DW_ONE_LAUNCH=1) on a second stream (NVP_DW_SIDE_STREAM=1) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
+    (NVP_DZ_LEVEL_MAJOR=0), the per-job dW workgroups (NVP_DW_GROUP=0), the two-kernel forward (NVP_FUSED_FWD=0: gather kernel -> latent in HBM -> MLP kernel), all dW jobs in one launch (NVP_DW_ONE_LAUNCH=1) on a second stream (NVP_DW_SIDE_STREAM=1) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
     accumulator, same index arithmetic; only where operands are staged differs)."""
     import subprocess
     import sys
@@ -1110,7 +1110,8 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     for k, env in enumerate(({"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # the defaults
                              {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1",
                               "NVP_DZ_LEVEL_MAJOR": "0"},                                                                # every alternative
-                             {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1", "NVP_SCATTER_PRESORT": "0"})):           # launch / stream experiments
+                             {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1", "NVP_SCATTER_PRESORT": "0"},            # launch / stream experiments
+                             {"NVP_DW_GROUP": "0", "NVP_FUSED_FWD": "0"})):                                                                      # the seven per-job dW workgroups instead of the grouped ones
         out = str(tmp_path / f"v{k}.npz")
         subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300,
                        env={**os.environ, **env})
