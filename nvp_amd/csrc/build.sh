@@ -8,7 +8,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS="encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r mlp_bwd mlp_bwd_b3 mlp_bwd_b3r mlp_dw harness optim"
+SRCS="encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r mlp_bwd mlp_bwd_b3 mlp_bwd_b3r mlp_dw mlp_dw_glds harness optim"
 
 # build_lib OUT.so OBJDIR "extra flags"
 build_lib() {

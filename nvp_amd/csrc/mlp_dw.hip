@@ -739,6 +739,9 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
 
 }  // namespace
 
+int nvp_mlp_dw_glds_launch(const float* steps, const float* zt, const float* saved, const float* dy, const nvp_mlp_params* p,
+                           float* partials, int32_t n_chunks, int64_t n, int32_t d, void* stream);        // mlp_dw_glds.hip
+
 extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
                               const float* dy, const nvp_mlp_params* p, float* partials, int32_t n_chunks,
                               const nvp_mlp_grads* g, int64_t n, int32_t d, void* stream) {
@@ -794,10 +797,13 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // HBM once instead of once per launch (PMC: 8.0 GB per step against 5.7 GB of distinct operand streams).  Bit-identical;
     // measured SLOWER (1.87 vs 1.71 ms): the plain jobs run on the heavier instantiation.  OFF by default.
     static const bool one_launch = [] { const char* e = getenv("NVP_DW_ONE_LAUNCH"); return e && e[0] == '1'; }();
-    // NVP_DW_GROUP (environment, read once; default 1): layers 1 and 2 run as GROUPED workgroups that stage every operand stream once
+    // NVP_DW_GROUP=1 (environment, read once; default 0): layers 1 and 2 run as register-staged GROUPED workgroups that stage every operand stream once
     // (mlp_dw_group_kernel); only dp_0 x z stays a plain job.  0: the seven per-job workgroups (bit-identical results).
-    static const bool group_on = [] { const char* e = getenv("NVP_DW_GROUP"); return !(e && e[0] == '0'); }();
-    const bool group = group_on && d <= 128 && !merge && !one_launch;
+    static const bool group_on = [] { const char* e = getenv("NVP_DW_GROUP"); return e && e[0] == '1'; }();      // register-staged grouping: measured slower, off
+    // NVP_DW_GLDS (environment, read once; default 1): the grouped workgroups fed by LDS DMA (mlp_dw_glds.hip)
+    static const bool glds_on = [] { const char* e = getenv("NVP_DW_GLDS"); return !(e && e[0] == '0'); }();
+    const bool glds = glds_on && NVP_DW_B3 && NVP_SPLIT_H2 && d <= 128 && (n & 3) == 0 && !merge && !one_launch;
+    const bool group = !glds && group_on && d <= 128 && !merge && !one_launch;
     if (one_launch && n0 + n1 <= 12) {
         for (int j = 0; j < n0; ++j) P1.job[n1++] = P0.job[j];
         n0 = 0;
@@ -806,6 +812,17 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     P0.n_jobs = n0; P2.n_jobs = n2; P1.n_jobs = n1;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
+    if (glds) {
+        // dp_0 x z as the one remaining plain job, then the two DMA-fed grouped launches
+        DwArgs Q0 = P0;
+        Q0.n_jobs = 1;                              // job 0 of P0 is (k = 0, c0 = 0): dp_0 x z with the bias
+        const size_t lds0 = ((NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
+        hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks), dim3(256), lds0, (hipStream_t)stream, Q0, partials, n, ntiles, tiles_per_chunk, n_chunks);
+        NVP_LAUNCH_CHECK();
+        const int rc = nvp_mlp_dw_glds_launch(steps, zt, saved, dy, p, partials, n_chunks, n, d, stream);
+        if (rc) return rc;
+        n0 = n2 = n1 = 0;
+    }
     if (group) {
         // dp_0 x z as the one remaining plain job, then the two grouped launches
         DwArgs Q0 = P0;
