@@ -800,8 +800,12 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // NVP_DW_GROUP=1 (environment, read once; default 0): layers 1 and 2 run as register-staged GROUPED workgroups that stage every operand stream once
     // (mlp_dw_group_kernel); only dp_0 x z stays a plain job.  0: the seven per-job workgroups (bit-identical results).
     static const bool group_on = [] { const char* e = getenv("NVP_DW_GROUP"); return e && e[0] == '1'; }();      // register-staged grouping: measured slower, off
-    // NVP_DW_GLDS (environment, read once; default 1): the grouped workgroups fed by LDS DMA (mlp_dw_glds.hip)
-    static const bool glds_on = [] { const char* e = getenv("NVP_DW_GLDS"); return !(e && e[0] == '0'); }();
+    // NVP_DW_GLDS=1 (environment, read once; default 0): layers 1 and 2 as grouped workgroups fed by LDS DMA, every operand stream
+    // read once and split once (mlp_dw_glds.hip).  Correct (same tolerances; not bit-identical: other summation order) and
+    // MEASURED SLOWER on MI355X - 0.99 + 0.92 ms for the two launches against 1.30 ms for the six jobs they replace: the DMA
+    // skeleton alone streams at 6 TB/s (0.5 ms per launch) and the MFMA phase hides under it, but the staging pass between them
+    // (three barriers and an LDS latency chain per 16-pixel step) adds 0.4 ms per launch.  Kept as the measured alternative.
+    static const bool glds_on = [] { const char* e = getenv("NVP_DW_GLDS"); return e && e[0] == '1'; }();
     const bool glds = glds_on && NVP_DW_B3 && NVP_SPLIT_H2 && d <= 128 && (n & 3) == 0 && !merge && !one_launch;
     const bool group = !glds && group_on && d <= 128 && !merge && !one_launch;
     if (one_launch && n0 + n1 <= 12) {

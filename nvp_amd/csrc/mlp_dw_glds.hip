@@ -1,34 +1,43 @@
-// Weight gradients of modulator layer k and SIREN layer k (k = 1, 2) with every operand stream read ONCE and fed to LDS by DMA.
+// Weight gradients of modulator layer k and SIREN layer k (k = 1, 2) with every operand stream read ONCE, fed to LDS by DMA and
+// split into 16-bit MFMA operands ONCE.
 //
 // Why.  As seven independent 256-thread jobs (mlp_dw.hip) the dW stage requests 7.5 KB per pixel for 4.56 KB of distinct operand
-// streams - jobs that share a stream each fetch it - and is bound by those bytes (PMC: 8.8 GB per step at 4.9 TB/s).  One 768-thread
-// workgroup per pixel chunk that owns the three jobs of a layer
-//     waves 0-3: dp_k x h_{k-1}      waves 4-7: dp_k x z      waves 8-11: dq_k x x_{k-1},   x = sin(.) h  rebuilt on the fly
-// needs 2.0 / 2.5 KB per pixel (k = 1 / 2).  Staged through registers (mlp_dw_group_kernel) that workgroup is alone on its CU and
-// keeps only ~70 KB in flight part of the time: 2.8 TB/s, slower than the jobs it replaces.  Here the tiles go global -> LDS with
-// global_load_lds (16 B per lane, no registers, no write pass): a ring of three 16-pixel stages keeps two stages (65-80 KB)
-// in flight all the time, across the barriers (raw s_barrier + counted vmcnt; tools/probes/glds_stream_probe.hip: this access
-// pattern streams at 6.0 TB/s from one workgroup per CU).
+// streams - jobs that share a stream each fetch it (PMC: 8.8 GB per step) - and every operand value is split into its fp16 hi / lo
+// parts by each of the two (dp: four) waves that consume it: bytes and VALU instructions are what the stage costs.  Here ONE
+// 768-thread workgroup per pixel chunk owns the three jobs of a layer
+//     waves 0-3: dp_k x h_{k-1}      waves 4-7: dp_k x z      waves 8-11: dq_k x x_{k-1},   x = sin(.) h
+// (2.0 / 2.5 KB per pixel for k = 1 / 2) and works in three phases per 16-pixel step:
+//   1. DMA.  global_load_lds (16 B per lane, no registers) brings the raw PTM4 half tiles of dp, dq, h, (q,) z (+ the 16 temporal
+//      steps) into a two-stage ring; one stage is always in flight across the barriers (raw s_barrier + counted vmcnt;
+//      tools/probes/glds_stream_probe.hip: this access pattern streams at 6.0 TB/s from one workgroup per CU).
+//   2. Stage.  Every thread takes the 16-byte units its own DMA instructions brought (4 rows x 1 pixel each), feeds the tiles'
+//      running maxima (the power-of-two block scales of the fp16 x 2 split, mlp_b3.h), splits each value ONCE, builds x = sin(.) h
+//      ONCE, and writes the hi / lo halves into fragment-shaped planes [row][16 px]: a lane's 8 consecutive k of one row are
+//      16 contiguous bytes.
+//   3. MFMA.  Each wave reads its two A and two B fragments as ds_read_b128 (hi, lo) and issues the 12 products of its 64 x 64
+//      sub-block: no split, no sine, no address arithmetic in the wave that multiplies.
+// Bias gradients (row sums of dp / dq) are accumulated by the staging threads, which see every value exactly once.
 //
-// LDS image.  A DMA writes lane l of a wave instruction to (wave-uniform base) + 16 l: the image is the PTM4 half tile itself,
-// [row-group][16 px] 16-byte units.  An MFMA fragment needs 8 consecutive pixels of ONE row = 8 dwords 16 bytes apart, and the
-// 32 lanes of a half wave (8 row-groups x 4 rows) would hit 4 banks.  So the SOURCE pixel of unit (rg, slot) is rotated,
-// slot = (px + 2 rg) & 15: the 8 row-groups of a fragment then start 8 banks apart and a ds_read_b32 is conflict free.
+// Arithmetic: split-operand 16-bit MFMA under a running power-of-two block scale per operand tile, as mlp_dw_kernel; x_{k-1}
+// shares h_{k-1}'s scale (|x| <= |h|).  Results equal the per-job kernels' to fp32 summation order, not bit for bit.
 //
-// Arithmetic: that of mlp_dw_kernel (split-operand 16-bit MFMA under a running power-of-two block scale per operand tile,
-// mlp_b3.h), one 16-pixel k-step per stage.  The tile maxima the scales follow are taken from LDS after a stage has landed.
-// x_{k-1} shares h_{k-1}'s scale (|x| <= |h|).  Results equal the per-job kernels' to fp32 summation order (the pixels of a
-// 32-pixel tile enter the k-steps in a different order), not bit for bit.
+// All LDS traffic of the main loop is inline assembly: hipcc's waitcnt insertion treats a pending LDS DMA as a write to ALL of
+// LDS and puts s_waitcnt vmcnt(0) in front of every LDS access it can see, which would drain the ring every step.
 #include <cstdlib>
 #include "mlp_b3.h"
 
 #ifndef NVP_DW_B3
 #define NVP_DW_B3 1
 #endif
+#ifndef NVP_GL_ABL
+#define NVP_GL_ABL 0        // ablation builds only (timing, wrong results): 1 = no staging pass; 2 = also no fragment reads / MFMAs
+#endif
 
 namespace {
 
-constexpr int kThreads = 768, kWaves = 12, kStages = 3;
+constexpr int kThreads = 768, kWaves = 12, kStages = 2;
+constexpr int kPlaneTile = 8192;                 // one operand tile in the planes: hi [128 rows][16 px] halves (4 KB), then lo
+constexpr int kPlanes = 5 * kPlaneTile;          // dp, dq, h, x, z
 
 struct GArgs {
     const float* a1;          // dp_k   (PTM4, 128 rows)
@@ -43,8 +52,8 @@ struct GArgs {
     int64_t w_h, w_z, w_x, b_mod, b_sir, total;
 };
 
-// stage layout in 16-byte units, every stream on a wave-instruction (64-unit) boundary so that a DMA instruction has ONE source
-// stream (uniform base in scalar registers + a 32-bit lane offset): [dp 512 | dq 512 | h 512 | (q 512) | z 512 (16 rgz used) | (steps 64, 4 used)]
+// raw stage layout in 16-byte units, every stream on a wave-instruction (64-unit) boundary so that a DMA instruction has ONE
+// source stream: [dp 512 | dq 512 | h 512 | (q 512) | z 512 (16 rgz used) | (steps 64, 4 used)]; unit = (row-group, pixel)
 template <int K> struct Lay {
     static constexpr int oA1 = 0, oA2 = 512, oH = 1024, oQ = 1536;
     static constexpr int oZ = K == 2 ? 2048 : 1536;
@@ -52,31 +61,19 @@ template <int K> struct Lay {
     static constexpr int units = K == 2 ? oZ + 512 : oS + 64;
 };
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)((const __attribute__((address_space(3))) char*)p); }
-
-// global -> LDS DMA of 16 bytes per lane: LDS destination = M0 (wave-uniform byte address) + 16 x lane.  Inline assembly, not
-// __builtin_amdgcn_global_load_lds: hipcc sinks the builtin below the MFMAs of the step (nothing it can see depends on it), which
-// halves the time a stage spends in flight; asm volatile statements keep their program order among themselves (LDS reads, waits).
-// Source = uniform 64-bit base (scalar registers) + a 32-bit per-lane byte offset.
+// global -> LDS DMA of 16 bytes per lane: LDS destination = M0 (wave-uniform byte address) + 16 x lane; source = uniform 64-bit base
+// (scalar registers) + a 32-bit per-lane byte offset
 __device__ __forceinline__ void glds16(const void* ubase, unsigned lane_off, unsigned lds_byte) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(ubase), "s"(lds_byte) : "memory");
 }
-// LDS accesses of the main loop are written as inline assembly: hipcc's waitcnt insertion treats a pending LDS DMA as a write to
-// ALL of LDS and puts s_waitcnt vmcnt(0) in front of every ds_read it can see - which would drain the ring each step.  The waits
-// (vmcnt counted by hand for the DMAs, lgkmcnt(0) for these reads) are placed explicitly.
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lds_rd(unsigned addr) { float v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); return v; }
-template <int O> __device__ __forceinline__ float lds_rd_o(unsigned addr) { float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(O)); return v; }
-__device__ __forceinline__ f32x4v lds_rd128(unsigned addr) { f32x4v v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); return v; }
+template <int O> __device__ __forceinline__ f32x4v lds_rd128(unsigned addr) { f32x4v v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(O)); return v; }
+template <int O> __device__ __forceinline__ u32x4 lds_rdq(unsigned addr) { u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(O)); return v; }
+template <int O> __device__ __forceinline__ void lds_w16(unsigned addr, unsigned v) { asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(O) : "memory"); }
+template <int O> __device__ __forceinline__ void lds_w16hi(unsigned addr, unsigned v) { asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(O) : "memory"); }
 __device__ __forceinline__ void lds_umax(unsigned addr, unsigned v) { asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-// s_waitcnt lgkmcnt(0), tied to the registers the preceding reads fill (so that no use can be scheduled above it)
-__device__ __forceinline__ void wait_lgkm8(float (&x)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
-}
-__device__ __forceinline__ void tie8(float (&x)[8]) {
-    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
-}
-
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm_n(int n) {            // n in [0, 4], wave-uniform
     if (n >= 4) wait_vm<4>(); else if (n == 3) wait_vm<3>(); else if (n == 2) wait_vm<2>(); else if (n == 1) wait_vm<1>(); else wait_vm<0>();
@@ -91,6 +88,18 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
     return max(max(a, b), max(c, d));
 }
 
+// the four values of a unit (rows 4 rg .. + 3 of one pixel), scaled and split, into the hi / lo planes of one tile:
+// `pa` = LDS byte address of (row 4 rg, this pixel) in the tile's hi plane
+__device__ __forceinline__ void split_store4(unsigned pa, const float (&v)[4], float s) {
+    const f16x2 h01 = {(_Float16)(v[0] * s), (_Float16)(v[1] * s)}, h23 = {(_Float16)(v[2] * s), (_Float16)(v[3] * s)};
+    const f16x2 l01 = {(_Float16)__builtin_fmaf(v[0], s, -(float)h01.x), (_Float16)__builtin_fmaf(v[1], s, -(float)h01.y)};
+    const f16x2 l23 = {(_Float16)__builtin_fmaf(v[2], s, -(float)h23.x), (_Float16)__builtin_fmaf(v[3], s, -(float)h23.y)};
+    const unsigned a = __builtin_bit_cast(unsigned, h01), b = __builtin_bit_cast(unsigned, h23);
+    const unsigned c = __builtin_bit_cast(unsigned, l01), d = __builtin_bit_cast(unsigned, l23);
+    lds_w16<0>(pa, a); lds_w16hi<32>(pa, a); lds_w16<64>(pa, b); lds_w16hi<96>(pa, b);                       // rows are 32 bytes apart
+    lds_w16<4096>(pa, c); lds_w16hi<4096 + 32>(pa, c); lds_w16<4096 + 64>(pa, d); lds_w16hi<4096 + 96>(pa, d);
+}
+
 template <int K>
 __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -100,17 +109,20 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float
     const int i = lane & 31, hh = lane >> 5;
     const int wr = w >> 1, wc = w & 1;
     const int rgz = A.z_rows >> 2;                           // row-groups of the latent
-    const int zunits = rgz * 16;
     constexpr int stage_bytes = Lay<K>::units * 16;
-    // DMA wave instructions per stage: the 128-row streams whole, the latent's (zunits + 63) / 64, (K == 1) one for the steps
-    const int n_z = (zunits + 63) >> 6;
-    constexpr int q_z0 = Lay<K>::oZ >> 6;                    // first instruction of the latent
-    auto instr_live = [&](int qi) { return qi < q_z0 + n_z || (K == 1 && qi == (Lay<K>::oS >> 6)); };
-    int my_instr = 0;                                        // ... issued by this wave (wave-uniform, 2..4)
+    constexpr int q_z0 = Lay<K>::oZ >> 6;                    // first DMA instruction of the latent
+    const int n_z = (rgz * 16 + 63) >> 6;                    // ... and how many it takes
+    constexpr int n_slots = Lay<K>::units >> 6;
+    auto instr_live = [&](int qi) { return qi < n_slots && (qi < q_z0 + n_z || (K == 1 && qi == (Lay<K>::oS >> 6))); };
+    int my_instr = 0;                                        // DMA instructions this wave issues per stage (wave-uniform, 2..4)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) my_instr += (wall + kWaves * m < (Lay<K>::units >> 6) && instr_live(wall + kWaves * m)) ? 1 : 0;
-    unsigned* mx = reinterpret_cast<unsigned*>(lds + kStages * stage_bytes);      // running maxima: dp, dq, h, z (bit patterns)
-    float* tab = reinterpret_cast<float*>(lds + kStages * stage_bytes + 32);      // K == 1: SIREN-0 weight / bias
+    for (int m = 0; m < 4; ++m) my_instr += instr_live(wall + kWaves * m) ? 1 : 0;
+
+    const unsigned l0 = lds_addr(lds);
+    const unsigned planes = l0 + kStages * stage_bytes;
+    const unsigned mx_a = planes + kPlanes;                  // running maxima: dp, dq, h, z (bit patterns)
+    unsigned* mx = reinterpret_cast<unsigned*>(lds + kStages * stage_bytes + kPlanes);
+    float* tab = reinterpret_cast<float*>(lds + kStages * stage_bytes + kPlanes + 32);      // K == 1: SIREN-0 weight / bias
 
     const int64_t s0 = (int64_t)blockIdx.x * tiles_per_chunk * 2;                  // half tiles of this chunk
     const int64_t s1 = min(ntiles * 2, s0 + (int64_t)tiles_per_chunk * 2);
@@ -119,25 +131,36 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float
 
     if (tid < 8) mx[tid] = __float_as_uint(kTinyMax);
     if (K == 1 && tid < NVP_H) { tab[tid] = A.sir0_wp[tid]; tab[NVP_H + tid] = A.sir0_bp[tid]; }
+    // the latent's rows past its end (and whatever an absent row-group would have brought) must read as zero in its planes
+    for (int e = tid; e < kPlaneTile / 4; e += kThreads) reinterpret_cast<unsigned*>(lds + kStages * stage_bytes + 4 * kPlaneTile)[e] = 0u;
+    __syncthreads();                                         // plain LDS traffic: before any DMA is in flight
 
-    // ---- DMA of half tile s0 + step into stage step % kStages.  Lane l of instruction qi fills unit qi * 64 + l: row-group
-    //      rg = 4 (qi & 7) + (l >> 4) of its stream, slot l & 15, i.e. source pixel (slot - 2 rg) & 15 (the bank rotation).
-    //      A wave's instructions qi = wave + 12 m all have the wave's parity, so 2 rg = 8 (qi & 7) + 2 (l >> 4) gives every one
-    //      of them the SAME per-lane source offset: one register; the stream / tile / row-group block is a scalar base.
+    // ---- this thread's units: unit (qi, lane) = row-group 4 (qi & 7) + (lane >> 4) of stream qi >> 3, pixel lane & 15
+    const int rgl = lane >> 4, px = lane & 15;
+    // K == 1: SIREN-0 weight / bias of the four rows of this thread's h unit (qi = wall + 12 is an h instruction for waves 4-11)
+    float w0r[4] = {0.f, 0.f, 0.f, 0.f}, c0r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (K == 1 && wall >= 4) {
+        const int row = 4 * (4 * ((wall + kWaves) & 7) + rgl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { w0r[e] = tab[row + e]; c0r[e] = tab[NVP_H + row + e]; }
+    }
+    float bacc[2][4];                                        // row sums of this thread's dp / dq units (m = 0: all waves; m = 1: waves 0-3)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bacc[m][e] = 0.f;
+
+    // ---- DMA of half tile s0 + step into stage step % kStages
     auto issue = [&](int step) {
-        // (recomputed per step behind an opaque zero: as a loop invariant it only gets spilled, and a scratch reload waits on vmcnt)
-        unsigned zero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-        const unsigned ln = (unsigned)lane + zero;
-        const unsigned lane_src = (ln >> 4) * 512u + (((ln & 15u) - 8u * (unsigned)(wall & 1) - 2u * (ln >> 4)) & 15u) * 16u;
         const int64_t ht = s0 + step;
         const int64_t tile = ht >> 1;
         const int half = (int)(ht & 1);
-        const unsigned stage = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr(lds) + (unsigned)(step % kStages) * stage_bytes));
+        const unsigned stage = (unsigned)__builtin_amdgcn_readfirstlane((int)(l0 + (unsigned)(step % kStages) * stage_bytes));
+        const unsigned lane_src = (unsigned)(rgl * 512 + px * 16);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int qi = wall + kWaves * m;                 // wave-uniform
-            if (qi >= (Lay<K>::units >> 6) || !instr_live(qi)) continue;
+            if (!instr_live(qi)) continue;
             if (K == 1 && qi == (Lay<K>::oS >> 6)) {          // the 16 temporal steps: 4 lanes
                 const unsigned e = (unsigned)tile * 32u + 16u * (unsigned)half + 4u * (unsigned)lane;      // (n < 2^31) n % 4 == 0: a lane's four steps are inside the batch or all beyond it
                 const unsigned lo = e + 4u <= (unsigned)n ? e * 4u : 0u;          // beyond the batch: any finite value will do (those pixels' dY are 0)
@@ -150,103 +173,99 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float
             const int rg0 = 4 * (qi & 7);                     // first row-group of this instruction
             const int64_t tbytes = lat ? (int64_t)rgz * 512 : 16384;
             const char* ub = reinterpret_cast<const char*>(base) + tile * tbytes + rg0 * 512 + half * 256;      // uniform
-            if (!lat || rg0 + (lane >> 4) < rgz) glds16(ub, lane_src, stage + (unsigned)(qi * 1024));
+            if (!lat || rg0 + rgl < rgz) glds16(ub, lane_src, stage + (unsigned)(qi * 1024));
         }
     };
 
-    // ---- per-lane fragment addressing (bytes inside a stage): row i of a 32-row tile, pixels 8 hh .. + 7.  ONE per-lane table:
-    //      a tile's first row-group is a multiple of 8, so the rotation (8 hh + 2 rg) & 15 only depends on the lane; the tile
-    //      (operand stream, 32-row block) is a wave-uniform byte offset.  The latent's region is a full 32 row-groups: the rows
-    //      past its end hold stale LDS contents, which only reach output columns >= d (never stored).
-    const int uA = job == 2 ? Lay<K>::oA2 : Lay<K>::oA1;
-    const int uB = job == 1 ? Lay<K>::oZ : Lay<K>::oH;
+    // ---- MFMA-phase addressing: row i of a 32-row block, the 8 pixels of lane half hh = 16 bytes of a plane row
+    const int tA = job == 2 ? 1 : 0, tB = job == 0 ? 2 : (job == 1 ? 4 : 3);
     const int slotA = job == 2 ? 1 : 0, slotB = job == 1 ? 3 : 2;
-    const unsigned baseA = (unsigned)(uA * 16 + wr * 4096), baseB = (unsigned)(uB * 16 + wc * 4096);      // + 2048 for the second 32-row block
-    // adA[k] / adB[k]: LDS byte address of pixel 8 hh + k of row i of this wave's first A / B 32-row block IN THE CURRENT STAGE
-    // (second block: + 2048; q behind h: + 8192 - immediates).  Advanced by one stage per step (16 adds) instead of rebuilt
-    // for each of the 40 reads: the loop is VALU-bound.
-    unsigned adA[8], adB[8];
-    {
-        const unsigned off_row = (unsigned)((i >> 2) * 256 + 4 * (i & 3));
-        const unsigned off_c = (unsigned)((8 * hh + 2 * (i >> 2)) & 15);
-        const unsigned l0 = lds_addr(lds);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned o = off_row + (((off_c + k) & 15u) << 4);
-            adA[k] = l0 + baseA + o;
-            adB[k] = l0 + baseB + o;
-        }
-    }
-    float w0r[2] = {0.f, 0.f}, c0r[2] = {0.f, 0.f};          // K == 1, job 2: SIREN-0 weight / bias of this lane's two x rows
+    const unsigned adA = planes + (unsigned)(tA * kPlaneTile + (64 * wr + i) * 32 + 16 * hh);      // + 1024 for the second 32-row block, + 4096 for lo
+    const unsigned adB = planes + (unsigned)(tB * kPlaneTile + (64 * wc + i) * 32 + 16 * hh);
 
     f32x16 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[r][c] = nvp_zero16();
-    float bsum0 = 0.f, bsum1 = 0.f;
-    const bool want_bias = job != 1 && wc == 0;
     unsigned run[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) run[u] = __float_as_uint(kTinyMax);
-    PxScale qa = px_scale(kTinyMax), qb = qa;
-    float curS = qa.s * qb.s, curU = qa.u * qb.u;
+    float curS, curU;
+    { const PxScale q0 = px_scale(kTinyMax); curS = q0.s * q0.s; curU = q0.u * q0.u; }
 
-    __syncthreads();                                         // mx, tab (plain loads: before any DMA is in flight)
-    if (K == 1 && job == 2) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { w0r[c] = tab[64 * wc + 32 * c + i]; c0r[c] = tab[NVP_H + 64 * wc + 32 * c + i]; }
-    }
     if (nsteps > 0) issue(0);
-    if (nsteps > 1) issue(1);
-
-    const unsigned lds0 = lds_addr(lds);
-    const unsigned mx_a = lds0 + kStages * stage_bytes;
     for (int s = 0; s < nsteps; ++s) {
-        const unsigned stage = lds0 + (unsigned)(s % kStages) * stage_bytes;
-        // stage s has landed (this wave's share): the DMAs of stage s + 1 may stay in flight
-        wait_vm_n(s + 1 < nsteps ? my_instr : 0);
-        __builtin_amdgcn_s_barrier();                        // everyone's share landed; everyone is past the MFMAs of step s - 1
-        if (s + 2 < nsteps) issue(s + 2);                    // into the stage step s - 1 used
-#ifndef NVP_GL_ABL
-#define NVP_GL_ABL 0        // ablation builds only (timing, wrong results): 1 = no tile maxima / second barrier; 2 = also no fragment reads, splits, MFMAs
-#endif
-#if NVP_SPLIT_H2 && NVP_GL_ABL == 0
-        {   // tile maxima of stage s -> running maxima (ds_max_u32), only when something raises them
-            f32x4v mv[4];
+        const unsigned stage = l0 + (unsigned)(s % kStages) * stage_bytes;
+        if (s + 1 < nsteps) issue(s + 1);                    // into the other stage: its readers finished in step s - 1 (barrier C below)
+        wait_vm_n(s + 1 < nsteps ? my_instr : 0);            // this wave's share of stage s has landed
+        __builtin_amdgcn_s_barrier();                        // A: everyone's share landed; everyone is past the MFMAs of step s - 1
+#if NVP_GL_ABL == 0
+        // ---- stage: own units -> registers, tile maxima
+        f32x4v val[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int qi = wall + kWaves * m;                 // the units this wave's own DMA instructions brought
-                const bool on = qi < q_z0 + n_z;                  // (not the steps)
-                const int u = qi * 64 + lane;
-                const bool live = on && (qi < q_z0 || u < Lay<K>::oZ + zunits);
-                mv[m] = lds_rd128(stage + (live ? u : 0) * 16);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]));
+        for (int m = 0; m < 4; ++m) val[m] = lds_rd128<0>(stage + (unsigned)((wall + kWaves * m) * 1024 + lane * 16));      // (dead slots read in-bounds garbage)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(val[0]), "+v"(val[1]), "+v"(val[2]), "+v"(val[3]));
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int qi = wall + kWaves * m;
-                if (qi >= q_z0 + n_z) continue;
-                const int u = qi * 64 + lane;
-                const bool live = qi < q_z0 || u < Lay<K>::oZ + zunits;
-                const unsigned mm = live ? __float_as_uint(fmaxf(fmaxf(fabsf(mv[m][0]), fabsf(mv[m][1])), fmaxf(fabsf(mv[m][2]), fabsf(mv[m][3])))) : 0u;
-                const int slot = qi < 8 ? 0 : (qi < 16 ? 1 : (qi < 24 ? 2 : (qi < q_z0 ? -1 : 3)));     // q needs no scale
-                if (slot >= 0 && __any(mm > run[slot])) { const unsigned wm = wave_umax(mm); if (lane == 0) lds_umax(mx_a + 4 * slot, wm); }
-            }
+        for (int m = 0; m < 4; ++m) {
+            const int qi = wall + kWaves * m;
+            if (qi >= q_z0 + n_z) continue;                   // steps / dead slots
+            const int slot = qi < 8 ? 0 : (qi < 16 ? 1 : (qi < 24 ? 2 : (qi < q_z0 ? -1 : 3)));     // q needs no scale
+            if (slot < 0) continue;
+            const bool live = qi < q_z0 || 4 * (qi & 7) + rgl < rgz;
+            const unsigned mm = live ? __float_as_uint(fmaxf(fmaxf(fabsf(val[m][0]), fabsf(val[m][1])), fmaxf(fabsf(val[m][2]), fabsf(val[m][3])))) : 0u;
+            if (__any(mm > run[slot])) { const unsigned wm = wave_umax(mm); if (lane == 0) lds_umax(mx_a + 4 * slot, wm); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                        // B: the running maxima include stage s
         {
-            float r4[8];
+            float r4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) r4[u] = lds_rd(mx_a + 4 * u);
-#pragma unroll
-            for (int u = 4; u < 8; ++u) r4[u] = 0.f;
-            wait_lgkm8(r4);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]));
 #pragma unroll
             for (int u = 0; u < 4; ++u) run[u] = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r4[u]));
         }
-        qa = px_scale(__uint_as_float(run[slotA])); qb = px_scale(__uint_as_float(run[slotB]));
+        // ---- stage: split own units into the planes (x from h; bias sums from dp / dq)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int qi = wall + kWaves * m;
+            if (qi >= q_z0 + n_z) continue;
+            const int sid = qi >> 3;
+            const bool lat = qi >= q_z0;
+            if (!lat && K == 2 && sid == 3) continue;         // q: consumed by the owners of the h units
+            const int rg = 4 * (qi & 7) + rgl;
+            const float v[4] = {val[m][0], val[m][1], val[m][2], val[m][3]};
+            const int tile_i = lat ? 4 : sid;                 // dp 0, dq 1, h 2, z 4 (x 3 below)
+            const unsigned pa = planes + (unsigned)(tile_i * kPlaneTile + rg * 128 + px * 2);
+            const float sc = px_scale(__uint_as_float(run[lat ? 3 : sid])).s;
+            if (!lat || rg < rgz) split_store4(pa, v, sc);
+            if (!lat && sid < 2 && m < 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bacc[m][e] += v[e];
+            }
+            if (!lat && sid == 2) {                           // x_{k-1} = sin(.) * h_{k-1}            (modulation.py:88-90)
+                float x[4];
+                if (K == 2) {
+                    f32x4v qv = lds_rd128<(Lay<K>::oQ - Lay<K>::oH) * 16>(stage + (unsigned)(qi * 1024 + lane * 16));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qv));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = nvp_sin(qv[e]) * v[e];
+                } else {
+                    float sp = lds_rd(stage + (unsigned)(Lay<K>::oS * 16 + px * 4));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sp));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = nvp_sin(30.0f * __fmaf_rn(sp, w0r[e], c0r[e])) * v[e];
+                }
+                split_store4(pa + kPlaneTile, x, sc);          // the x tile follows the h tile; same scale (|x| <= |h|)
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // C: the planes hold step s; raw stage s is free
+#endif
+#if NVP_GL_ABL < 2
+        // ---- MFMA phase
+        const PxScale qa = px_scale(__uint_as_float(run[slotA])), qb = px_scale(__uint_as_float(run[slotB]));
         {
             const float S = qa.s * qb.s;
             if (S != curS) {                                 // wave-uniform: a tile raised a running maximum
@@ -258,75 +277,18 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float
                 curS = S; curU = qa.u * qb.u;
             }
         }
+        BOp pb[2], pa2[2];
+        pb[0].p[0] = lds_rdq<0>(adB); pb[0].p[1] = lds_rdq<4096>(adB);
+        pb[1].p[0] = lds_rdq<1024>(adB); pb[1].p[1] = lds_rdq<4096 + 1024>(adB);
+        pa2[0].p[0] = lds_rdq<0>(adA); pa2[0].p[1] = lds_rdq<4096>(adA);
+        pa2[1].p[0] = lds_rdq<1024>(adA); pa2[1].p[1] = lds_rdq<4096 + 1024>(adA);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pb[0].p[0]), "+v"(pb[0].p[1]), "+v"(pb[1].p[0]), "+v"(pb[1].p[1]),
+                     "+v"(pa2[0].p[0]), "+v"(pa2[0].p[1]), "+v"(pa2[1].p[0]), "+v"(pa2[1].p[1]));
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mac_parts(acc[r2][c], pa2[r2].p, pb[c]);
 #endif
-#if NVP_GL_ABL < 2
-        // ---- B fragments (two 32-column tiles), one at a time (registers): read, wait, (rebuild x,) split
-        BOp pb[2];
-        {
-            float sv[8];
-            if (K == 1 && job == 2) {
-                f32x4v sa = lds_rd128(stage + Lay<K>::oS * 16 + 32 * hh), sb = lds_rd128(stage + Lay<K>::oS * 16 + 32 * hh + 16);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sa), "+v"(sb));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { sv[k] = sa[k]; sv[4 + k] = sb[k]; }
-            }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                float xb[8], xs[8];
-                if (job == 2) {                              // the sine factor of x_{k-1} = sin(.) * h_{k-1} first   (modulation.py:88-90)
-                    if (K == 2) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) xs[k] = c == 0 ? lds_rd_o<(Lay<K>::oQ - Lay<K>::oH) * 16>(adB[k]) : lds_rd_o<(Lay<K>::oQ - Lay<K>::oH) * 16 + 2048>(adB[k]);
-                        wait_lgkm8(xs);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            xs[k] = nvp_sin(xs[k]);
-                            if (k & 1) __builtin_amdgcn_sched_barrier(0);      // two sines at a time: their temporaries must not pile up on top of the accumulators
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            xs[k] = nvp_sin(30.0f * __fmaf_rn(sv[k], w0r[c], c0r[c]));
-                            if (k & 1) __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xb[k] = c == 0 ? lds_rd_o<0>(adB[k]) : lds_rd_o<2048>(adB[k]);
-                wait_lgkm8(xb);
-                if (job == 2) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) xb[k] = xs[k] * xb[k];
-                }
-                split8(xb, qb.s, pb[c]);
-            }
-        }
-        // ---- A fragments (two 32-row tiles) and the products
-        {
-            float xa[2][8];
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xa[r2][k] = r2 == 0 ? lds_rd_o<0>(adA[k]) : lds_rd_o<2048>(adA[k]);
-            wait_lgkm8(xa[0]); tie8(xa[1]);
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2) {
-                if (want_bias) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { if (r2 == 0) bsum0 += xa[r2][k]; else bsum1 += xa[r2][k]; }
-                }
-                BOp pa;
-                split8(xa[r2], qa.s, pa);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) mac_parts(acc[r2][c], pa.p, pb[c]);
-            }
-        }
-#endif
-        {   // next stage
-            const unsigned d = (s % kStages) == kStages - 1 ? (unsigned)(-(kStages - 1) * stage_bytes) : (unsigned)stage_bytes;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { adA[k] += d; adB[k] += d; }
-        }
     }
 
     // ---- store (plain global stores: no DMA is in flight any more)
@@ -334,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float
         const int ncols = job == 1 ? A.d : NVP_H;
         const int64_t woff = job == 0 ? A.w_h : (job == 1 ? A.w_z : A.w_x);
         const int ld = job == 2 ? NVP_H : A.ld_mod;
-        const float un = (NVP_DW_B3 && NVP_SPLIT_H2) ? curU : 1.0f;
+        const float un = curU;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int col = 64 * wc + 32 * c + i;
@@ -348,13 +310,22 @@ __global__ __launch_bounds__(kThreads, 1) void mlp_dw_glds_kernel(GArgs A, float
                     }
             }
         }
-        if (want_bias) {
-            bsum0 += __shfl_xor(bsum0, 32);
-            bsum1 += __shfl_xor(bsum1, 32);
-            if (hh == 0) {
-                const int64_t boff = job == 0 ? A.b_mod : A.b_sir;
-                part[boff + 64 * wr + i] = bsum0;
-                part[boff + 64 * wr + 32 + i] = bsum1;
+        // bias gradients: a row's sum over the chunk = the sum over the 16 lanes (pixels) that staged its row-group
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int qi = wall + kWaves * m;
+            if (qi >= 16) continue;                           // not a dp / dq instruction
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bacc[m][e];
+                v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+                bacc[m][e] = v;
+            }
+            if (px == 0) {
+                const int row = 4 * (4 * (qi & 7) + rgl);
+                const int64_t boff = qi < 8 ? A.b_mod : A.b_sir;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[boff + row + e] = bacc[m][e];
             }
         }
     }
@@ -378,7 +349,7 @@ int nvp_mlp_dw_glds_launch(const float* steps, const float* zt, const float* sav
         G.z = zt; G.z_rows = rows; G.d = d; G.steps = steps; G.sir0_wp = p->sir_w[0]; G.sir0_bp = p->sir_b[0];
         G.ld_mod = NVP_H + d; G.w_h = P.mod_w[k]; G.w_z = P.mod_w[k] + NVP_H; G.w_x = P.sir_w[k];
         G.b_mod = P.mod_b[k]; G.b_sir = P.sir_b[k]; G.total = P.total;
-        const size_t lds = (size_t)kStages * (k == 2 ? Lay<2>::units : Lay<1>::units) * 16 + 32 + 2 * NVP_H * sizeof(float);
+        const size_t lds = (size_t)kStages * (k == 2 ? Lay<2>::units : Lay<1>::units) * 16 + kPlanes + 32 + 2 * NVP_H * sizeof(float);
         if (lds > 160 * 1024) return NVP_ERR_UNSUPPORTED;
         if (k == 1) hipLaunchKernelGGL((mlp_dw_glds_kernel<1>), dim3(n_chunks), dim3(kThreads), lds, (hipStream_t)stream, G, partials, n, ntiles, tiles_per_chunk);
         else hipLaunchKernelGGL((mlp_dw_glds_kernel<2>), dim3(n_chunks), dim3(kThreads), lds, (hipStream_t)stream, G, partials, n, ntiles, tiles_per_chunk);
