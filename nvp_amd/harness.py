@@ -352,7 +352,7 @@ def _pink_field(ch: int, h: int, w: int, alpha: float, gen: torch.Generator, dev
     return (out - out.mean(dim=(1, 2), keepdim=True)) / out.std(dim=(1, 2), keepdim=True)
 
 
-def natural_video(T: int, H: int, W: int, device, seed: int = 0, grain: float = 1.5, alpha: float = 1.0, n_objects: int = 6) -> torch.Tensor:
+def natural_video(T: int, H: int, W: int, device, seed: int = 0, grain: float = 1.25, alpha: float = 1.15, n_objects: int = 6) -> torch.Tensor:
     """Synthetic clip with NATURAL-IMAGE STATISTICS - a stand-in for the UVG clips the reference's README table is measured
     on (README.md:92-100), which are not shipped and cannot be fetched.  NOT UVG: numbers measured on it only say how the
     encoder behaves on content with a 1/f spectrum, edges, motion and sensor noise instead of a handful of sinusoids.

@@ -3,16 +3,22 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-pmc}
+BENCH_ARGS=${BENCH_ARGS:-}            # e.g. BENCH_ARGS="--config l" bash tools/pmc.sh r03l
+PASSES=${PASSES:-"sq1 sq2 fetch write"}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|GRBM_[A-Z_]+|TCC_[A-Z_0-9]+|FETCH_SIZE|WRITE_SIZE|MfmaUtil|VALUBusy|OccupancyPercent)\b" | sort -u > gpurun_out/${TAG}_counters.txt
 grep -cE "." gpurun_out/${TAG}_counters.txt
 run() { # name counters...
   local name=$1; shift
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/${TAG}_$name" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/${TAG}_$name.log" 2>&1 ); echo "$name rc=$?"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/${TAG}_$name" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-isolate $BENCH_ARGS > "$OLDPWD/gpurun_out/${TAG}_$name.log" 2>&1 ); echo "$name rc=$?"
 }
-run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY
-run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE
-run fetch FETCH_SIZE
-run write WRITE_SIZE
+for P in $PASSES; do
+  case $P in
+    sq1) run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY;;
+    sq2) run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE;;
+    fetch) run fetch FETCH_SIZE;;
+    write) run write WRITE_SIZE;;
+  esac
+done
 ls gpurun_out/${TAG}_sq1 | head

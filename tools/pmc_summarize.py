@@ -7,8 +7,11 @@ and come from separate --pmc passes; on gfx950 FETCH_SIZE reports exactly half o
 WRITE_SIZE is used as reported (uncalibrated in the guide)."""
 import collections, csv, json, os, sys
 tag = sys.argv[1]
+config = sys.argv[2] if len(sys.argv) > 2 else "s"           # bench.py --config this pass was collected with
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = {"mlp_fwd_kernel": "nvp_mlp_fwd", "mlp_fwd_b3_kernel": "nvp_mlp_fwd", "mlp_fwd_b3r_kernel": "nvp_mlp_fwd", "mlp_bwd_b3_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_b3r_kernel": "nvp_mlp_bwd_dx", "encode_fwd_lds_kernel": "nvp_encode_fwd", "mlp_bwd_dx_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_kernel": "nvp_mlp_bwd_dx",
+KEYS = {"mlp_fwd_kernel": "nvp_mlp_fwd", "mlp_fwd_b3_kernel<true, 2>": "nvp_encode_mlp_fwd", "mlp_fwd_b3_kernel<true, 4>": "nvp_encode_mlp_fwd",
+        "mlp_fwd_b3_kernel<false, 2>": "nvp_encode_mlp_fwd", "mlp_fwd_b3_kernel": "nvp_mlp_fwd", "mlp_dw_group_kernel": "nvp_mlp_bwd_dw", "mlp_dw_glds_kernel": "nvp_mlp_bwd_dw",
+        "csort_hist_kernel": "nvp_encode_bwd", "csort_scan_kernel": "nvp_encode_bwd", "csort_tilesum_kernel": "nvp_encode_bwd", "csort_scatter_kernel": "nvp_encode_bwd", "mlp_fwd_b3r_kernel": "nvp_mlp_fwd", "mlp_bwd_b3_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_b3r_kernel": "nvp_mlp_bwd_dx", "encode_fwd_lds_kernel": "nvp_encode_fwd", "mlp_bwd_dx_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_kernel": "nvp_mlp_bwd_dx",
         "mlp_dw_kernel": "nvp_mlp_bwd_dw", "dw_reduce_kernel": "nvp_mlp_bwd_dw", "dw_records_kernel": "nvp_mlp_bwd_dw", "encode_fwd_kernel": "nvp_encode_fwd",
         "band_kernel": "nvp_encode_bwd", "permute_kernel": "nvp_encode_bwd", "sparse_band_kernel": "nvp_encode_bwd",
         "sparse_keys_kernel": "nvp_encode_bwd", "slab_reduce_kernel": "nvp_encode_bwd", "rowstart_kernel": "nvp_encode_bwd", "keys_kernel": "nvp_encode_bwd"}
@@ -47,5 +50,10 @@ for p in ("sq1", "sq2"):
         vals = {c: sum(v) / len(v) for c, v in d[k].items()}
         out.append(f"{k:22s} [{p}] " + " ".join(f"{c}={v:.4g}" for c, v in sorted(vals.items())))
 open(os.path.join(root, "profiles", f"{tag}_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
-json.dump({k: round(v) for k, v in stage.items()}, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+tpath = os.path.join(root, "profiles", "pmc_traffic.json")
+allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
+if "nvp_mlp_fwd" in allt or "nvp_mlp_bwd_dw" in allt:        # round-2 flat layout (configs[1]) -> per-config layout
+    allt = {"s": allt}
+allt[config] = {k: round(v) for k, v in stage.items() if k}
+json.dump(allt, open(tpath, "w"), indent=1)
 print("\n".join(out[:12])); print(dict(stage))
