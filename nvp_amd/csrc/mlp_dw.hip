@@ -714,13 +714,17 @@ __global__ __launch_bounds__(256) void dw_records_kernel(const float* __restrict
 struct ReduceArgs {
     float* dst[14];
     int64_t off[15];
+    int nch[14];          // pixel chunks whose partials hold this tensor (the plain and the transform jobs may be chunked differently)
 };
 
 // Element idx of every chunk's partial, summed in chunk order (fixed order -> deterministic).
 // 16 independent loads are kept in flight per thread; the additions stay sequential.
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partials, ReduceArgs R, int n_chunks, int64_t total) {
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partials, ReduceArgs R, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
+    int tt = 0;
+    while (idx >= R.off[tt + 1]) ++tt;
+    const int n_chunks = R.nch[tt];
     const float* src = partials + idx;
     float s = 0.f;
     int c = 0;
@@ -732,9 +736,7 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
         for (int u = 0; u < 16; ++u) s += v[u];
     }
     for (; c < n_chunks; ++c) s += src[(int64_t)c * total];
-    int t = 0;
-    while (idx >= R.off[t + 1]) ++t;
-    R.dst[t][idx - R.off[t]] = s;
+    R.dst[tt][idx - R.off[tt]] = s;
 }
 
 }  // namespace
@@ -816,6 +818,12 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     P0.n_jobs = n0; P2.n_jobs = n2; P1.n_jobs = n1;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
+    // The transform jobs (SIREN layers 1, 2: two workgroups per CU, two jobs) fill the chip with 256 chunks exactly; the five plain
+    // jobs (three workgroups per CU) want 5 n_chunks close below a multiple of 768 (304: 1520 of 1536 slots in two rounds, instead
+    // of 1280 = one round and two thirds).  NVP_DW_CHUNKS_XF (environment, read once) caps the transform jobs' chunk count.
+    static const int xf_cap = [] { const char* e = getenv("NVP_DW_CHUNKS_XF"); return e ? atoi(e) : 256; }();
+    const int nch1 = (xf_cap > 0 && xf_cap < n_chunks) ? xf_cap : n_chunks;
+    const int tiles_per_chunk1 = (int)((ntiles + nch1 - 1) / nch1);
     if (glds) {
         // dp_0 x z as the one remaining plain job, then the two DMA-fed grouped launches
         DwArgs Q0 = P0;
@@ -857,7 +865,9 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     NVP_LAUNCH_CHECK();
     if (n2) hipLaunchKernelGGL((mlp_dw_kernel<0, 2>), dim3(n_chunks * n2), dim3(512), lds_bytes2, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
-    if (n1) hipLaunchKernelGGL((mlp_dw_kernel<1, 1>), dim3(n_chunks * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles, tiles_per_chunk, n_chunks);
+    const bool xf_own = n1 > 0 && !one_launch;       // (one launch: the plain jobs ride in P1 and share its chunking)
+    if (n1) hipLaunchKernelGGL((mlp_dw_kernel<1, 1>), dim3((xf_own ? nch1 : n_chunks) * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles,
+                               xf_own ? tiles_per_chunk1 : tiles_per_chunk, xf_own ? nch1 : n_chunks);
     NVP_LAUNCH_CHECK();
     hipLaunchKernelGGL(dw_records_kernel, dim3(n_chunks, (kRecFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy + 3 * act, partials,
                        ntiles, tiles_per_chunk, P.total, P.last_w, P.last_b, P.sir_w[0], P.sir_b[0]);
@@ -870,7 +880,9 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     R.dst[t] = g->last_w; R.off[t++] = P.last_w;
     R.dst[t] = g->last_b; R.off[t++] = P.last_b;
     R.off[t] = P.total;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, R, n_chunks, P.total);
+    for (int u = 0; u < 14; ++u) R.nch[u] = n_chunks;
+    if (xf_own) { R.nch[8] = R.nch[9] = R.nch[10] = R.nch[11] = nch1; }      // sir_w[1], sir_b[1], sir_w[2], sir_b[2]: the transform jobs' tensors
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((unsigned)((P.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, R, P.total);
     NVP_LAUNCH_CHECK();
     return 0;
 }
