@@ -1,5 +1,6 @@
-// Backward dX chain + latent gradient + per-tile records (mlp_bwd_b3.hip, latent <= 128 rows, fused latent gradient) with
-// WORKGROUP-SHARED weight operands: the A operands of every transposed GEMM come from a two-slot LDS ring that the four
+// Backward dX chain + latent gradient + per-tile records (mlp_bwd_b3.hip) with WORKGROUP-SHARED weight operands - latents of
+// <= 128 rows: latent gradient fused (mlp_bwd_b3r_kernel<true>); 129-256 rows (nvp_l): mlp_bwd_b3r_kernel<false> followed by
+// mlp_bwd_dz_b3r_kernel<8>, whose eight-tile weight steps go through a full-step ring (ZRing below): the A operands of every transposed GEMM come from a two-slot LDS ring that the four
 // waves of the workgroup fill cooperatively (mlp_b3_ring.h, half-step ring: the per-wave transpose / parking tiles leave
 // 12 KiB per workgroup with two workgroups per CU) instead of 8 / 12 KiB of per-wave global loads per k-step.  Arithmetic,
 // streams, records and the latent gradient are those of mlp_bwd_b3_kernel<true>, bit for bit (same MFMA order per
@@ -21,6 +22,10 @@ __device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ 
     load_ptm16(v, tile_base, T, lane);
 }
 
+// FUSE_DZ (latent <= 128 rows): the weights come from the consumption-ordered copy (z / mod-h streams interleaved per k-step);
+// otherwise every chain walks ONE stream, whose ordinary packed layout already is its consumption order (a k-step's four tiles =
+// two consecutive half-steps), so the ring reads the plain streams: half-step 16 s of stream s.
+template <bool FUSE_DZ>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
                                                                     const float* __restrict__ saved, nvp_mlp_params p,
                                                                     const unsigned* __restrict__ packed,
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
     float* xl = xl_all + wv * kRecTileFloats;
     HRing R;
     R.lds = reinterpret_cast<u32x4*>(xl_all + kWaves * kRecTileFloats);
-    R.g = reinterpret_cast<const u32x4*>(packed + nvp_bwd_b3_ring_off(4));
+    R.g = reinterpret_cast<const u32x4*>(FUSE_DZ ? packed + nvp_bwd_b3_ring_off(4) : packed);
     R.chain_end = 0; R.wv = wv; R.lane = lane;
     int hs = 0;                                        // running half-step: the ring copy of the weights is in consumption order
     float* rec = dy + 3 * act + tile * (int64_t)NVP_H * 32;      // this tile's record (stream-3 slot)
@@ -142,13 +147,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
         for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
         {
             const PxScale pq = px_scale(fmaxf(px_absmax(dx), kTinyMax));
-            chain_h_b3_hring(acc, dx, pq.s, R, hs, lane, NVP_RING_MERGE_OPEN ? 48 : 16);        // streams 0 (sir2^T), 1 (sir1^T)
+            if (!FUSE_DZ) hs = 16 * (2 - k);
+            chain_h_b3_hring(acc, dx, pq.s, R, hs, lane, (FUSE_DZ && NVP_RING_MERGE_OPEN) ? 48 : 16);        // streams 0 (sir2^T), 1 (sir1^T)
             scale4(acc, pq.u * wsc[8 + 2 - k]);
         }
 #pragma unroll
         for (int T = 0; T < 4; ++T) { dx[T] = acc[T]; nvp_pin(dx[T]); }
         const PxScale pp = px_scale(fmaxf(px_absmax(dh), kTinyMax));       // dp_k feeds the dz and the dh chain
-        if (true) {
+        if (!FUSE_DZ) {
+            // dh_{k-1} = W_k[:, :128]^T dp_k; the latent gradient is mlp_bwd_dz_b3r_kernel's
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            hs = 16 * (4 - k);
+            chain_h_b3_hring(acc, dh, pp.s, R, hs, lane, 16);          // streams 2 (mod2h^T), 3 (mod1h^T)
+            scale4(acc, pp.u * wsc[8 + 4 - k]);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { dh[T] = acc[T]; nvp_pin(dh[T]); }
+            continue;
+        } else {
             // dz += W_k[:, 128:]^T dp_k and dh_{k-1} = W_k[:, :128]^T dp_k in ONE pass over dp (one operand split per
             // k-step instead of two).  Both accumulators are live, so dx' waits in the wave's LDS tile meanwhile: the
             // parked dz accumulator is swapped out for it before the pass and back in after it.
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
         for (int T = 0; T < 4; ++T) {
             f32x16 hn;
             if (T < 3) load_act16(hn, h0, T + 1, lane);
-            if (true) {
+            if (FUSE_DZ) {
                 if (T == 0) fetch_dz(0);
                 if (T < 3) fetch_dz(T + 1);
             }
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
         }
         rec[kRecSir0W + lane] = wl; rec[kRecSir0W + 64 + lane] = wh;
         rec[kRecSir0B + lane] = cl; rec[kRecSir0B + 64 + lane] = ch;
-        if (true) {
+        if (FUSE_DZ) {
             // dz += W_0^T dp_0, then the row-major store (same layout as mlp_bwd_dz_kernel)
             NVP_LOAD_FENCE();
             const PxScale pp = px_scale(fmaxf(px_absmax(dh), kTinyMax));
@@ -285,16 +301,145 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
 }
 
 
+// ---- latent gradient of a wide latent through a full-step ring ---------------------------------------------------------
+// mlp_bwd_dz_b3_kernel<8> (mlp_bwd_b3.hip) pulls the three eight-tile z^T streams - 384 KiB per 32-pixel tile - through every
+// wave's own vector-memory path.  Here the four waves of a workgroup share them: a ring slot holds one whole k-step (ZT tiles x
+// kP parts = 16 KiB fp16 x 2), every wave moves a quarter of it (fetched into registers two k-steps ahead, written to the free
+// slot one k-step ahead), one barrier per k-step.  This kernel parks nothing in LDS, so two 16-KiB slots per workgroup fit
+// easily with two workgroups per CU.  The 24 k-steps of a tile (z2^T, z1^T, z0^T) are ONE ring sequence: no refill at the layer
+// boundaries.  Same MFMA order per accumulator as the per-wave kernel: bit-identical.
+template <int ZT>
+struct ZRing {
+    static constexpr int kPieces = ZT * kP;        // 1-KiB pieces per k-step
+    static constexpr int kMine = kPieces / 4;      // per wave
+    static constexpr int kQuads = kPieces * 64;    // u32x4 per k-step
+    u32x4* lds;                // two slots of kQuads
+    const u32x4* g;            // packed buffer
+    int wv, lane;
+    u32x4 sg[kMine];
+    // ring step s = k-step (s & 7) of stream 6 - (s >> 3): z2^T, z1^T, z0^T in the order the layers are walked
+    __device__ __forceinline__ const u32x4* src(int s) const { return g + nvp_bwd_b3_off(6 - (s >> 3), ZT) / 4 + (int64_t)(s & 7) * kQuads; }
+    __device__ __forceinline__ void fetch(int s) {
+        const u32x4* p = src(s) + (kMine * wv) * 64;
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) sg[q] = (p + q * 64)[(unsigned)lane];
+    }
+    __device__ __forceinline__ void publish(int s) {
+        u32x4* d = lds + (s & 1) * kQuads + (kMine * wv) * 64;
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) (d + q * 64)[(unsigned)lane] = sg[q];
+    }
+    __device__ __forceinline__ void open() { fetch(0); publish(0); fetch(1); end(); }
+    __device__ __forceinline__ const u32x4* begin(int s) {
+        if (s + 1 < 24) publish(s + 1);
+        if (s + 2 < 24) fetch(s + 2);
+        return lds + (s & 1) * kQuads;
+    }
+    __device__ __forceinline__ void end() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+};
+
+template <int ZT>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3r_kernel(const float* __restrict__ dy, const unsigned* __restrict__ packed,
+                                                                        float* __restrict__ dzr, NvpDzLm lm, int64_t n, int64_t ntiles, int d) {
+    static_assert((ZT * kP) % 4 == 0, "a k-step must split into four equal shares");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
+    if (tile >= ntiles) tile = ntiles - 1;             // every wave walks the ring; a surplus wave rewrites the last tile's values (identical bits)
+    nvp_stagger_start();
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    const float* dyt = dy + tile * (int64_t)NVP_H * 32;
+    const float* wsc = reinterpret_cast<const float*>(packed + nvp_bwd_b3_off(7, ZT)) + kB3ScaleOff;
+    extern __shared__ __attribute__((aligned(16))) float xl_all[];
+    ZRing<ZT> R;
+    R.lds = reinterpret_cast<u32x4*>(xl_all);
+    R.g = reinterpret_cast<const u32x4*>(packed);
+    R.wv = wv; R.lane = lane;
+    const unsigned ul = (unsigned)lane;
+    f32x16 dz[ZT];
+#pragma unroll
+    for (int T = 0; T < ZT; ++T) dz[T] = nvp_zero16();
+    f32x16 b[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + 2 * act, T, lane);
+    R.open();
+    int s = 0;
+#pragma unroll 1
+    for (int k = 2; k >= 0; --k) {
+        NVP_LOAD_FENCE();
+        const PxScale pp = px_scale(fmaxf(px_absmax(b), kTinyMax));
+        if (NVP_SPLIT_H2) {                                         // the running sum into this layer's scaled units (exact)
+            const float f = pp.s * wsc[4 + k];
+#pragma unroll
+            for (int T = 0; T < ZT; ++T) dz[T] *= f;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const u32x4* w = R.begin(s);
+            float x[8];
+            chain_in8(x, b, c);
+            BOp bo;
+            split8(x, pp.s, bo);
+            u32x4 a[2][kP];
+#pragma unroll
+            for (int q = 0; q < kP; ++q) a[0][q] = (w + q * 64)[ul];
+#pragma unroll
+            for (int T = 0; T < ZT; ++T) {
+                if (T + 1 < ZT) {
+#pragma unroll
+                    for (int q = 0; q < kP; ++q) a[(T + 1) & 1][q] = (w + ((T + 1) * kP + q) * 64)[ul];
+                }
+                NVP_CHAIN_FENCE();
+                mac_parts(dz[T], a[T & 1], bo);
+            }
+            R.end();
+            ++s;
+        }
+#ifndef NVP_ABL_DZ_NOLOAD        // ablation builds only (wrong results): what the exposed dp loads of layers 1 and 0 cost
+        if (k > 0) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) load_ptm16(b[T], dyt + (int64_t)(k - 1) * act, T, lane);
+        }
+#endif
+        if (NVP_SPLIT_H2) {
+            const float f = pp.u * wsc[8 + 4 + k];
+#pragma unroll
+            for (int T = 0; T < ZT; ++T) dz[T] *= f;
+        }
+    }
+    const int stride = nvp_dz_stride_dev(d);
+    float* o = dzr + (tile * 32 + j) * stride;
+    const int F = d / 57;
+    const int64_t px = tile * 32 + j;
+    unsigned mx = 0u, msx = 0u;
+#pragma unroll
+    for (int T = 0; T < ZT; ++T)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int base = 32 * T + 8 * g + 4 * h;
+            if (base < stride && !nvp_dz_store_lm(lm, F, base, px, n, dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3], mx, msx))
+                *reinterpret_cast<float4*>(o + base) = make_float4(dz[T][4 * g], dz[T][4 * g + 1], dz[T][4 * g + 2], dz[T][4 * g + 3]);
+        }
+    nvp_dz_lm_finish(lm, mx, msx, tile, lane);
+}
+
 }  // namespace
 
-// called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on, the latent has <= 128 rows and NVP_MLP_RING_BWD != 0
+// called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on and NVP_MLP_RING_BWD != 0
 int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* saved, const nvp_mlp_params* p,
                            const float* packed_bwd, float* dy, float* dz_rows, NvpDzLm lm, int64_t n, int32_t d, void* stream) {
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
     const size_t lds = kWaves * kRecTileFloats * sizeof(float) + 2 * kHalfQuads * sizeof(u32x4);        // 67 584 + 8 192 / 12 288 B: two workgroups per CU
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_bwd);
-    hipLaunchKernelGGL(mlp_bwd_b3r_kernel, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, lm, n, ntiles, d);
+    if (nvp_bwd_b3_zt(d) == 4) {
+        hipLaunchKernelGGL(mlp_bwd_b3r_kernel<true>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, lm, n, ntiles, d);
+    } else {
+        hipLaunchKernelGGL(mlp_bwd_b3r_kernel<false>, grid, dim3(kWaves * 64), lds, (hipStream_t)stream, drgb, steps, saved, *p, pk, dy, dz_rows, NVP_DZLM_OFF, n, ntiles, d);
+        const size_t zlds = 2 * (size_t)ZRing<8>::kQuads * sizeof(u32x4);                                 // 32 / 48 KiB
+        hipLaunchKernelGGL(mlp_bwd_dz_b3r_kernel<8>, grid, dim3(kWaves * 64), zlds, (hipStream_t)stream, dy, pk, dz_rows, lm, n, ntiles, d);
+    }
     NVP_LAUNCH_CHECK();
     return 0;
 }
