@@ -299,11 +299,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_enqueue_ms = [0.0, 0.0]        # host time to ENQUEUE one step (mean, max) in the last timed() pass: far below ms_per_step = the GPU, not Python, sets the pace
+
     def timed(state, n_steps, record=False):
         barrier()
         t0 = time.perf_counter()
+        host = []
         for _ in range(n_steps):
+            h0 = time.perf_counter()
             loss_ = one_step(state, record)
+            host.append(time.perf_counter() - h0)
+        host_enqueue_ms[:] = [round(sum(host) / max(len(host), 1) * 1e3, 3), round(max(host, default=0.0) * 1e3, 3)]
         barrier()
         dt_ = time.perf_counter() - t0
         if world > 1:
@@ -350,6 +356,7 @@ def main():
 
     functional.TIMER = functional.KernelTimer()
     dt, loss = timed(state, args.steps, record=True)
+    host_ms = list(host_enqueue_ms)
     kernels = functional.TIMER.summary()
     functional.TIMER = None
     # ---- second pass, N = 1: the same steps with every side stream OFF, so that each stage's HIP-event span is that stage alone
@@ -464,6 +471,7 @@ def main():
             "stages": stages,
             "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
             "final_loss": float(loss),
+            "host_enqueue_ms_per_step": {"mean": host_ms[0], "max": host_ms[1]},
             "isolated": iso_line,
         }
         if multi:

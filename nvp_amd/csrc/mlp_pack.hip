@@ -1,6 +1,7 @@
 // Re-lay the 14 MLP tensors out as MFMA A-operand streams (see mlp_layout.h).
 // ~0.5 MB per call, one thread per packed float; runs once per optimizer step.
 #include "mlp_layout.h"
+#include <cstdlib>
 
 namespace {
 
@@ -178,6 +179,97 @@ __global__ __launch_bounds__(256) void pack_fwd_b3_kernel(nvp_mlp_params p, unsi
     out[idx] = packed;
 }
 
+// The forward pack in ONE launch (scales + streams + tables): it sits on the critical path of every training step - the
+// forward kernel needs it and it needs the optimizer's last update - so three dependent launches (15 + 28 + 5 us) are one
+// of ~15 us.  One 1024-thread block per k-step (kB3StepU32 packed words, two per thread): the block first takes the maximum
+// over the tensor(s) its stream is cut from - redundantly with the other blocks of the stream, 45 L2-resident loads per
+// thread - and derives the stream's scale exactly as pack_b3_scales_kernel does, so the packed words are the same bits.
+__device__ __forceinline__ void b3_scale_from_max(unsigned mbits, float& sc, float& inv) {
+    const unsigned e = mbits >> 23;
+    sc = 1.0f; inv = 1.0f;
+#if NVP_SPLIT_H2
+    if (e < 255u) {
+        const unsigned ec = max(e, 87u);
+        sc = __uint_as_float((267u - ec) << 23); inv = __uint_as_float((ec - 13u) << 23);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(1024) void pack_fwd_b3_all_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
+    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
+    float* tab = reinterpret_cast<float*>(out + L.off[5]);
+    const int64_t base = (int64_t)blockIdx.x * kB3StepU32;
+    if (base >= L.off[5]) {                         // the block behind the streams: the D-register-ordered tables
+        for (int idx = threadIdx.x; idx < kB3ScaleOff; idx += 1024) {
+            const int r = idx & 15, T = (idx >> 4) & 3, h = (idx >> 6) & 1, t = idx >> 7;
+            const int row = 32 * T + 8 * (r >> 2) + 4 * h + (r & 3);
+            tab[idx] = t == 0 ? p.sir_w[0][row] : (t == 1 ? p.sir_b[0][row] : p.last_w[(t - 2) * NVP_H + row]);
+        }
+        return;
+    }
+    int seg = 0;
+    for (int k = 0; k < 5; ++k)
+        if (base >= L.off[k] && base < L.off[k] + (int64_t)L.steps[k] * kB3StepU32) seg = k;
+    const float* W; const float* b; int ld; bool has_h, has_z;
+    switch (seg) {
+        case 0: W = p.mod_w[0]; b = p.mod_b[0]; ld = d; has_h = false; has_z = true; break;
+        case 1: W = p.mod_w[1]; b = p.mod_b[1]; ld = NVP_H + d; has_h = true; has_z = true; break;
+        case 2: W = p.mod_w[2]; b = p.mod_b[2]; ld = NVP_H + d; has_h = true; has_z = true; break;
+        case 3: W = p.sir_w[1]; b = p.sir_b[1]; ld = NVP_H; has_h = true; has_z = false; break;
+        default: W = p.sir_w[2]; b = p.sir_b[2]; ld = NVP_H; has_h = true; has_z = false; break;
+    }
+    const int64_t nw = (int64_t)NVP_H * ld;
+    unsigned m = 0u;
+    for (int64_t i0 = threadIdx.x; i0 < nw; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < nw ? W[i0 + u * 1024] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = max(m, __float_as_uint(v[u]) & 0x7fffffffu);
+    }
+    if (threadIdx.x < NVP_H) m = max(m, __float_as_uint(b[threadIdx.x]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) m = max(m, red[w]);
+    float sc, inv;
+    b3_scale_from_max(m, sc, inv);
+    const int step = (int)((base - L.off[seg]) / kB3StepU32);
+    if (step == 0 && threadIdx.x == 0) { tab[kB3ScaleOff + seg] = sc; tab[kB3ScaleOff + 8 + seg] = inv; }
+#pragma unroll
+    for (int u = 0; u < kB3StepU32 / 1024; ++u) {
+        const int loc = u * 1024 + threadIdx.x;                  // word within the k-step: ((tile * kP + part) * 64 + lane) * 4 + pair
+        const int pr = loc & 3;
+        const int lane = (loc >> 2) & 63;
+        const int part = (loc >> 8) % kB3Parts;
+        const int tp = ((loc >> 8) / kB3Parts) & 3;
+        const int i = lane & 31, h = lane >> 5;
+        const int out_row = 32 * tp + i;
+        unsigned packed = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int q = 2 * pr + e;
+            float v = 0.f;
+            if (step == 0) {
+                if (h == 0 && q == 0) v = b[out_row];
+            } else {
+                const int s = step - 1;
+                if (has_h && s < 8) {
+                    v = W[(int64_t)out_row * ld + nvp_b3_chain_in(s, h, q)];
+                } else if (has_z) {
+                    const int in = 16 * (has_h ? s - 8 : s) + 8 * h + q;
+                    if (in < d) v = W[(int64_t)out_row * ld + (has_h ? NVP_H : 0) + in];
+                }
+            }
+            packed |= nvp_split_part(v, sc, part) << (16 * e);
+        }
+        out[base + loc] = packed;
+    }
+}
+
 // split backward streams (mlp_layout.h): one thread per packed u32
 __global__ __launch_bounds__(256) void pack_bwd_b3_kernel(nvp_mlp_params p, unsigned* __restrict__ out, int d) {
     const int zt = nvp_bwd_b3_zt(d);
@@ -268,6 +360,13 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (!p || !packed || d < 1) return NVP_ERR_BADARG;
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
         const int64_t nb = nvp_fwd_layout_b3(d).off[5];
+        // NVP_PACK_ONE_LAUNCH=0 (environment, read once): the three-launch version (same bits)
+        static const bool one = [] { const char* e = getenv("NVP_PACK_ONE_LAUNCH"); return !(e && e[0] == '0'); }();
+        if (one) {
+            hipLaunchKernelGGL(pack_fwd_b3_all_kernel, dim3((unsigned)(nb / kB3StepU32 + 1)), dim3(1024), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
+            NVP_LAUNCH_CHECK();
+            return 0;
+        }
         hipLaunchKernelGGL(pack_b3_scales_kernel, dim3(5), dim3(1024), 0, (hipStream_t)stream, *p, packed + nb, d, 0);
         hipLaunchKernelGGL(pack_fwd_b3_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
         hipLaunchKernelGGL(pack_b3_tables_kernel, dim3((kB3ScaleOff + 255) / 256), dim3(256), 0, (hipStream_t)stream, *p, packed + nb);

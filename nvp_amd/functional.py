@@ -397,11 +397,17 @@ class NVPFused(torch.autograd.Function):
                 t.record_stream(side)
             if pk_b is not None:
                 pk_b.record_stream(side)
-            with torch.cuda.stream(side):
+            if fused:
+                # one-launch forward: nothing can run underneath this pack (the forward kernel needs it, and it needs the optimizer's
+                # last update) - on the side stream it would only add two cross-queue hand-overs to the step boundary
                 L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(pk_f), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
-                ev = torch.cuda.Event()
-                ev.record()
-                packed_fwd = (pk_f, ev)
+                packed_fwd = (pk_f, None)
+            else:
+                with torch.cuda.stream(side):                  # two-kernel forward: underneath the gather kernel
+                    L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(pk_f), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    packed_fwd = (pk_f, ev)
         if bwd_follows:
             L.ptr(coords)
             lvs = (lv_xy, lv_yt, lv_xt)
@@ -431,7 +437,8 @@ class NVPFused(torch.autograd.Function):
             pstruct = L.mlp_params_struct(mlp)
             if packed_fwd is not None:
                 packed, ev = packed_fwd
-                torch.cuda.current_stream(dev).wait_event(ev)
+                if ev is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev)
             else:
                 packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
                 L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, L.stream_ptr()), "nvp_mlp_pack_fwd")

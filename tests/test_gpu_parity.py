@@ -1110,7 +1110,7 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     for k, env in enumerate(({"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # the defaults
                              {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1",
                               "NVP_DZ_LEVEL_MAJOR": "0"},                                                                # every alternative
-                             {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1", "NVP_SCATTER_PRESORT": "0"},            # launch / stream experiments
+                             {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1", "NVP_SCATTER_PRESORT": "0", "NVP_PACK_ONE_LAUNCH": "0"},            # launch / stream experiments
                              {"NVP_FUSED_FWD": "0"})):                                                                      # the seven per-job dW workgroups instead of the grouped ones
         out = str(tmp_path / f"v{k}.npz")
         subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300,
