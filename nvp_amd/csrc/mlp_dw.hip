@@ -32,7 +32,13 @@
 #define NVP_DW_B3 1           // dW GEMMs on bf16 x 3 split MFMA (fragments split after the LDS read): 2.72 -> 2.21 ms
 #endif
 
+#ifndef NVP_DW_PAIR_DEFAULT
+#define NVP_DW_PAIR_DEFAULT 0
+#endif
+
 namespace {
+
+inline bool getenv_on(const char* name) { const char* e = getenv(name); return e && e[0] == '1'; }
 
 struct DwJob {
     const float* a;       // dY stream (PTM4, 128 rows)
@@ -424,6 +430,203 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
     }
 }
 
+// ---- paired jobs: dp_k x [B | BB] in ONE 256-thread workgroup ---------------------------------------------------------------------
+// Two jobs that share their A operand (dp_k x h_{k-1} and dp_k x z; for wide latents also dp_0 x z[0:128] and dp_0 x z[128:]) as
+// one workgroup that stages the dp_k tile ONCE: wave (wr, wc) owns the 64 x 64 sub-block (wr, wc) of BOTH outputs (128
+// accumulator registers; two workgroups per CU instead of three), the A fragments are split once for both.  Unlike the merged
+// jobs above (512 threads, 108 KiB, one workgroup per CU) the workgroup keeps the per-job kernel's shape: single-buffered tiles
+// (54 KiB), three tiles = 48 KiB of loads in flight per workgroup, 96 KiB per CU - the same as three per-job workgroups.  Same
+// fragments, same MFMA order per accumulator, same running block scales: BIT-identical to the two separate jobs.
+struct PairStage { float4 a[4], b[4], bb[4]; };
+
+__device__ __forceinline__ void pair_load(PairStage& s, const DwJob& J, int64_t t, int tid) {
+    const float4* A4 = reinterpret_cast<const float4*>(J.a) + t * 1024;
+    const float4* B4 = reinterpret_cast<const float4*>(J.b) + (t * (J.b_rows >> 2) + (J.b_row0 >> 2)) * 32;
+    const float4* C4 = reinterpret_cast<const float4*>(J.bb) + (t * (J.bb_rows >> 2) + (J.bb_row0 >> 2)) * 32;
+    const int nv = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32), nvv = min(1024, ((J.bb_rows - J.bb_row0) >> 2) * 32);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.a[k] = A4[k * 256 + tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.b[k] = B4[min(k * 256 + tid, nv - 1)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.bb[k] = C4[min(k * 256 + tid, nvv - 1)];
+}
+
+__device__ __forceinline__ unsigned pair_write_tile(float* __restrict__ l, const float4 (&v)[4], int nvalid, int tid) {
+    unsigned m = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = k * 256 + tid;
+        const int o = (4 * (f >> 5)) * kRowStride + (f & 31);
+        const bool ok = f < nvalid;
+        l[o] = ok ? v[k].x : 0.f; l[o + kRowStride] = ok ? v[k].y : 0.f; l[o + 2 * kRowStride] = ok ? v[k].z : 0.f; l[o + 3 * kRowStride] = ok ? v[k].w : 0.f;
+        if (NVP_SPLIT_H2 && ok) m = max(m, __float_as_uint(absmax_f4(0.f, v[k])));
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_dw_pair_kernel(DwArgs A, float* __restrict__ partials, int64_t n, int64_t ntiles, int tiles_per_chunk, int n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // [A tile | B tile | BB tile] | maxima
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    int chunk, job;
+    {
+        const int L = blockIdx.x, nj = A.n_jobs;
+        if (NVP_DW_XCD && (n_chunks & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            chunk = (slot / nj) * 8 + xcd;
+            job = slot - (slot / nj) * nj;
+        } else {
+            chunk = L / nj;
+            job = L - chunk * nj;
+        }
+    }
+    const int64_t t0 = (int64_t)chunk * tiles_per_chunk;
+    const int64_t t1 = min(ntiles, t0 + tiles_per_chunk);
+    float* part = partials + (int64_t)chunk * A.total;
+    const DwJob J = A.job[job];
+    const int wr = w >> 1, wc = w & 1;
+    const int nv = min(1024, ((J.b_rows - J.b_row0) >> 2) * 32), nvv = min(1024, ((J.bb_rows - J.bb_row0) >> 2) * 32);
+    float* la = lds;
+    float* lb[2] = {lds + kTileFloats, lds + 2 * kTileFloats};
+    unsigned* mx = reinterpret_cast<unsigned*>(lds + 3 * kTileFloats);      // [2 slot sets][A | B | BB][4 waves]
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[g][r][c] = nvp_zero16();
+    float bsum0 = 0.f, bsum1 = 0.f;
+    const bool want_bias = (J.bias_off >= 0) && (wc == 0);
+
+    // a staging wave publishes its share of a tile's maxima only when one of them exceeds the running maximum (publish_max)
+    auto publish = [&](int par, unsigned ma, unsigned mb, unsigned mbb, unsigned ra, unsigned rb, unsigned rbb) {
+#if NVP_SPLIT_H2
+        if (!__any(ma > ra || mb > rb || mbb > rbb)) return;
+        ma = wave_umax(ma); mb = wave_umax(mb); mbb = wave_umax(mbb);
+        if (lane == 0) { mx[(par * 3 + 0) * 4 + w] = ma; mx[(par * 3 + 1) * 4 + w] = mb; mx[(par * 3 + 2) * 4 + w] = mbb; }
+#endif
+    };
+
+    PairStage st;
+    unsigned wma = 0u, wmb = 0u, wmbb = 0u;
+    if (t0 < t1) {
+        pair_load(st, J, t0, tid);
+        wma = pair_write_tile(la, st.a, 1024, tid);
+        wmb = pair_write_tile(lb[0], st.b, nv, tid);
+        wmbb = pair_write_tile(lb[1], st.bb, nvv, tid);
+        if (tid < 24) mx[tid] = 0u;
+        __syncthreads();
+        publish(0, wma, wmb, wmbb, 0u, 0u, 0u);
+    }
+    unsigned runA = __float_as_uint(kTinyMax), runB[2] = {runA, runA};
+    PxScale qa = px_scale(kTinyMax), qb[2] = {qa, qa};
+    float curS[2] = {qa.s * qa.s, qa.s * qa.s}, curU[2] = {qa.u * qa.u, qa.u * qa.u};
+    int par = 0;
+    __syncthreads();
+    for (int64_t t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        if (more) pair_load(st, J, t + 1, tid);
+        if (NVP_SPLIT_H2) {
+            const unsigned* mr = mx + par * 12;
+            unsigned mA = 0u, mB = 0u, mC = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { mA = max(mA, mr[u]); mB = max(mB, mr[4 + u]); mC = max(mC, mr[8 + u]); }
+            runA = max(runA, (unsigned)__builtin_amdgcn_readfirstlane((int)mA));
+            runB[0] = max(runB[0], (unsigned)__builtin_amdgcn_readfirstlane((int)mB));
+            runB[1] = max(runB[1], (unsigned)__builtin_amdgcn_readfirstlane((int)mC));
+            qa = px_scale(__uint_as_float(runA));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                qb[g] = px_scale(__uint_as_float(runB[g]));
+                const float S = qa.s * qb[g].s;
+                if (S != curS[g]) {                  // wave-uniform: a tile raised a running maximum
+                    const float ratio = S * curU[g];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[g][r][c] *= ratio;
+                    curS[g] = S; curU[g] = qa.u * qb[g].u;
+                }
+            }
+        }
+        {
+            // the A fragments of both row tiles, split once for both outputs
+            BOp pa[2][2];
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                float fa[16];
+                read_frag(fa, la, 64 * wr + 32 * r2 + i, h);
+                if (want_bias) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { if (r2 == 0) bsum0 += fa[k]; else bsum1 += fa[k]; }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float x[8] = {fa[8 * s2], fa[8 * s2 + 1], fa[8 * s2 + 2], fa[8 * s2 + 3], fa[8 * s2 + 4], fa[8 * s2 + 5], fa[8 * s2 + 6], fa[8 * s2 + 7]};
+                    split8(x, qa.s, pa[r2][s2]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float fb[16];
+                    read_frag(fb, lb[g], 64 * wc + 32 * c + i, h);
+                    BOp pb[2];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const float x[8] = {fb[8 * s2], fb[8 * s2 + 1], fb[8 * s2 + 2], fb[8 * s2 + 3], fb[8 * s2 + 4], fb[8 * s2 + 5], fb[8 * s2 + 6], fb[8 * s2 + 7]};
+                        split8(x, qb[g].s, pb[s2]);
+                    }
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) mac_parts(acc[g][r2][c], pa[r2][s2].p, pb[s2]);
+                }
+        }
+        __syncthreads();                            // everyone finished reading the single buffer
+        if (more) {
+            wma = pair_write_tile(la, st.a, 1024, tid);
+            wmb = pair_write_tile(lb[0], st.b, nv, tid);
+            wmbb = pair_write_tile(lb[1], st.bb, nvv, tid);
+            publish(par ^ 1, wma, wmb, wmbb, runA, runB[0], runB[1]);
+        }
+        par ^= 1;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int ncols = g ? J.nn_cols : J.n_cols;
+        const int64_t woff = g ? J.ww_off : J.w_off;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = 64 * wc + 32 * c + i;
+            if (col < ncols) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 64 * wr + 32 * r2 + nvp_frag_row(r, h);
+                        part[woff + (int64_t)row * J.ld + col] = NVP_SPLIT_H2 ? acc[g][r2][c][r] * curU[g] : acc[g][r2][c][r];
+                    }
+            }
+        }
+    }
+    if (want_bias) {
+        bsum0 += __shfl_xor(bsum0, 32);
+        bsum1 += __shfl_xor(bsum1, 32);
+        if (h == 0) {
+            part[J.bias_off + 64 * wr + i] = bsum0;
+            part[J.bias_off + 64 * wr + 32 + i] = bsum1;
+        }
+    }
+}
+
 // ---- grouped jobs: every operand stream of a (modulator layer k, SIREN layer k) pair is staged ONCE per workgroup -----------------
 // The seven GEMM jobs share operands: dp_k feeds dp_k x h_{k-1} and dp_k x z, h_{k-1} feeds dp_k x h_{k-1} and (as x_{k-1} = sin(.) h_{k-1})
 // dq_k x x_{k-1}.  As separate 256-thread jobs every stream is fetched once per job that uses it (7.5 KB per pixel requested
@@ -760,8 +963,12 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // (which the XCD-local L2 partly served anyway) give back.  OFF by default; kept as the A/B evidence.
     static const bool merge_on = [] { const char* e = getenv("NVP_DW_MERGE"); return e && e[0] == '1'; }();
     const bool merge = merge_on && d <= 128;          // one latent column block: [h ; z] = exactly two B tiles
-    DwArgs P0, P2, P1;                                // plain single-tile jobs, merged two-tile jobs, transform jobs
-    int n0 = 0, n2 = 0, n1 = 0;
+    // NVP_DW_PAIR (environment, read once): dp_k x h_{k-1} and dp_k x z (wide latents: also the two column blocks of dp_0 x z) as ONE
+    // 256-thread workgroup that stages dp_k once (mlp_dw_pair_kernel); bit-identical to the separate jobs
+    static const bool pair_on = [] { const char* e = getenv("NVP_DW_PAIR"); return e ? e[0] == '1' : (NVP_DW_PAIR_DEFAULT != 0); }();
+    const bool pair = pair_on && NVP_DW_B3 && !merge && !getenv_on("NVP_DW_GLDS") && !getenv_on("NVP_DW_GROUP") && !getenv_on("NVP_DW_ONE_LAUNCH");
+    DwArgs P0, P2, P1, PP;                            // plain single-tile jobs, merged two-tile jobs, transform jobs, paired jobs
+    int n0 = 0, n2 = 0, n1 = 0, np = 0;
     auto plain = [&](DwJob& J, int k, const float* b, int b_rows, int b_row0, int n_cols, int64_t w_off, int ld, int64_t bias_off) {
         J.a = dy + (int64_t)k * act; J.b = b; J.b2 = b; J.mode = 0; J.b_rows = b_rows; J.b_row0 = b_row0;
         J.n_cols = n_cols; J.w_off = w_off; J.ld = ld; J.bias_off = bias_off;
@@ -778,11 +985,25 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
             continue;
         }
         bool bias_done = false;
-        if (k > 0) {
+        int c_first = 0;
+        if (pair && (k > 0 || d > 128)) {
+            // A = dp_k staged once; B = h_{k-1} (k > 0) or the first column block of z (k = 0), BB = the next column block of z
+            DwJob& J = PP.job[np++];
+            if (k > 0) {
+                plain(J, k, saved + (int64_t)(k - 1) * act, NVP_H, 0, NVP_H, P.mod_w[k], ld, P.mod_b[k]);
+                J.bb = zt; J.bb_rows = rows; J.bb_row0 = 0; J.nn_cols = d < 128 ? d : 128; J.ww_off = P.mod_w[k] + NVP_H;
+                c_first = 128;
+            } else {
+                plain(J, k, zt, rows, 0, 128, P.mod_w[k], ld, P.mod_b[k]);
+                J.bb = zt; J.bb_rows = rows; J.bb_row0 = 128; J.nn_cols = (d - 128 < 128) ? d - 128 : 128; J.ww_off = P.mod_w[k] + 128;
+                c_first = 256;
+            }
+            bias_done = true;
+        } else if (k > 0) {
             plain(P0.job[n0++], k, saved + (int64_t)(k - 1) * act, NVP_H, 0, NVP_H, P.mod_w[k], ld, P.mod_b[k]);
             bias_done = true;
         }
-        for (int c0 = 0; c0 < d; c0 += 128) {
+        for (int c0 = c_first; c0 < d; c0 += 128) {
             plain(P0.job[n0++], k, zt, rows, c0, (d - c0 < 128) ? d - c0 : 128, P.mod_w[k] + (k == 0 ? 0 : NVP_H) + c0, ld,
                   bias_done ? -1 : P.mod_b[k]);
             bias_done = true;
@@ -814,8 +1035,8 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
         for (int j = 0; j < n0; ++j) P1.job[n1++] = P0.job[j];
         n0 = 0;
     }
-    for (DwArgs* Q : {&P0, &P2, &P1}) { Q->steps = steps; Q->sir0_wp = p->sir_w[0]; Q->sir0_bp = p->sir_b[0]; Q->total = P.total; }
-    P0.n_jobs = n0; P2.n_jobs = n2; P1.n_jobs = n1;
+    for (DwArgs* Q : {&P0, &P2, &P1, &PP}) { Q->steps = steps; Q->sir0_wp = p->sir_w[0]; Q->sir0_bp = p->sir_b[0]; Q->total = P.total; }
+    P0.n_jobs = n0; P2.n_jobs = n2; P1.n_jobs = n1; PP.n_jobs = np;
 
     const int tiles_per_chunk = (int)((ntiles + n_chunks - 1) / n_chunks);
     // The transform jobs (SIREN layers 1, 2: two workgroups per CU, two jobs) fill the chip with 256 chunks exactly; the five plain
@@ -861,6 +1082,11 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     const size_t lds_bytes = (2 * 2 * kTileFloats + 4 * kMxW + 2 * NVP_H) * sizeof(float);
     const size_t lds_bytes0 = ((NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
     const size_t lds_bytes2 = (2 * 3 * kTileFloats + 4 * kMxW) * sizeof(float);          // 108 KiB: one 8-wave workgroup per CU
+    if (np) {
+        const size_t lds_pair = (3 * kTileFloats + 24) * sizeof(float);                     // 54 KiB: two workgroups per CU
+        hipLaunchKernelGGL(mlp_dw_pair_kernel, dim3(n_chunks * np), dim3(256), lds_pair, (hipStream_t)stream, PP, partials, n, ntiles, tiles_per_chunk, n_chunks);
+        NVP_LAUNCH_CHECK();
+    }
     if (n0) hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
     if (n2) hipLaunchKernelGGL((mlp_dw_kernel<0, 2>), dim3(n_chunks * n2), dim3(512), lds_bytes2, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);

@@ -1124,7 +1124,7 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     # nvp_l's 228-row latent (F = 4): the ring variants of the backward chain and of the eight-tile latent-gradient kernel against
     # the per-wave kernels (NVP_MLP_RING_BWD=0)
     wide = []
-    for k, env in enumerate(({"NVP_MLP_RING_BWD": "1"}, {"NVP_MLP_RING_BWD": "0"})):
+    for k, env in enumerate(({"NVP_MLP_RING_BWD": "1", "NVP_DW_PAIR": "0"}, {"NVP_MLP_RING_BWD": "0", "NVP_DW_PAIR": "1"})):
         out = str(tmp_path / f"w{k}.npz")
         subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "4", "50001"], check=True, timeout=300, env={**os.environ, **env})
         wide.append(np.load(out))
@@ -1132,7 +1132,7 @@ def test_kernel_variants_are_bit_identical(tmp_path):
         assert np.array_equal(wide[0][k], wide[1][k], equal_nan=True), f"{k} differs between the ring and the per-wave backward (F = 4)"
     # The grouped dW workgroups - register-staged (NVP_DW_GROUP=1: bit-identical) and DMA-fed with operands split once
     # (NVP_DW_GLDS=1: another summation order, so equal to the gradient tolerance, not bit for bit) - measured slower, off by default
-    for env, exact in (({"NVP_DW_GROUP": "1"}, True), ({"NVP_DW_GLDS": "1"}, False)):
+    for env, exact in (({"NVP_DW_GROUP": "1"}, True), ({"NVP_DW_GLDS": "1"}, False), ({"NVP_DW_PAIR": "1"}, True), ({"NVP_DW_PAIR": "0"}, True)):
         out = str(tmp_path / ("g_" + "_".join(env) + ".npz"))
         subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300, env={**os.environ, **env})
         b = np.load(out)
