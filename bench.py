@@ -318,11 +318,12 @@ def main():
             dt_ = float(tt)
         return dt_, loss_
 
-    def verify_replicas(what):
+    def verify_replicas(what, fatal=True):
         """N > 1: every rank must hold bit-identical parameters after a step (same SUM on every rank, element-wise AdamW).  A
-        scheme that lets the replicas diverge produces a throughput number for a broken training: refuse to report it."""
+        scheme that lets the replicas diverge produces a throughput number for a broken training: refuse to report it.
+        fatal=False (the scheme autotune): returns False instead of ending the run, so that another scheme can be tried."""
         if world <= 1:
-            return
+            return True
         ps = parallel.unique_parameters(model)
         chk = torch.stack([p.detach().double().sum() for p in ps] + [p.detach().double().abs().sum() for p in ps])
         allc = [torch.zeros_like(chk) for _ in range(world)]
@@ -330,24 +331,53 @@ def main():
         bad = [r for r in range(world) if not torch.equal(allc[r], allc[0])]
         if bad:
             if rank == 0:
-                print(f"bench.py: replicas DIVERGED under '{what}' (ranks {bad} differ from rank 0 after identical steps): no result line", file=sys.stderr)
+                print(f"bench.py: replicas DIVERGED under '{what}' (ranks {bad} differ from rank 0 after identical steps)"
+                      + (": no result line" if fatal else ": scheme excluded"), file=sys.stderr)
+            if not fatal:
+                return False
             dist.barrier()
             dist.destroy_process_group()
             sys.exit(3)
+        return True
 
     # ---- exchange scheme (N > 1): chosen by measurement, before the warm-up, on untimed steps
     mode, tune = args.dp, None
     if multi and mode == "auto":
         tune = {}
         for cand in ("sharded", "a2a", "replicated"):
-            st = make_state(cand)
-            one_step(st)                                  # first steps of a scheme allocate / connect (RCCL sets channels up lazily
-            one_step(st)                                  # per collective and message size: seen as one 400-ms step)
-            tune[cand] = round(timed(st, 3)[0] / 3 * 1e3, 3)
-            verify_replicas(cand)                         # 5 steps of this scheme over RCCL: the replicas must still be identical
+            # A scheme that raises on this node (a collective RCCL refuses) or lets the replicas diverge is EXCLUDED, not fatal: the
+            # first hardware run should still produce a line from a scheme that works (the timed run re-verifies the chosen one, fatally).
+            # Every rank reaches the same verdict: exceptions are exchanged through a MAX all-reduce, the checksums through all_gather.
+            st, failed = None, 0
+            try:
+                st = make_state(cand)
+                one_step(st)                              # first steps of a scheme allocate / connect (RCCL sets channels up lazily
+                one_step(st)                              # per collective and message size: seen as one 400-ms step)
+                t_c = round(timed(st, 3)[0] / 3 * 1e3, 3)
+            except Exception as e:                        # noqa: BLE001 - anything a scheme throws excludes the scheme
+                failed = 1
+                print(f"bench.py[rank {rank}]: scheme '{cand}' raised {type(e).__name__}: {e}", file=sys.stderr)
+            flag = torch.tensor([failed], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag):
+                tune[cand] = None
+            elif not verify_replicas(cand, fatal=False):  # 5 steps of this scheme over RCCL: the replicas must still be identical
+                tune[cand] = None
+            else:
+                tune[cand] = t_c
             del st
+            torch.cuda.synchronize()
             torch.cuda.empty_cache()
-        mode = min(tune, key=tune.get)
+            if tune[cand] is None:
+                parallel.broadcast_parameters(model)      # the next scheme starts from identical replicas again
+        ok = {k: v for k, v in tune.items() if v is not None}
+        if not ok:
+            if rank == 0:
+                print("bench.py: no exchange scheme survived the autotune (see above): no result line", file=sys.stderr)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+        mode = min(ok, key=ok.get)
     state = make_state(mode)
 
     for _ in range(args.warmup):
@@ -434,6 +464,10 @@ def main():
                         "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
                 if dom in FLOP_PX:
                     roof["mfma_frac"] = st["mfma_frac"]
+                if traffic.get(dom):
+                    # what the kernel actually moved through HBM per second (PMC bytes / this run's launch time): the gap between
+                    # `frac` and this is re-fetched or sector-padded traffic, the gap between this and 1 is what the kernel leaves idle
+                    roof["traffic_frac"] = round(traffic[dom] / (kms[dom] * 1e-3) / PEAK_HBM, 4)
         iso_line = None
         if isolated is not None:
             ikms = {k: round(v[0] * v[1] / max(args.steps, 1), 4) for k, v in isolated["kernels"].items()}

@@ -259,3 +259,31 @@ def test_two_gpu_rccl_sharded_adamw(algo, fast):
     """The same checks (sharded / a2a == replicated bit for bit; with `fast` the sorted-batch sparse-first path) over the real
     RCCL backend ("nccl") on two GPUs of one node; skipped on single-GPU boxes."""
     _spawn_sharded(algo, "nccl", (0, 1), fast=fast)
+
+
+def test_bench_two_ranks_through_the_scheme_autotune():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), with both ranks on
+    the one GPU of the box over gloo (NVP_DIST_BACKEND=gloo: RCCL refuses two ranks per device): the scheme autotune runs all
+    three exchange schemes on HIP tensors, verifies after each that the replicas hold identical parameters, the timed pass
+    re-verifies, and ONE JSON line with the whole-job rate comes out.  (The timings themselves mean nothing over gloo.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {**os.environ, "NVP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch_pixels"] == 2 * d["config"]["pixels_per_gpu_step"]
+    assert set(d["dp"]["autotune_ms_per_step"]) == {"sharded", "a2a", "replicated"}
+    assert all(v is not None for v in d["dp"]["autotune_ms_per_step"].values()), d["dp"]      # no scheme raised or diverged
+    assert d["dp"]["mode"] in d["dp"]["autotune_ms_per_step"]
+    assert abs(d["value"] - 2 * d["config"]["pixels_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
