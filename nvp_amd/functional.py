@@ -339,6 +339,13 @@ def modulated_siren_streams(latent: torch.Tensor, steps: torch.Tensor, mlp: Sequ
     return out
 
 
+def _scatter_ws_bytes(lib, n, lv_xy, lv_yt, lv_xt, sh) -> int:
+    b = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh))
+    if b < 0:
+        raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
+    return b
+
+
 class NVPFused(torch.autograd.Function):
     """NVP.forward hot path (R11): coords [N,3], steps [N] -> rgb [N,3] in four kernels
     (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""
@@ -385,6 +392,9 @@ class NVPFused(torch.autograd.Function):
             pstruct = L.mlp_params_struct(mlp)
             pk_f = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
             pk_b = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32) if bwd_follows else None
+            if bwd_follows:                    # the scatter workspace too, BEFORE the one hand-over to the side stream (every
+                ws_bytes = _scatter_ws_bytes(lib, n, lv_xy, lv_yt, lv_xt, sh)      # wait_stream is an event marker on the compute queue)
+                ctx.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
             side.wait_stream(torch.cuda.current_stream(dev))     # allocations, parameters and coordinates are ordered on the compute stream
             # Lifetimes: these buffers come from the COMPUTE stream's allocator pool but are written (and the coordinates /
             # parameters read) on the side stream.  If the autograd graph is dropped without a backward pass (a validation
@@ -411,16 +421,15 @@ class NVPFused(torch.autograd.Function):
         if bwd_follows:
             L.ptr(coords)
             lvs = (lv_xy, lv_yt, lv_xt)
-            ws_bytes = lib.nvp_encode_bwd_workspace_bytes(n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh))
-            if ws_bytes < 0:
-                raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
-            ctx.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            if ctx.ws is None:
+                ws_bytes = _scatter_ws_bytes(lib, n, lv_xy, lv_yt, lv_xt, sh)
+                ctx.ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            ws_bytes = ctx.ws.numel()
             bflags = L.COORDS_SORTED_BY_Y if y_sorted else 0
             if DZ_LEVEL_MAJOR and y_sorted and lib.nvp_dz_lm_supported(d):
                 bflags |= L.DZ_PLANES_READY
             ctx.bflags = bflags
             if SIDE_WORK:
-                side.wait_stream(torch.cuda.current_stream(dev))     # the workspace allocation
                 ctx.ws.record_stream(side)
                 with torch.cuda.stream(side):
                     L.check(lib.nvp_encode_bwd_presort(L.ptr(coords), n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh),
@@ -511,10 +520,13 @@ class NVPFused(torch.autograd.Function):
                     "nvp_encode_bwd")
 
         dz_rows_ref = [None]
+        packed_bwd, ctx.packed_bwd = ctx.packed_bwd, None
 
         def scatter(dz_rows):
             dz_rows_ref[0] = dz_rows
-            if presorted is not None:
+            # the presort's event was recorded on the side stream BEFORE the backward pack's, which the compute stream has waited
+            # for in front of the chain kernel: a second wait would only be one more marker on the compute queue
+            if presorted is not None and packed_bwd is None:
                 torch.cuda.current_stream(coords.device).wait_event(presorted)
             if (hk.sparse_ready is not None or hk.early_grads is not None) and (flags & L.DZ_PLANES_READY):
                 # the sparse grid (80 % of the gradient bytes) is scattered first and handed on - to the data-parallel exchange, or
@@ -535,6 +547,5 @@ class NVPFused(torch.autograd.Function):
                 hk.grids_ready()            # e.g. start the (async) all-reduce of the grid gradients
 
         # order: dX chain -> grid scatter (needs only dz) -> dW GEMMs (independent of the scatter)
-        packed_bwd, ctx.packed_bwd = ctx.packed_bwd, None
         _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm, packed=packed_bwd, sink=sink)
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, None, *grads)

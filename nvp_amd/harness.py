@@ -82,8 +82,10 @@ class DeviceVideo:
             self._issue()
         batch, ev = self._next
         cur.wait_event(ev)
-        for t in (batch[0]["all_coords"], batch[0]["temporal_steps"], batch[1]["img"]):
-            t.record_stream(cur)                  # allocated on the side stream, consumed on this one
+        # The batch tensors come from the SIDE stream's allocator pool and are consumed on this stream.  No record_stream (each
+        # would cost an event marker on the compute queue when the tensor is freed - ~11 us of queue time apiece): a freed batch
+        # can only be handed out again by a later _draw, every _draw is enqueued behind `side.wait_stream(compute stream)` in
+        # _issue, and whoever freed the batch had enqueued its last use before that.
         self._issue()
         return batch
 
