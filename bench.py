@@ -217,6 +217,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm", type=int, default=0,
+                    help="extra untimed steps BEFORE the --warmup steps (reported as prewarm_steps).  Off by default: a first process on a "
+                         "fresh box was seen twice at 8.9 instead of 6.8 ms per step, but not reproducibly, and 100 extra steps made "
+                         "the timed ones 0.05 ms SLOWER (6.86-6.88 vs 6.77-6.85 ms: the board runs at its power limit and warms up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=N_PX // 8)
     ap.add_argument("--config", choices=list(WORKLOADS), default="s",
@@ -264,7 +268,7 @@ def main():
     data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank,   # rank-offset sampler seed
                                sort_by_y=os.environ.get("NVP_BENCH_UNSORTED", "0") != "1",
                                prefetch=os.environ.get("NVP_SAMPLER_PREFETCH", "1") != "0")   # next batch drawn on a side stream: -0.05 ms (eight interleaved 40-step runs: 7.42-7.44 vs 7.47-7.49)
-    total = args.warmup + 2 * args.steps       # cosine horizon: warm-up + the timed pass + the isolated pass
+    total = args.prewarm + args.warmup + 2 * args.steps       # cosine horizon: pre-warm + warm-up + the timed pass + the isolated pass
     multi = world > 1 or os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1"
 
     def make_state(mode):
@@ -392,7 +396,7 @@ def main():
         mode = min(ok, key=ok.get)
     state = make_state(mode)
 
-    for _ in range(args.warmup):
+    for _ in range(args.prewarm + args.warmup):
         one_step(state)
     verify_replicas(mode + " (after the warm-up)")
 
@@ -519,6 +523,7 @@ def main():
             "final_loss": float(loss),
             "host_enqueue_ms_per_step": {"mean": host_ms[0], "max": host_ms[1]},
             "stage_event_steps": n_inst,
+            "prewarm_steps": args.prewarm,
             "isolated": iso_line,
         }
         if multi:

@@ -21,7 +21,10 @@
 
 namespace {
 
-constexpr int kWaves = 4;
+#ifndef NVP_FWD_WAVES
+#define NVP_FWD_WAVES 4        // waves (= 32-pixel tiles) per workgroup; the waves are independent (no barrier, per-wave LDS tiles)
+#endif
+constexpr int kWaves = NVP_FWD_WAVES;
 // `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
 // step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
 __device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane) {

@@ -276,7 +276,7 @@ def test_bench_two_ranks_through_the_scheme_autotune():
     s.close()
     env = {**os.environ, "NVP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0",
                         "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
