@@ -260,6 +260,14 @@ def main():
     T, H, W = wl["video"]
     cfg = make_cfg(F, T)
     FLOP_PX, BYTES_PX = work_per_pixel(F)
+    # one GPU, default path: the scatter's flush also applies the sparse grid's AdamW step (nvp_encode_bwd_sparse_adamw): p, m, v read
+    # and written once per element, per step - that is optimizer work (K13) done inside the scatter stage, so it is added to the
+    # stage's algorithmic bytes (the separate AdamW launch for the sparse grid and its gradient tensor are gone)
+    fused_sparse_bytes_per_px = 0.0
+    if (world == 1 and not (os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1") and harness.EARLY_ADAMW
+            and harness.FUSED_SPARSE_ADAMW and os.environ.get("NVP_BENCH_UNSORTED", "0") != "1"):
+        fused_sparse_bytes_per_px = 6 * 4 * T * 300 * 300 * F / N_PX
+        BYTES_PX = dict(BYTES_PX, nvp_encode_bwd=BYTES_PX["nvp_encode_bwd"] + fused_sparse_bytes_per_px)
     model = NVP(out_features=3, encoding_config=cfg, verbose=False).to(dev)
     parallel.broadcast_parameters(model)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -452,10 +460,11 @@ def main():
         # every hot-path stage against its rooflines (SURVEY 8d asks for the isolated gather/scatter fractions too).  The MLP
         # stages are priced against BOTH the matrix peak of their arithmetic and HBM (their algorithmic stream bytes); the
         # roof a stage sits closer to is reported as its bound.
-        def price(k, ms):
+        def price(k, ms, alone=False):
             out = {"ms": ms}
             if k in BYTES_PX:
-                a = BYTES_PX[k] * N_PX / (ms * 1e-3)
+                # (the side-streams-off pass also runs the optimizer after backward: its scatter stage carries no AdamW bytes)
+                a = (BYTES_PX[k] - (fused_sparse_bytes_per_px if alone and k == "nvp_encode_bwd" else 0.0)) * N_PX / (ms * 1e-3)
                 out.update({"achieved_gbs": round(a / 1e9, 1), "hbm_frac": round(a / PEAK_HBM, 4),
                             "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None})
             if k in FLOP_PX:
@@ -490,7 +499,7 @@ def main():
             iso_line = {"what": "same workload, second timed pass with every side stream off (NVP_EARLY_ADAMW=0 NVP_SCATTER_PRESORT=0 "
                                 "NVP_SAMPLER_PREFETCH=0 equivalents): each stage's span is that stage alone; the step is longer",
                         "ms_per_step": isolated["ms_per_step"], "kernels_ms": ikms,
-                        "stages": {k: price(k, ms) for k, ms in ikms.items() if k in FLOP_PX or k in BYTES_PX}}
+                        "stages": {k: price(k, ms, alone=True) for k, ms in ikms.items() if k in FLOP_PX or k in BYTES_PX}}
             if roof is not None and roof["kernel"] in iso_line["stages"]:
                 st = iso_line["stages"][roof["kernel"]]
                 iso_line["roofline"] = {"kernel": roof["kernel"], "bound": roof["bound"], "unit": roof["unit"], "peak": roof["peak"],

@@ -188,6 +188,18 @@ int nvp_encode_bwd_prepare(int64_t n, const nvp_levels* lv_xy, const nvp_levels*
  * workspace; `flags` as for nvp_encode_bwd.  Bit-identical gradients. */
 int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                            const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream);
+/* The sparse grid's half of the split scatter (NVP_SCATTER_SPARSE_ONLY semantics; flags must carry NVP_COORDS_SORTED_BY_Y |
+ * NVP_DZ_PLANES_READY) with the OPTIMIZER STEP applied in the flush: the gradient of a sparse-grid element goes from the kernel's
+ * LDS table straight into the AdamW update of (emb, exp_avg, exp_avg_sq) - same arithmetic, same bits as nvp_adamw_step on the
+ * gradient nvp_encode_bwd would have written (reference: sparsegrid.py autograd + training.py:13-14,75), but the gradient never
+ * touches HBM (432 MB written + 432 MB read per step less for config_nvp_s).  One GPU only: a data-parallel step must exchange the
+ * gradient first.  Returns NVP_ERR_UNSUPPORTED with nothing enqueued when y_res * n_features is not a multiple of 4, a tensor is
+ * not 16-B aligned or one band table exceeds 4 096 entries: take nvp_encode_bwd + nvp_adamw_step then. */
+int nvp_encode_bwd_sparse_adamw(const float* coords, const float* dz, int32_t dz_stride, int64_t n,
+                                const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                                const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
+                                float* emb, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                                double weight_decay, int64_t step, void* stream);
 int32_t nvp_dz_lm_supported(int32_t latent_dim);   /* does nvp_mlp_bwd_dx honour `lm` for this latent width in this build? */
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,

@@ -91,6 +91,8 @@ SIGNATURES = {
     "nvp_encode_bwd_prepare": [_i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64,
                                C.POINTER(ScatterLm), _vp],
     "nvp_encode_bwd_presort": [_p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64, _i32, _vp],
+    "nvp_encode_bwd_sparse_adamw": [_p, _p, _i32, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64, _i32,
+                                    _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp],
     "nvp_dz_lm_supported": [_i32],
     "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
@@ -129,6 +131,9 @@ def load() -> C.CDLL:
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
     return lib
+
+
+ERR_BADARG, ERR_UNSUPPORTED = -1, -2          # include/nvp_hip.h
 
 
 class NvpHipError(RuntimeError):

@@ -29,6 +29,7 @@
 // N contributions cannot overflow 2^62; each contribution keeps >= 40 significant bits below
 // max|dz| (fp32 carries 24), so the scatter is more accurate than an fp32 atomic chain.
 #include <cstring>
+#include "adamw.h"
 #include "grid_math.h"
 
 #pragma clang fp contract(off)
@@ -614,11 +615,19 @@ __global__ __launch_bounds__(256) void sparse_keys_kernel(const float* __restric
 template <int F>
 struct SparseUnit { int row, yi; bool on; float g[3 * F]; };
 
-template <int F>
+// ADAM: the flush applies the optimizer step instead of writing the gradient (adamw.h): the gradient of a sparse-grid element
+// goes from the LDS table straight into the update of (p, m, v) and never touches HBM - 432 MB written and 432 MB read per step
+// less for nvp_s.  The item's (p, m, v) are requested at the item's START (kAdamTrips float4 of each per thread, in registers)
+// and arrive while the item's units are added into the table.  Needs y_res * F % 4 == 0 and 16-B aligned tensors (host check).
+constexpr int kAdamTrips = 4;                     // float4 trips per thread and item: tables up to 4 096 entries
+struct SparseAdam { float* p; float* m; float* v; AdamScalars S; };
+
+template <int F, bool ADAM>
 __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float* __restrict__ coords, const float* __restrict__ dz, int dz_stride, int col0,
                                                                      const int* __restrict__ order, const int* __restrict__ rowstart,
                                                                      const unsigned* __restrict__ dzmax, float* __restrict__ demb,
-                                                                     nvp_sparse_shape sh, int rows_per_band, int bands, int n_items, int headroom_bits) {
+                                                                     nvp_sparse_shape sh, int rows_per_band, int bands, int n_items, int headroom_bits,
+                                                                     SparseAdam ad) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];
     __shared__ int s_k;
     __shared__ bool s_poison;
@@ -680,6 +689,19 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
         const int r0 = band * rows_per_band, r1 = min(sh.x_res, r0 + rows_per_band);
         const int entries = (r1 - r0) * sh.y_res * F;
         const int lo = lo_n, units = (hi_n - lo_n) * 3;
+        const int64_t item0 = (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
+        float4 pp[kAdamTrips], mm[kAdamTrips], vv[kAdamTrips];
+        if (ADAM) {
+#pragma unroll
+            for (int k = 0; k < kAdamTrips; ++k) {
+                const int q = threadIdx.x + kSparseThreads * k;
+                if (4 * q < entries) {
+                    pp[k] = reinterpret_cast<const float4*>(ad.p + item0)[q];
+                    mm[k] = reinterpret_cast<const float4*>(ad.m + item0)[q];
+                    vv[k] = reinterpret_cast<const float4*>(ad.v + item0)[q];
+                }
+            }
+        }
         unit_apply(un[0]);
         unit_apply(un[1]);
         for (int u = threadIdx.x + 2 * kSparseThreads; u < units; u += kSparseThreads) {      // rare: more than 512 units
@@ -690,11 +712,33 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
         }
         __syncthreads();
         if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);          // in flight during the flush
-        float* out = demb + (((int64_t)t * sh.x_res + r0) * sh.y_res) * F;
-        for (int i = threadIdx.x; i < entries; i += kSparseThreads) {
-            const long long v = (long long)tab[i];
-            tab[i] = 0ull;                                                          // ready for the next item
-            out[i] = poison ? __uint_as_float(0x7fc00000u) : (float)((double)v * inv);
+        if (ADAM) {
+#pragma unroll
+            for (int k = 0; k < kAdamTrips; ++k) {
+                const int q = threadIdx.x + kSparseThreads * k;
+                if (4 * q < entries) {
+                    ulonglong2* t2 = reinterpret_cast<ulonglong2*>(tab + 4 * q);
+                    const ulonglong2 a = t2[0], b = t2[1];
+                    t2[0] = make_ulonglong2(0ull, 0ull); t2[1] = make_ulonglong2(0ull, 0ull);          // ready for the next item
+                    const float nanv = __uint_as_float(0x7fc00000u);
+                    const float g0 = poison ? nanv : (float)((double)(long long)a.x * inv), g1 = poison ? nanv : (float)((double)(long long)a.y * inv);
+                    const float g2 = poison ? nanv : (float)((double)(long long)b.x * inv), g3 = poison ? nanv : (float)((double)(long long)b.y * inv);
+                    adam1(pp[k].x, g0, mm[k].x, vv[k].x, ad.S);
+                    adam1(pp[k].y, g1, mm[k].y, vv[k].y, ad.S);
+                    adam1(pp[k].z, g2, mm[k].z, vv[k].z, ad.S);
+                    adam1(pp[k].w, g3, mm[k].w, vv[k].w, ad.S);
+                    reinterpret_cast<float4*>(ad.p + item0)[q] = pp[k];
+                    reinterpret_cast<float4*>(ad.m + item0)[q] = mm[k];
+                    reinterpret_cast<float4*>(ad.v + item0)[q] = vv[k];
+                }
+            }
+        } else {
+            float* out = demb + item0;
+            for (int i = threadIdx.x; i < entries; i += kSparseThreads) {
+                const long long v = (long long)tab[i];
+                tab[i] = 0ull;                                                          // ready for the next item
+                out[i] = poison ? __uint_as_float(0x7fc00000u) : (float)((double)v * inv);
+            }
         }
         __syncthreads();
     }
@@ -750,7 +794,8 @@ int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_s
 
 template <int F>
 int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
-               const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s) {
+               const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s,
+               const SparseAdam* adam = nullptr) {
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     // xy / yt latent gradients already level-major in ws AND the sparse columns' max|dz| already in its slots (chain kernel)
     const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;
@@ -840,9 +885,20 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         if (per_cu < 1) per_cu = 1;
         const int grid = n_items < 256 * per_cu ? n_items : 256 * per_cu;
         const size_t lds = (size_t)rows * sh->y_res * sh->n_features * 8;
+        SparseAdam ad{};
+        if (adam) {
+            // whole float4 per table quad, 16-B aligned tensors, the item's table within kAdamTrips trips of the workgroup
+            if ((sh->y_res * sh->n_features) & 3 || rows * sh->y_res * sh->n_features > 4 * kSparseThreads * kAdamTrips ||
+                (((uintptr_t)adam->p | (uintptr_t)adam->m | (uintptr_t)adam->v) & 15)) return NVP_ERR_UNSUPPORTED;
+            ad = *adam;
+        }
         switch (sh->n_features) {
-#define NVP_SPARSE_CASE(FF) case FF: hipLaunchKernelGGL((sparse_band_kernel<FF>), dim3((unsigned)grid), dim3(kSparseThreads), lds, s, coords, dz, dz_stride, scol0, \
-                           (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, n_items, headroom_bits + 2); break;
+#define NVP_SPARSE_CASE(FF) case FF: \
+            if (adam) hipLaunchKernelGGL((sparse_band_kernel<FF, true>), dim3((unsigned)grid), dim3(kSparseThreads), lds, s, coords, dz, dz_stride, scol0, \
+                           (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, n_items, headroom_bits + 2, ad); \
+            else hipLaunchKernelGGL((sparse_band_kernel<FF, false>), dim3((unsigned)grid), dim3(kSparseThreads), lds, s, coords, dz, dz_stride, scol0, \
+                           (const int*)sorder, (const int*)srs, (const unsigned*)sdzmax, demb, *sh, rows, bands, n_items, headroom_bits + 2, ad); \
+            break;
             NVP_SPARSE_CASE(1) NVP_SPARSE_CASE(2) NVP_SPARSE_CASE(4) NVP_SPARSE_CASE(8)
 #undef NVP_SPARSE_CASE
             default: return NVP_ERR_UNSUPPORTED;
@@ -921,10 +977,10 @@ int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_
 
 // dz: row-major latent gradient [>= n][dz_stride] (columns xy | yt | xt | sparse).
 // d_kf_* and d_emb: every element is OVERWRITTEN (no zero-fill needed).
-int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
+static int encode_bwd_impl(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream) {
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream, const SparseAdam* adam) {
     if (!levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh || n < 0) return NVP_ERR_BADARG;
     if (lv_xy->n_features != lv_yt->n_features || lv_xy->n_features != lv_xt->n_features) return NVP_ERR_UNSUPPORTED;
     if (n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;
@@ -940,7 +996,9 @@ int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
         hipError_t e = hipMemsetAsync(d_emb, 0, (size_t)sh->t_res * sh->x_res * sh->y_res * sh->n_features * 4, s);
         return (int)e;
     }
-    if (!coords || !dz || !d_kf_xy || !d_kf_yt || !d_kf_xt || !d_emb || !workspace) return NVP_ERR_BADARG;
+    // a split call only needs the outputs it produces; the fused-optimizer call produces no d_emb at all
+    const bool want_dense = !(flags & NVP_SCATTER_SPARSE_ONLY), want_emb = !(flags & NVP_SCATTER_DENSE_ONLY) && !adam;
+    if (!coords || !dz || !workspace || (want_dense && (!d_kf_xy || !d_kf_yt || !d_kf_xt)) || (want_emb && !d_emb)) return NVP_ERR_BADARG;
     Plan P;
     make_plan(P, lv, n);
     Ws W;
@@ -953,15 +1011,48 @@ int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
     if ((lv_xy->n_levels * lv_xy->n_features) & 3 || (lv_yt->n_levels * lv_yt->n_features) & 3 || (lv_xt->n_levels * lv_xt->n_features) & 3)
         return NVP_ERR_UNSUPPORTED;             // 16-B aligned per-plane row segments (true for every 4-level-multiple config)
     switch (lv_xy->n_features) {
-        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
-        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
-        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
-        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s); break;
+        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
+        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
+        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
+        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
         default: return NVP_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
     NVP_LAUNCH_CHECK();
     return 0;
+}
+
+int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
+                   float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
+                   const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream) {
+    return encode_bwd_impl(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv_xy, lv_yt, lv_xt, sh, workspace, workspace_bytes, flags, stream, nullptr);
+}
+
+// The sparse grid's half of the split scatter (NVP_SCATTER_SPARSE_ONLY semantics: needs NVP_COORDS_SORTED_BY_Y |
+// NVP_DZ_PLANES_READY) with the optimizer step applied in the flush: no d_emb is produced, `emb` / `exp_avg` / `exp_avg_sq` are
+// updated in place exactly as nvp_adamw_step would update them from that gradient (same arithmetic: adamw.h).
+// NVP_ERR_UNSUPPORTED (nothing enqueued) if y_res * F is not a multiple of 4, a tensor is not 16-B aligned or a table exceeds
+// 4 096 entries: the caller then takes the two-kernel route.
+int nvp_encode_bwd_sparse_adamw(const float* coords, const float* dz, int32_t dz_stride, int64_t n,
+                                const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                                const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
+                                float* emb, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                                double weight_decay, int64_t step, void* stream) {
+    if (!emb || !exp_avg || !exp_avg_sq || step < 1 || n < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1)) return NVP_ERR_BADARG;
+    if (!(flags & NVP_DZ_PLANES_READY) || !(flags & NVP_COORDS_SORTED_BY_Y) || (flags & NVP_SCATTER_DENSE_ONLY)) return NVP_ERR_BADARG;
+    if (!sh || (sh->y_res * sh->n_features) & 3 || (((uintptr_t)emb | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)) return NVP_ERR_UNSUPPORTED;
+    {
+        int sentries = kSparseEntries;
+        if (sh->y_res * sh->n_features > sentries) sentries = sh->y_res * sh->n_features;
+        int rows = sentries / (sh->y_res * sh->n_features);
+        if (rows * sh->y_res * sh->n_features > 4 * kSparseThreads * kAdamTrips) return NVP_ERR_UNSUPPORTED;
+    }
+    SparseAdam ad;
+    ad.p = emb; ad.m = exp_avg; ad.v = exp_avg_sq;
+    ad.S = adam_scalars(lr, beta1, beta2, eps, weight_decay, step, 1.0);
+    return encode_bwd_impl(coords, dz, dz_stride, nullptr, nullptr, nullptr, nullptr, n, lv_xy, lv_yt, lv_xt, sh, workspace, workspace_bytes,
+                           flags | NVP_SCATTER_SPARSE_ONLY, stream, &ad);
 }
 
 }  // extern "C"

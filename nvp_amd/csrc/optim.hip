@@ -10,6 +10,7 @@
 // Bound: HBM.  16 B read (p,g,m,v) + 12 B written (p,m,v) per element = 3.8 GB per step for nvp_s; one
 // pass, 16-B accesses, nothing cached (the state is 2.2 GB, far beyond L2/MALL).
 #include "nvp_common.h"
+#include "adamw.h"
 
 namespace {
 
@@ -26,24 +27,6 @@ struct AdamSegs {
     int32_t aligned[kMaxSegs];
     int32_t n_segs;
 };
-
-struct AdamScalars {
-    float decay;          // 1 - lr*wd
-    float one_m_b1, b2, one_m_b2;
-    float neg_step;       // -lr / (1 - b1^t)
-    float bc2_sqrt;       // sqrt(1 - b2^t)
-    float eps, grad_scale;
-    int scale_grad;
-};
-
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamScalars& S) {
-    if (S.scale_grad) g = g * S.grad_scale;
-    p = p * S.decay;
-    m = m + (g - m) * S.one_m_b1;
-    v = v * S.b2 + S.one_m_b2 * g * g;
-    const float denom = sqrtf(v) / S.bc2_sqrt + S.eps;
-    p = p + S.neg_step * (m / denom);
-}
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamSegs A, AdamScalars S) {
     int s = 0;
@@ -99,17 +82,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamSegs A, AdamScalars S) {
 extern "C" int nvp_adamw_step(const nvp_adamw_seg* segs, int32_t n_segs, double lr, double beta1, double beta2, double eps,
                               double weight_decay, int64_t step, double grad_scale, void* stream) {
     if (n_segs < 0 || (n_segs > 0 && !segs) || step < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1)) return NVP_ERR_BADARG;
-    AdamScalars S;
-    // scalar pre-computation in double, like the Python side of torch.optim.AdamW
-    S.decay = (float)(1.0 - lr * weight_decay);
-    S.one_m_b1 = (float)(1.0 - beta1);
-    S.b2 = (float)beta2;
-    S.one_m_b2 = (float)(1.0 - beta2);
-    S.neg_step = (float)(-(lr / (1.0 - pow(beta1, (double)step))));
-    S.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
-    S.eps = (float)eps;
-    S.grad_scale = (float)grad_scale;
-    S.scale_grad = grad_scale != 1.0;
+    const AdamScalars S = adam_scalars(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     int s = 0;
     while (s < n_segs) {
         AdamSegs A;

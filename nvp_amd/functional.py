@@ -77,14 +77,19 @@ class StepHooks:
       early_grads   callback([(parameter tensor, gradient tensor)]) fired as soon as those grid gradients have been enqueued - the
                     sparse grid's first, then the three planes' (optim.AdamW.early_update runs their AdamW on a side stream,
                     underneath the rest of the scatter and the dW GEMMs).  Only meaningful when each grid feeds ONE NVPFused call
-                    per step."""
-    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads")
+                    per step;
+      fused_sparse  an optimizer with fused_peek(tensor) / fused_commit(tensor) (optim.AdamW; one GPU, no grad_sink): the sparse
+                    grid's AdamW step is applied INSIDE the scatter's flush (nvp_encode_bwd_sparse_adamw) - its gradient is never
+                    written to HBM, backward returns None for it.  Falls back to the gradient + early_grads route when the
+                    optimizer declines (peek returns None) or the kernel does not support the layout."""
+    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse")
 
-    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None):
+    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None, fused_sparse=None):
         self.grad_sink, self.sparse_ready, self.grids_ready, self.early_grads = grad_sink, sparse_ready, grids_ready, early_grads
+        self.fused_sparse = fused_sparse
 
     def clear(self) -> None:
-        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = None
+        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = self.fused_sparse = None
 
 
 _NO_HOOKS = StepHooks()
@@ -494,7 +499,12 @@ class NVPFused(torch.autograd.Function):
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
         hk = ctx.hooks if ctx.hooks is not None else _NO_HOOKS
         sink = hk.grad_sink
-        d_xy, d_yt, d_xt, d_emb = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt, emb))
+        # one GPU: the sparse grid's optimizer step inside the scatter's flush (no gradient tensor for it at all)
+        fused_st = None
+        if hk.fused_sparse is not None and sink is None and (ctx.bflags & L.DZ_PLANES_READY):
+            fused_st = hk.fused_sparse.fused_peek(emb)
+        d_xy, d_yt, d_xt = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt))
+        d_emb = _grad_buffer(emb, sink) if fused_st is None else None
 
         # scatter workspace: allocated (and its coordinate-only part started) in forward
         ws, flags, presorted, lm = ctx.ws, ctx.bflags, ctx.presorted, None
@@ -528,7 +538,24 @@ class NVPFused(torch.autograd.Function):
             # for in front of the chain kernel: a second wait would only be one more marker on the compute queue
             if presorted is not None and packed_bwd is None:
                 torch.cuda.current_stream(coords.device).wait_event(presorted)
-            if (hk.sparse_ready is not None or hk.early_grads is not None) and (flags & L.DZ_PLANES_READY):
+            nonlocal d_emb, fused_st
+            if fused_st is not None:
+                f = fused_st
+                rc = _call("nvp_encode_bwd", lib.nvp_encode_bwd_sparse_adamw, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1], n,
+                           C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.ptr(ws, torch.uint8), ws_bytes, flags,
+                           L.ptr(emb), L.ptr(f["exp_avg"]), L.ptr(f["exp_avg_sq"]), f["lr"], f["beta1"], f["beta2"], f["eps"],
+                           f["weight_decay"], f["step"], L.stream_ptr())
+                if rc == L.ERR_UNSUPPORTED:             # layout the fused flush does not take: the gradient route after all
+                    fused_st = None
+                    d_emb = _grad_buffer(emb, sink)
+                else:
+                    L.check(rc, "nvp_encode_bwd_sparse_adamw")
+                    hk.fused_sparse.fused_commit(emb)
+            if fused_st is not None:
+                scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
+                if hk.early_grads is not None:
+                    hk.early_grads([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
+            elif (hk.sparse_ready is not None or hk.early_grads is not None) and (flags & L.DZ_PLANES_READY):
                 # the sparse grid (80 % of the gradient bytes) is scattered first and handed on - to the data-parallel exchange, or
                 # to the optimizer - while the dense planes are still being scattered
                 scatter_call(flags | L.SCATTER_SPARSE_ONLY)

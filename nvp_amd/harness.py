@@ -21,6 +21,9 @@ N_SAMPLES = 1245184          # reference dataio.py:91
 AFTER_BACKWARD_HOOK = None
 # one GPU, nvp_amd.optim.AdamW: update the grids on a side stream as soon as the scatter has produced their gradients (0: after backward)
 EARLY_ADAMW = os.environ.get("NVP_EARLY_ADAMW", "1") != "0"
+# one GPU, nvp_amd.optim.AdamW, y-sorted batches: the sparse grid's AdamW step is applied by the scatter kernel's flush
+# (nvp_encode_bwd_sparse_adamw; bit-identical parameters; 0: gradient tensor + early_update)
+FUSED_SPARSE_ADAMW = os.environ.get("NVP_FUSED_SPARSE_ADAMW", "1") != "0"
 
 
 class ImageMSEU8(torch.autograd.Function):
@@ -193,6 +196,8 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
         if EARLY_ADAMW and isinstance(opt, AdamW):
             opt.begin_step()                        # forget early updates of an iteration whose step() never ran (exception)
             hooks.early_grads = opt.early_update    # the grids' AdamW underneath the rest of backward (one GPU)
+            if FUSED_SPARSE_ADAMW:
+                hooks.fused_sparse = opt            # ... and the sparse grid's INSIDE the scatter's flush: its gradient never reaches HBM
     try:
         loss.backward(gradient=unit_gradient(loss.device) if loss.is_cuda else None)
     finally:

@@ -78,6 +78,32 @@ class AdamW(torch.optim.Optimizer):
                 self._early_done.add(id(p))
 
     @torch.no_grad()
+    def fused_peek(self, t: torch.Tensor):
+        """For a kernel that applies this optimizer's step to the parameter with storage `t` ITSELF (the scatter's flush:
+        nvp_encode_bwd_sparse_adamw): the state tensors and the scalars of the step that is due, WITHOUT advancing anything -
+        fused_commit() does that once the kernel has been enqueued.  None when the parameter is unknown to this optimizer, was
+        already stepped in this iteration, or already has a .grad (autograd would accumulate: the kernel's gradient alone is not
+        the gradient)."""
+        if self._by_ptr is None or any(p.data_ptr() != k for k, (p, _) in self._by_ptr.items()):
+            self._by_ptr = {p.data_ptr(): (p, g) for g in self.param_groups for p in g["params"]}
+        ent = self._by_ptr.get(t.data_ptr())
+        if ent is None or id(ent[0]) in self._early_done or ent[0].grad is not None:
+            return None
+        p, group = ent
+        st = self._state_of(p)
+        for x in (p, st["exp_avg"], st["exp_avg_sq"]):
+            _lib.ptr(x)
+        b1, b2 = group["betas"]
+        return {"param": p, "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"], "lr": float(group["lr"]), "beta1": float(b1),
+                "beta2": float(b2), "eps": float(group["eps"]), "weight_decay": float(group["weight_decay"]), "step": int(st["step"]) + 1}
+
+    def fused_commit(self, t: torch.Tensor) -> None:
+        """The kernel that took fused_peek()'s state has been enqueued on the compute stream: count the step, skip the parameter in step()."""
+        p, _ = self._by_ptr[t.data_ptr()]
+        self._state_of(p)["step"] += 1
+        self._early_done.add(id(p))
+
+    @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, schedule=None):
         """One AdamW update.  `grad_scale` multiplies every gradient inside the kernel (data parallel: 1/world
         after a SUM all-reduce of the flat gradient, which saves a separate scaling pass over 543 MB).

@@ -895,26 +895,32 @@ def test_early_grid_update_equals_the_in_order_optimizer_step():
     from nvp_amd.modules import NVP
     cfg = small_cfg(F=2, T=6, X=20, Y=20)          # 16 levels: the level-major hand-over and with it the sparse-first, two-call scatter are on
     video = torch.randint(0, 256, (6, 48, 64, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(dev())
+    # ... and the sparse grid's update applied INSIDE the scatter's flush (nvp_encode_bwd_sparse_adamw: its gradient tensor never
+    # exists) must give the same bits again
     results = []
-    for early in (True, False):
+    for early, fused in ((True, True), (True, False), (False, False)):
         torch.manual_seed(11)
         model = NVP(out_features=3, encoding_config=cfg).to(dev())
         data = harness.DeviceVideo(video, n_samples=20000, seed=5)
         opt, sched = harness.make_optimizer(model, total_steps=4)
-        old = harness.EARLY_ADAMW
-        harness.EARLY_ADAMW = early
+        old = harness.EARLY_ADAMW, harness.FUSED_SPARSE_ADAMW
+        harness.EARLY_ADAMW, harness.FUSED_SPARSE_ADAMW = early, fused
         try:
             for _ in range(4):
                 mi, gt = data.sample()
                 harness.train_step(model, opt, sched, mi, gt)
+                assert (model.sparse_grid.embeddings.grad is None) == fused      # the fused flush produces no gradient tensor
         finally:
-            harness.EARLY_ADAMW = old
+            harness.EARLY_ADAMW, harness.FUSED_SPARSE_ADAMW = old
         torch.cuda.synchronize()
         results.append(([p.detach().clone() for p in model.parameters()],
-                        [opt.state[p]["exp_avg_sq"].clone() for p in model.parameters()], [opt.state[p]["step"] for p in model.parameters()]))
-    (pa, va, sa), (pb, vb, sb) = results
-    assert sa == sb and all(x == 4 for x in sa)
+                        [opt.state[p]["exp_avg_sq"].clone() for p in model.parameters()] + [opt.state[p]["exp_avg"].clone() for p in model.parameters()],
+                        [opt.state[p]["step"] for p in model.parameters()]))
+    (pa, va, sa), (pf, vf, sf), (pb, vb, sb) = results
+    assert sa == sb == sf and all(x == 4 for x in sa)
     for a, b in zip(pa + va, pb + vb):
+        assert torch.equal(a, b), "fused sparse-grid update differs from the in-order optimizer step"
+    for a, b in zip(pf + vf, pb + vb):
         assert torch.equal(a, b), "early grid update differs from the in-order optimizer step"
 
 
