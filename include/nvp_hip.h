@@ -251,6 +251,14 @@ int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const
 int nvp_mse_u8(const float* rgb, const uint8_t* gt_u8, float* drgb, float* loss_sum,
                int64_t n, void* stream);
 
+
+/* Delivery order of a batch (harness: counterpart of sorting the reference sampler's draws, dataio.py:104-120, by image column):
+ * order[k] (int64, what torch.argsort returns) = index of the sample that comes k-th in ascending (pi % width), ties in drawing
+ * order (a stable sort).  One counting sort on the log2(width)-bit key; workspace from nvp_sample_order_workspace_bytes.
+ * NVP_ERR_UNSUPPORTED for width > 12288 (the per-chunk table lives in LDS): use a library sort then. */
+int64_t nvp_sample_order_workspace_bytes(int64_t n, int32_t width);
+int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int32_t width, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- row H helpers: on-device sampler (reference dataio.py:104-120) -------------------
  * ti [N], pi [N] int64 indices (drawn by the caller with torch.randint, temporal first,
  * same order as the reference); video u8 [T][H*W][3] resident on the device;

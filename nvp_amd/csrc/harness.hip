@@ -32,6 +32,96 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const uint8_t* __res
     gt[k * 3 + 2] = src[2];
 }
 
+// ---- delivery order of a batch: ascending image column, stable -----------------------------------------------------------------
+// order[k] = index of the sample that comes k-th when the batch is sorted by (pi % width), ties in drawing order - exactly what a
+// stable sort of the column keys gives (and what torch.argsort's radix sort delivered), as ONE counting sort on a key of
+// log2(width) bits: per-chunk histograms (key-major), one exclusive scan over (key, chunk), and a scatter in which one wave walks
+// its chunk in drawing order (rank among equal keys inside a 64-sample group from ballots, running per-key cursors in LDS).
+// Three small launches instead of the vendor sort's six (two radix passes, histogram, index initialisation, copies): the sampler
+// runs on a side stream underneath the forward kernel and every microsecond of it is taken from that kernel's workgroup slots.
+constexpr int kSortChunk = 4096;                 // samples per chunk (one histogram / scatter workgroup each)
+constexpr int kSortScanTile = 4096;              // scan: entries per workgroup (256 threads x 16)
+
+__global__ __launch_bounds__(256) void sort_hist_kernel(const int64_t* __restrict__ pi, unsigned* __restrict__ cnt, int64_t n, int width, int nchunks) {
+    extern __shared__ unsigned hist[];
+    for (int k = threadIdx.x; k < width; k += 256) hist[k] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+    for (int j = 0; j < kSortChunk / 256; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(unsigned)(pi[i] % width)], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < width; k += 256) cnt[(int64_t)k * nchunks + blockIdx.x] = hist[k];
+}
+
+__global__ __launch_bounds__(256) void sort_tilesum_kernel(const unsigned* __restrict__ cnt, unsigned* __restrict__ tsum, int64_t total) {
+    const int64_t k0 = (int64_t)blockIdx.x * kSortScanTile + threadIdx.x * 16;
+    unsigned sum = 0u;
+    for (int e = 0; e < 16; ++e) if (k0 + e < total) sum += cnt[k0 + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// in place: cnt[i] <- number of samples in (key, chunk) cells before cell i
+__global__ __launch_bounds__(256) void sort_scan_kernel(unsigned* __restrict__ cnt, const unsigned* __restrict__ tsum, int64_t total) {
+    __shared__ unsigned part[256];
+    __shared__ unsigned tile_base;
+    unsigned b = 0u;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) b += tsum[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o);
+    __shared__ unsigned red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_base = red[0] + red[1] + red[2] + red[3];
+    const int64_t k0 = (int64_t)blockIdx.x * kSortScanTile + threadIdx.x * 16;
+    unsigned v[16], sum = 0u;
+    for (int e = 0; e < 16; ++e) { v[e] = k0 + e < total ? cnt[k0 + e] : 0u; sum += v[e]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // 256 partial sums: a serial scan is a microsecond
+        unsigned run = tile_base;
+        for (int t = 0; t < 256; ++t) { const unsigned x = part[t]; part[t] = run; run += x; }
+    }
+    __syncthreads();
+    unsigned run = part[threadIdx.x];
+    for (int e = 0; e < 16; ++e) if (k0 + e < total) { cnt[k0 + e] = run; run += v[e]; }
+}
+
+// one wave per chunk, in drawing order
+__global__ __launch_bounds__(64) void sort_scatter_kernel(const int64_t* __restrict__ pi, const unsigned* __restrict__ cnt, int64_t* __restrict__ order,
+                                                          int64_t n, int width, int nchunks, int key_bits) {
+    extern __shared__ unsigned cursor[];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < width; k += 64) cursor[k] = cnt[(int64_t)k * nchunks + blockIdx.x];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = (int64_t)blockIdx.x * kSortChunk;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int g = 0; g < kSortChunk / 64; ++g) {
+        const int64_t i = base + g * 64 + lane;
+        const bool ok = i < n;                                       // wave-uniform except in the batch's last group
+        const unsigned key = ok ? (unsigned)(pi[i] % width) : 0xffffffffu;
+        unsigned long long same = __ballot(ok);
+        for (int b = 0; b < key_bits; ++b) {
+            const unsigned long long m = __ballot((key >> b) & 1u);
+            same &= ((key >> b) & 1u) ? m : ~m;
+        }
+        if (ok) {
+            const unsigned rank = (unsigned)__popcll(same & lt);
+            const unsigned pos = cursor[key] + rank;
+            order[pos] = i;
+            // the lane that comes last among its equals moves the key's cursor past all of them (every lane of the group has read it)
+            if ((same >> lane) == 1ull) cursor[key] = pos + 1u;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(1024) void mse_u8_kernel(const float* __restrict__ rgb, const uint8_t* __restrict__ gt,
                                                      float* __restrict__ drgb, float* __restrict__ loss_sum,
                                                      int64_t n3, float gscale) {
@@ -88,6 +178,33 @@ int nvp_sample_gather(const uint8_t* video, const int64_t* ti, const int64_t* pi
     if (n == 0) return 0;
     hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        video, ti, pi, order, tcoord_tab, tstep_tab, coords, steps, gt_u8, n, height, width);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int64_t nvp_sample_order_workspace_bytes(int64_t n, int32_t width) {
+    if (n < 0 || width < 1) return NVP_ERR_BADARG;
+    const int64_t nchunks = (n + kSortChunk - 1) / kSortChunk, total = nchunks * width;
+    return (total + (total + kSortScanTile - 1) / kSortScanTile + 64) * 4;
+}
+
+// order[k] (int64, as torch.argsort returns) = index of the k-th sample in ascending image column (pi % width), ties in drawing order
+int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int32_t width, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!pi || !order || !workspace || n < 0 || width < 1) return NVP_ERR_BADARG;
+    if (width > 12288 || n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;          // the per-chunk table lives in LDS
+    if (workspace_bytes < nvp_sample_order_workspace_bytes(n, width)) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    const int nchunks = (int)((n + kSortChunk - 1) / kSortChunk);
+    const int64_t total = (int64_t)nchunks * width;
+    const unsigned ntiles = (unsigned)((total + kSortScanTile - 1) / kSortScanTile);
+    unsigned* cnt = (unsigned*)workspace;
+    unsigned* tsum = cnt + total;
+    int key_bits = 1;
+    while ((1 << key_bits) < width) ++key_bits;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nchunks), dim3(256), (size_t)width * 4, (hipStream_t)stream, pi, cnt, n, width, nchunks);
+    hipLaunchKernelGGL(sort_tilesum_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const unsigned*)cnt, tsum, total);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, cnt, (const unsigned*)tsum, total);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nchunks), dim3(64), (size_t)width * 4, (hipStream_t)stream, pi, (const unsigned*)cnt, order, n, width, nchunks, key_bits);
     NVP_LAUNCH_CHECK();
     return 0;
 }

@@ -24,6 +24,7 @@ EARLY_ADAMW = os.environ.get("NVP_EARLY_ADAMW", "1") != "0"
 # one GPU, nvp_amd.optim.AdamW, y-sorted batches: the sparse grid's AdamW step is applied by the scatter kernel's flush
 # (nvp_encode_bwd_sparse_adamw; bit-identical parameters; 0: gradient tensor + early_update)
 FUSED_SPARSE_ADAMW = os.environ.get("NVP_FUSED_SPARSE_ADAMW", "1") != "0"
+SAMPLER_SORT = os.environ.get("NVP_SAMPLER_SORT", "nvp")        # "torch": torch.argsort for the sampler's column order
 
 
 class ImageMSEU8(torch.autograd.Function):
@@ -132,7 +133,20 @@ class DeviceVideo:
             # is permutation-invariant; the order gives the grid gathers row locality and lets the
             # gradient scatter skip one sort (NVP_COORDS_SORTED_BY_Y).  The gather kernel applies the permutation.
             # 16-bit keys halve the radix passes; wider frames than 32 767 columns keep 32-bit keys (int16 would wrap)
-            order = torch.argsort((pi % self.W).to(torch.int16 if self.W <= 32767 else torch.int32))
+            # a stable counting sort on the column key (nvp_sample_order_by_column: three small launches; the vendor sort needed six);
+            # NVP_SAMPLER_SORT=torch keeps torch.argsort (same order: its radix sort is stable too)
+            order = None
+            if SAMPLER_SORT != "torch":
+                ws_bytes = lib.nvp_sample_order_workspace_bytes(n, self.W)
+                ws = torch.empty(max(int(ws_bytes), 4), device=dev, dtype=torch.uint8)
+                order = torch.empty(n, device=dev, dtype=torch.int64)
+                rc = lib.nvp_sample_order_by_column(L.ptr(pi, torch.int64), L.ptr(order, torch.int64), n, self.W, L.ptr(ws, torch.uint8), ws.numel(), L.stream_ptr())
+                if rc == L.ERR_UNSUPPORTED:
+                    order = None
+                else:
+                    L.check(rc, "nvp_sample_order_by_column")
+            if order is None:
+                order = torch.argsort((pi % self.W).to(torch.int16 if self.W <= 32767 else torch.int32), stable=True)
         coords = torch.empty((n, 3), device=dev, dtype=torch.float32)
         steps = torch.empty((n,), device=dev, dtype=torch.float32)
         gt = torch.empty((n, 3), device=dev, dtype=torch.uint8)

@@ -1031,6 +1031,24 @@ def _oracle_frame(sd, cfg, f, org_nframes, res, nframes, temporal_interp, n_slic
     return torch.clamp((out.reshape(Hq, Wq, 3) + 1) / 2, 0, 1)
 
 
+@pytest.mark.parametrize("n,width", [(1, 7), (63, 5), (4097, 1920), (300000, 1920), (50000, 3840), (70001, 12288)])
+def test_sample_order_is_the_stable_sort_by_column(n, width):
+    """nvp_sample_order_by_column (the sampler's delivery order): the indices of a STABLE sort of the column keys pi % width - the
+    same permutation torch.argsort(stable=True) returns, whatever the chunking does to equal keys."""
+    from nvp_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(n + width)
+    pi = torch.randint(0, 1080 * width, (n,), generator=g).to(dev())
+    if n > 1000:
+        pi[: n // 3] = pi[0] - (pi[0] % width) + 3 % width            # a long run of one key across many chunks
+    ws = torch.empty(int(lib.nvp_sample_order_workspace_bytes(n, width)), device=dev(), dtype=torch.uint8)
+    order = torch.full((n,), -1, device=dev(), dtype=torch.int64)
+    L.check(lib.nvp_sample_order_by_column(L.ptr(pi, torch.int64), L.ptr(order, torch.int64), n, width, L.ptr(ws, torch.uint8), ws.numel(), L.stream_ptr()), "order")
+    want = torch.argsort(pi % width, stable=True)
+    assert torch.equal(order, want)
+    assert lib.nvp_sample_order_by_column(L.ptr(pi, torch.int64), L.ptr(order, torch.int64), n, 20000, L.ptr(ws, torch.uint8), ws.numel(), L.stream_ptr()) == L.ERR_UNSUPPORTED
+
+
 def test_eval_drivers_t_interp_and_s_interp_vs_oracle():
     from nvp_amd import harness
     T, H, W = 6, 20, 30
