@@ -253,3 +253,14 @@ def mlp_params_struct(tensors: Sequence[torch.Tensor]) -> MlpParams:
     s.last_w = ptr(tensors[12])
     s.last_b = ptr(tensors[13])
     return s
+
+
+def side_stream(dev) -> "torch.cuda.Stream":
+    """A side stream for work that should run UNDERNEATH the compute stream's kernels (sampler, coordinate-only scatter kernels,
+    weight packing, early optimizer updates).  NVP_SIDE_PRIORITY (integer, default: unset = the default priority): a LOWER
+    priority than the compute stream's (a larger number in HIP's convention) makes the dispatcher prefer the compute stream's
+    workgroups whenever both have some ready."""
+    pr = os.environ.get("NVP_SIDE_PRIORITY")
+    if pr is None or pr == "":
+        return torch.cuda.Stream(device=dev)
+    return torch.cuda.Stream(device=dev, priority=int(pr))

@@ -59,7 +59,7 @@ def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = _SIDE_STREAMS.get(idx)
     if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=dev)
+        st = _SIDE_STREAMS[idx] = L.side_stream(dev)
     return st
 
 class StepHooks:

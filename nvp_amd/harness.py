@@ -92,7 +92,7 @@ class DeviceVideo:
         # small latency-bound kernels - two randint, a 16-bit argsort, a 3-byte gather - that depends on nothing the step
         # computes); same draws, same order of batches as without it.  Worth 0.05 ms of a 7.5-ms step on MI355X (the sampler's
         # ~0.2 ms of small kernels hide underneath the gather / MLP kernels, which slow down by 0.06 ms): bench.py and train.py turn it on
-        self._side = torch.cuda.Stream(device=dev) if (prefetch and video_u8.is_cuda) else None
+        self._side = L.side_stream(dev) if (prefetch and video_u8.is_cuda) else None
         self._next = None
 
     def sample(self) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:

@@ -51,7 +51,7 @@ class AdamW(torch.optim.Optimizer):
         lib = _lib.load()
         dev = pairs[0][0].device
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            self._side = _lib.side_stream(dev)
         ready = torch.cuda.Event()
         ready.record()                                        # the gradients are complete at this point of the compute stream
         self._side.wait_event(ready)
