@@ -501,7 +501,7 @@ class NVPFused(torch.autograd.Function):
         sink = hk.grad_sink
         # one GPU: the sparse grid's optimizer step inside the scatter's flush (no gradient tensor for it at all)
         fused_st = None
-        if hk.fused_sparse is not None and sink is None and (ctx.bflags & L.DZ_PLANES_READY):
+        if hk.fused_sparse is not None and sink is None and (ctx.bflags & L.DZ_PLANES_READY) and ctx.needs_input_grad[5]:       # [5]: emb
             fused_st = hk.fused_sparse.fused_peek(emb)
         d_xy, d_yt, d_xt = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt))
         d_emb = _grad_buffer(emb, sink) if fused_st is None else None
