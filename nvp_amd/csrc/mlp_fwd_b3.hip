@@ -142,7 +142,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __res
     if (!active) tile = ntiles - 1;                   // walks the barriers; its (duplicate) results are not stored
 #else
 #define NVP_LAYER_SYNC()
-    const int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
+#ifndef NVP_FWD_XCD_REMAP
+#define NVP_FWD_XCD_REMAP 0      // 1 (fused gather only): workgroup b -> tile group (b % 8) * (blocks / 8) + b / 8: every XCD walks its own contiguous range of the
+#endif                           // y-sorted batch, so the xy / yt grid rows a range touches are filled into ONE XCD's L2 instead of all eight
+    int64_t blk = blockIdx.x;
+    if (NVP_FWD_XCD_REMAP && GF != 0 && (gridDim.x & 7) == 0) blk = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t tile = blk * kWaves + wv;
     if (tile >= ntiles) return;                       // wave-uniform
     const bool active = true;
 #endif
