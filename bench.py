@@ -217,10 +217,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prewarm", type=int, default=0,
-                    help="extra untimed steps BEFORE the --warmup steps (reported as prewarm_steps).  Off by default: a first process on a "
-                         "fresh box was seen twice at 8.9 instead of 6.8 ms per step, but not reproducibly, and 100 extra steps made "
-                         "the timed ones 0.05 ms SLOWER (6.86-6.88 vs 6.77-6.85 ms: the board runs at its power limit and warms up)")
+    ap.add_argument("--prewarm", type=int, default=5,
+                    help="extra untimed steps BEFORE the --warmup steps (reported as prewarm_steps): lazy initialisation and clock ramp take about "
+                         "ten steps to settle whatever --warmup the caller passes (same box, 10 timed steps: 15.6 / 7.14 / 7.08 / 6.97 / 6.92 ms "
+                         "per step after 0 / 1 / 2 / 3 / 5 untimed ones); many more do not help - 100 made the timed steps 0.05 ms SLOWER "
+                         "(the board runs at its power limit and warms up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=N_PX // 8)
     ap.add_argument("--config", choices=list(WORKLOADS), default="s",
