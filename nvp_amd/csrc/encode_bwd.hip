@@ -500,18 +500,48 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     const float* dz = A.dzs[plane] + (int64_t)level * n * F;
     const int span = (r1 - r0) * res;
     const int base = r0 * res;
+    // The visit of pixel kk + kBandThreads is REQUESTED (coordinates and latent gradient: 8 + 4 F bytes) before pixel kk is worked
+    // on: the loop body is ~40 VALU operations and a few LDS atomics behind two loads, and left to itself every trip waited out
+    // its own round trip (NVP_BAND_PREFETCH=0: the plain loop).
+#ifndef NVP_BAND_PREFETCH
+#define NVP_BAND_PREFETCH 1
+#endif
+    auto visit_index = [&](int kk) { return kk < lenX ? loX + kk : (kk < lenX + lenA ? loA + (kk - lenX) : loW + (kk - lenX - lenA)); };
+    float2 c_nx = make_float2(0.f, 0.f);
+    float g_nx[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) g_nx[f] = 0.f;
+    if (NVP_BAND_PREFETCH && kb + (int)threadIdx.x < ke) {
+        const int p = visit_index(kb + threadIdx.x);
+        c_nx = cs[p];
+#pragma unroll
+        for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)p * F + f];
+    }
     for (int kk = kb + threadIdx.x; kk < ke; kk += kBandThreads) {
         const bool extra = kk < lenX;
-        const int p = extra ? loX + kk : (kk < lenX + lenA ? loA + (kk - lenX) : loW + (kk - lenX - lenA));
-        const float2 c = cs[p];
+        const int p = visit_index(kk);
+        float2 c;
+        float g[F];
+        if (NVP_BAND_PREFETCH) {
+            c = c_nx;
+#pragma unroll
+            for (int f = 0; f < F; ++f) g[f] = g_nx[f];
+            if (kk + kBandThreads < ke) {
+                const int pn = visit_index(kk + kBandThreads);
+                c_nx = cs[pn];
+#pragma unroll
+                for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)pn * F + f];
+            }
+        } else {
+            c = cs[p];
+        }
         const float p0 = nvp_grid_pos(c.x, scale, lflags), p1 = nvp_grid_pos(c.y, scale, lflags);
         const float f0 = floorf(p0), f1 = floorf(p1);
         const int i0 = (int)f0, i1 = (int)f1;
         if (extra && ((lflags & NVP_GRID_CLAMP) || i0 + 1 < res)) continue;      // row r0-2 only reaches row r0 through the wrap
-        float g[F];
         bool any = false;
 #pragma unroll
-        for (int f = 0; f < F; ++f) { g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
+        for (int f = 0; f < F; ++f) { if (!NVP_BAND_PREFETCH) g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
         // cells first: a visit that touches no row of this band ends here, before any weight or conversion is computed
         int off[4];
         bool hit = false;
