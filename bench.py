@@ -212,6 +212,28 @@ def eval_bench(args, dev):
     print(json.dumps(line))
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks of this same command under torch.distributed.run on
+    127.0.0.1 (one process per GPU, RCCL), wait for them, return their exit status.  Refuses (2) when the node has fewer than N
+    devices - N ranks sharing devices over RCCL would be a mislabelled point - unless NVP_DIST_BACKEND=gloo (the one-GPU smoke test
+    of the multi-rank code path)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("NVP_DIST_BACKEND") != "gloo":
+        print(f"bench.py: --gpus {n} but this node shows {have} HIP device(s): no result line", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -238,14 +260,25 @@ def main():
                          "before the warm-up and keep the fastest (all ranks agree through a MAX all-reduce of the timings)")
     args = ap.parse_args()
 
+    # ---- plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment): launch the N ranks ourselves, exactly as the
+    # documented torch.distributed.run line does, and hand their exit status back.  Either launch style prints the same one JSON line.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
     from nvp_amd import _lib, functional, harness, parallel
     from nvp_amd.modules import NVP
     import torch.distributed as dist
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        # a line whose n_gpus differs from what the caller asked for would be read as a point of the scaling curve it is not: refuse
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to print a mislabelled line "
+                  f"(launch {args.gpus} ranks, or pass --gpus {world_env})", file=sys.stderr)
+        sys.exit(2)
     rank, world, local = parallel.init_distributed()
-    if world != args.gpus:
-        if rank == 0 and args.gpus > 1:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if os.environ.get("NVP_DIST_BACKEND") == "gloo":
         local = 0                              # smoke test: every rank on the one GPU of the box

@@ -287,3 +287,36 @@ def test_bench_two_ranks_through_the_scheme_autotune():
     assert all(v is not None for v in d["dp"]["autotune_ms_per_step"].values()), d["dp"]      # no scheme raised or diverged
     assert d["dp"]["mode"] in d["dp"]["autotune_ms_per_step"]
     assert abs(d["value"] - 2 * d["config"]["pixels_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+
+
+def test_bench_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the way the driver starts the N = 1 run): bench.py must start the two ranks
+    itself (bench.self_launch -> torch.distributed.run on 127.0.0.1) and print ONE line with n_gpus == 2 and the dp object - never
+    an n_gpus: 1 line.  Both ranks share the box's one GPU over gloo (NVP_DIST_BACKEND=gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"NVP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0",
+                        "--no-cpu-baseline", "--dp", "sharded"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dp"]["mode"] == "sharded" and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * d["config"]["pixels_per_gpu_step"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="box has two devices: the plain launch would legitimately run")
+def test_bench_plain_launch_refuses_more_ranks_than_devices():
+    """--gpus 2 on a one-GPU box over RCCL: no line, non-zero exit (a two-ranks-on-one-device run would be a mislabelled point)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NVP_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

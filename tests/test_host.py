@@ -318,3 +318,32 @@ def test_video_loaders_and_eval_slices(tmp_path):
     assert out.shape == (2, 12, 16, 3) and int(out.min()) == int(out.max()) == 128
     assert harness.eval_slices(1920 * 1080) == 100 and harness.eval_slices(3840 * 2160) == 100      # eval.py:233: Nslice = 100
     assert harness.eval_slices(64 * 64) == 64 and (97 * 89) % harness.eval_slices(97 * 89) == 0
+
+
+def _run_bench(argv, env_extra, drop=()):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NVP_DIST_BACKEND") + tuple(drop)}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_refuses_a_line_whose_n_gpus_is_not_what_was_asked():
+    """`--gpus 8` inside a 1-rank world used to print an n_gpus: 1 line; now it exits non-zero with no line."""
+    r = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode == 2 and "mislabelled" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "1"})
+    assert r.returncode == 2 and not r.stdout.strip()
+
+
+def test_bench_plain_multi_gpu_launch_needs_the_devices():
+    """`python bench.py --gpus 2` with no WORLD_SIZE self-launches its ranks; in this container (no HIP device) it must refuse
+    rather than start ranks that cannot own a GPU each."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode == 2 and "no result line" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
