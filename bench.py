@@ -33,6 +33,73 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _cpulist(text: str):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def apply_cpu_policy() -> dict:
+    """Thread / NUMA policy of the cpu_baseline leg, applied BEFORE torch (and its OpenMP pool) is loaded, in a process of its own:
+    one hardware thread per PHYSICAL core of every socket the process may run on ("all physical cores"), the
+    OpenMP threads bound to those cores, and - on hosts with more than one NUMA node - page allocation INTERLEAVED across the nodes
+    (set_mempolicy(MPOL_INTERLEAVE)): with first-touch placement the 543 MB gradient tensors of the oracle land on whichever socket
+    the touching thread happens to run on, and the rate moved by 2x between two boxes of the same CPU model.  If the
+    kernel refuses the memory policy (seccomp), the threads are pinned to the physical cores of NUMA node 0 alone instead.
+    Returns what was applied; the caller reports it inside the cpu_baseline object."""
+    import ctypes
+    allowed = sorted(os.sched_getaffinity(0))
+    phys = []
+    for c in allowed:
+        try:
+            sib = _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read())
+        except OSError:
+            sib = [c]
+        if c == min(x for x in sib if x in allowed):
+            phys.append(c)
+    nodes = {}
+    try:
+        for d in sorted(os.listdir("/sys/devices/system/node")):
+            if d.startswith("node") and d[4:].isdigit():
+                cs = [c for c in _cpulist(open(f"/sys/devices/system/node/{d}/cpulist").read()) if c in phys]
+                if cs:
+                    nodes[int(d[4:])] = cs
+    except OSError:
+        pass
+    policy = {"numa_nodes": len(nodes) or 1, "allowed_cpus": len(allowed), "physical_cores": len(phys)}
+    use = phys
+    if len(nodes) > 1:
+        mask = ctypes.c_ulong(sum(1 << k for k in nodes))
+        rc = -1
+        try:
+            libc = ctypes.CDLL(None, use_errno=True)
+            rc = libc.syscall(238, 3, ctypes.byref(mask), ctypes.c_ulong(max(nodes) + 2))       # x86-64 set_mempolicy(MPOL_INTERLEAVE, nodemask, maxnode)
+        except Exception:                                                                        # noqa: BLE001
+            rc = -1
+        if rc == 0:
+            policy["memory"] = f"interleaved over NUMA nodes {sorted(nodes)} (set_mempolicy MPOL_INTERLEAVE)"
+        else:
+            use = nodes[min(nodes)]
+            policy["memory"] = f"first touch; threads pinned to NUMA node {min(nodes)} only (set_mempolicy refused)"
+    else:
+        policy["memory"] = "single NUMA node: first touch"
+    os.sched_setaffinity(0, set(use))
+    os.environ["OMP_NUM_THREADS"] = str(len(use))
+    os.environ["MKL_NUM_THREADS"] = str(len(use))
+    os.environ["OMP_PROC_BIND"] = "close"
+    os.environ["OMP_PLACES"] = "cores"
+    policy["threads"] = len(use)
+    policy["binding"] = "sched_setaffinity to one hardware thread per physical core, OMP_PROC_BIND=close OMP_PLACES=cores"
+    return policy
+
+
+CPU_POLICY = apply_cpu_policy() if "--cpu-baseline-only" in sys.argv else None
+
 import torch  # noqa: E402
 
 CONFIG_NVP_S = {  # values of the reference's config/config_nvp_s.json
@@ -111,6 +178,20 @@ def cpu_model() -> str:
 
 
 def cpu_baseline(n_sample: int, reps: int = 3):
+    """The cpu_baseline leg in a PROCESS OF ITS OWN (`bench.py --cpu-baseline-only`): its thread / NUMA policy (apply_cpu_policy) must be
+    in place before torch's OpenMP pool exists, and this process's pool was created long ago.  Returns the worker's JSON object."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""            # the worker is CPU-only
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", str(n_sample), "--cpu-reps", str(reps)],
+                       env=env, capture_output=True, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu_baseline worker failed (rc {r.returncode}): {r.stderr[-1500:]}")
+    return json.loads(lines[-1])
+
+
+def cpu_baseline_worker(n_sample: int, reps: int = 3):
     """the oracle's fwd+bwd (incl. the dense grid gradients, as the reference's autograd produces
     them; optimizer excluded) on this host's cores, 1 warm-up + `reps` timed evaluations.  A full N = 1 245 184 step takes
     more than 60 s here, so the sample is N/8 = 155 648 pixels of the same batch distribution and the rate is quoted per
@@ -140,7 +221,8 @@ def cpu_baseline(n_sample: int, reps: int = 3):
     times.sort()
     med = times[len(times) // 2]
     rate = lambda t: round(n_sample / t / 1e6, 6)      # noqa: E731
-    return {"value": rate(med), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port",
+    par = [ln.strip() for ln in torch.__config__.parallel_info().splitlines() if any(k in ln for k in ("get_num_threads", "omp_get_max_threads", "mkl_get_max_threads", "ATen parallel backend"))]
+    return {"value": rate(med), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port", "policy": CPU_POLICY, "torch_parallel_info": par,
             "min": rate(times[-1]), "median": rate(med), "max": rate(times[0]),
             "seconds_per_sample_step": [round(t, 3) for t in times], "extrapolated_seconds_per_full_step": round(med * N_PX / n_sample, 1),
             "cpu": cpu_model(),
@@ -246,6 +328,10 @@ def main():
                          "(the board runs at its power limit and warms up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=N_PX // 8)
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="worker mode of the cpu_baseline leg: apply the thread / NUMA policy, time the oracle on --cpu-sample pixels, print the "
+                         "cpu_baseline object as one JSON line (no GPU is touched)")
     ap.add_argument("--config", choices=list(WORKLOADS), default="s",
                     help="s = BASELINE.json configs[1] (the headline line); l = configs[2] (nvp_l, 1080p x 300); 4k = configs[3] (nvp_l, 4K x 300)")
     ap.add_argument("--mode", choices=["train", "eval"], default="train",
@@ -254,11 +340,19 @@ def main():
     ap.add_argument("--no-isolate", action="store_true",
                     help="N = 1: skip the second timed pass with every side stream off (sampler prefetch, scatter presort / weight packing, "
                          "early AdamW), whose per-stage times are recorded beside the overlapped ones as 'isolated'")
+    ap.add_argument("--no-reference-surface", action="store_true",
+                    help="N = 1: skip the third timed pass that drives the model the way the reference's training.py:42-76 does (raw-order "
+                         "batches, torch-expression MSE, torch.optim.AdamW), recorded as 'reference_surface'")
     ap.add_argument("--dp", choices=["auto", "sharded", "a2a", "replicated"], default=os.environ.get("NVP_DP_MODE", "auto"),
                     help="N > 1 gradient exchange: sharded = reduce-scatter + sharded AdamW + all-gather (ZeRO-1), a2a = the same with the "
                          "one-hop all_to_all exchange, replicated = chunked all-reduce + full AdamW; auto = time 3 untimed steps of each "
                          "before the warm-up and keep the fastest (all ranks agree through a MAX all-reduce of the timings)")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        if CPU_POLICY and torch.get_num_threads() != CPU_POLICY["threads"]:
+            torch.set_num_threads(CPU_POLICY["threads"])
+        print(json.dumps(cpu_baseline_worker(args.cpu_sample, args.cpu_reps)))
+        return
 
     # ---- plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment): launch the N ranks ourselves, exactly as the
     # documented torch.distributed.run line does, and hand their exit status back.  Either launch style prints the same one JSON line.
@@ -465,6 +559,46 @@ def main():
         finally:
             functional.TIMER = None
             harness.EARLY_ADAMW, functional.SIDE_WORK, data._side = keep
+    # ---- third pass, N = 1: the REFERENCE SURFACE.  The model driven exactly as the reference's loop drives it (training.py:42-76):
+    # batches in the sampler's raw order (no sorted_by_y promise), model(model_input)['model_out'], the torch-expression MSE on the
+    # normalised ground truth (training.py:47-48, loss_functions.py:1-3), zero_grad / backward / step of a stock torch.optim.AdamW +
+    # CosineAnnealingLR (training.py:13-14,73-76) - no StepHooks, no nvp_amd.harness.train_step, no nvp_amd.optim.  What an unmodified
+    # caller gets from the drop-in modules; the headline above is what nvp_amd's own loop gets from the same kernels.
+    ref_surface = None
+    if world == 1 and not multi and not args.no_reference_surface and args.steps > 0:
+        torch.cuda.synchronize()
+        del state
+        torch.cuda.empty_cache()
+        rdata = harness.DeviceVideo(video, n_samples=N_PX, seed=777, sort_by_y=False, prefetch=False)
+        ropt = torch.optim.AdamW(lr=1e-2, params=model.parameters(), weight_decay=0.001)              # training.py:13
+        rsched = torch.optim.lr_scheduler.CosineAnnealingLR(ropt, T_max=max(total, 1), eta_min=1e-5)   # training.py:14
+        for p_ in model.parameters():
+            p_.grad = None
+
+        def ref_step():
+            mi, gt = rdata.sample()
+            gt_img = (gt["img"].float() - 127.5) / 127.5                                                 # training.py:47-48
+            out = model(mi)                                                                              # training.py:50
+            loss_ = ((out["model_out"] - gt_img) ** 2).mean()                                            # loss_functions.image_mse
+            ropt.zero_grad()                                                                             # training.py:73-76
+            loss_.backward()
+            ropt.step()
+            rsched.step()
+            return loss_
+
+        for _ in range(3):
+            ref_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rloss = ref_step()
+        barrier()
+        rdt = (time.perf_counter() - t0) / args.steps * 1e3
+        ref_surface = {"what": "same workload through the reference's own loop shape (training.py:42-76): raw-order batches, model(mi)['model_out'], torch-expression "
+                               "MSE, zero_grad / backward / torch.optim.AdamW.step / CosineAnnealingLR.step; no StepHooks, no nvp_amd.harness / nvp_amd.optim",
+                       "ms_per_step": round(rdt, 3), "mpx_s": round(N_PX / (rdt * 1e-3) / 1e6, 3), "steps": args.steps, "final_loss": float(rloss),
+                       "optimizer": "torch.optim.AdamW (default implementation)", "row_order": functional.ROW_ORDER}
+        del ropt, rsched, rdata
     verify_replicas(mode + " (after the timed steps)")
     post_ms = sum(a.elapsed_time(b) for a, b in post_bwd) / max(len(post_bwd), 1)
     post_all = [post_ms]
@@ -568,6 +702,7 @@ def main():
             "stage_event_steps": n_inst,
             "prewarm_steps": args.prewarm,
             "isolated": iso_line,
+            "reference_surface": (dict(ref_surface, ratio_to_headline=round(ref_surface["ms_per_step"] / ms_per_step, 3)) if ref_surface else None),
         }
         if multi:
             # what a rank spends between the end of backward and the end of the optimizer: exposed gradient exchange + its share

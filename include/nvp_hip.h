@@ -259,6 +259,16 @@ int nvp_mse_u8(const float* rgb, const uint8_t* gt_u8, float* drgb, float* loss_
 int64_t nvp_sample_order_workspace_bytes(int64_t n, int32_t width);
 int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int32_t width, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Row order of an ARBITRARY batch - what a drop-in caller delivers (the reference sampler's raw order, dataio.py:104-120; replaces
+ * the library argsort nvp_amd.functional.NVPFused used for such batches).  order[k] (int64) = index of the sample that comes k-th in
+ * ascending key(y) = sum over the levels of the xy / yt planes' grid row index of coords[:,2] (both planes are indexed by y,
+ * modules.py:61,63), ties in input order (stable, hence deterministic).  A batch gathered in this order has non-decreasing grid rows
+ * at every level, which is all NVP_COORDS_SORTED_BY_Y promises the scatter.  One counting sort; NVP_ERR_UNSUPPORTED when the key
+ * space exceeds 12 288 (level geometries far beyond the reference's configs): use a library sort of coords[:,2] then. */
+int64_t nvp_order_by_rows_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt);
+int nvp_order_by_rows(const float* coords, int64_t* order, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- row H helpers: on-device sampler (reference dataio.py:104-120) -------------------
  * ti [N], pi [N] int64 indices (drawn by the caller with torch.randint, temporal first,
  * same order as the reference); video u8 [T][H*W][3] resident on the device;

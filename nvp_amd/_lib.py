@@ -98,6 +98,8 @@ SIGNATURES = {
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],
     "nvp_sample_order_workspace_bytes": [_i64, _i32],
     "nvp_sample_order_by_column": [_p, _p, _i64, _i32, _vp, _i64, _vp],
+    "nvp_order_by_rows_workspace_bytes": [_i64, C.POINTER(Levels), C.POINTER(Levels)],
+    "nvp_order_by_rows": [_p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), _vp, _i64, _vp],
     "nvp_sample_gather": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _vp],
     "nvp_adamw_step": [C.POINTER(AdamwSeg), _i32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, C.c_double, _vp],
     "nvp_packed_fwd_floats": [_i32],
@@ -109,7 +111,7 @@ SIGNATURES = {
     "nvp_mlp_mfma_products": [],
 }
 _RESTYPES = {
-    "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64, "nvp_sample_order_workspace_bytes": _i64,
+    "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64, "nvp_sample_order_workspace_bytes": _i64, "nvp_order_by_rows_workspace_bytes": _i64,
     "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
     "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32, "nvp_mlp_mfma_products": _i32, "nvp_encode_mlp_fwd_supported": _i32,
 }

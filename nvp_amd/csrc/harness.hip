@@ -2,7 +2,7 @@
 // the batch gather of dataio.py:104-120 with the video resident in HBM, and image_mse
 // (loss_functions.py:1-3 after the (x-127.5)/127.5 normalisation of training.py:47-48)
 // fused with its own gradient.
-#include "nvp_common.h"
+#include "grid_math.h"
 
 // __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
 // index and interpolation arithmetic keeps the reference's separately rounded multiply and add.
@@ -42,14 +42,19 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const uint8_t* __res
 constexpr int kSortChunk = 4096;                 // samples per chunk (one histogram / scatter workgroup each)
 constexpr int kSortScanTile = 4096;              // scan: entries per workgroup (256 threads x 16)
 
-__global__ __launch_bounds__(256) void sort_hist_kernel(const int64_t* __restrict__ pi, unsigned* __restrict__ cnt, int64_t n, int width, int nchunks) {
+// key of sample i: its image column (pi % width), or - `keys` given - a precomputed key in [0, width)
+__device__ __forceinline__ unsigned sort_key(const int64_t* __restrict__ pi, const unsigned* __restrict__ keys, int64_t i, int width) {
+    return keys ? min(keys[i], (unsigned)(width - 1)) : (unsigned)(pi[i] % width);
+}
+
+__global__ __launch_bounds__(256) void sort_hist_kernel(const int64_t* __restrict__ pi, const unsigned* __restrict__ keys, unsigned* __restrict__ cnt, int64_t n, int width, int nchunks) {
     extern __shared__ unsigned hist[];
     for (int k = threadIdx.x; k < width; k += 256) hist[k] = 0u;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kSortChunk;
     for (int j = 0; j < kSortChunk / 256; ++j) {
         const int64_t i = base + j * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&hist[(unsigned)(pi[i] % width)], 1u);
+        if (i < n) atomicAdd(&hist[sort_key(pi, keys, i, width)], 1u);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < width; k += 256) cnt[(int64_t)k * nchunks + blockIdx.x] = hist[k];
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(unsigned* __restrict__ c
 }
 
 // one wave per chunk, in drawing order
-__global__ __launch_bounds__(64) void sort_scatter_kernel(const int64_t* __restrict__ pi, const unsigned* __restrict__ cnt, int64_t* __restrict__ order,
+__global__ __launch_bounds__(64) void sort_scatter_kernel(const int64_t* __restrict__ pi, const unsigned* __restrict__ keys, const unsigned* __restrict__ cnt, int64_t* __restrict__ order,
                                                           int64_t n, int width, int nchunks, int key_bits) {
     extern __shared__ unsigned cursor[];
     const int lane = threadIdx.x;
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(64) void sort_scatter_kernel(const int64_t* __restr
     for (int g = 0; g < kSortChunk / 64; ++g) {
         const int64_t i = base + g * 64 + lane;
         const bool ok = i < n;                                       // wave-uniform except in the batch's last group
-        const unsigned key = ok ? (unsigned)(pi[i] % width) : 0xffffffffu;
+        const unsigned key = ok ? sort_key(pi, keys, i, width) : 0xffffffffu;
         unsigned long long same = __ballot(ok);
         for (int b = 0; b < key_bits; ++b) {
             const unsigned long long m = __ballot((key >> b) & 1u);
@@ -120,6 +125,18 @@ __global__ __launch_bounds__(64) void sort_scatter_kernel(const int64_t* __restr
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// key(y) of every sample: sum over the levels of the (clamped) grid row index, as encode_bwd.hip's keys_kernel computes it
+__global__ __launch_bounds__(256) void row_keys_kernel(const float* __restrict__ coords, unsigned* __restrict__ keys, nvp_levels lv0, nvp_levels lv1, int both, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float y = coords[i * 3 + 2];
+    unsigned key = 0u;
+    for (int l = 0; l < lv0.n_levels; ++l) key += (unsigned)min(max((int)floorf(nvp_grid_pos(y, lv0.scale[l], lv0.flags)), 0), lv0.res[l] + 1);
+    if (both)
+        for (int l = 0; l < lv1.n_levels; ++l) key += (unsigned)min(max((int)floorf(nvp_grid_pos(y, lv1.scale[l], lv1.flags)), 0), lv1.res[l] + 1);
+    keys[i] = key;
 }
 
 __global__ __launch_bounds__(1024) void mse_u8_kernel(const float* __restrict__ rgb, const uint8_t* __restrict__ gt,
@@ -188,12 +205,8 @@ int64_t nvp_sample_order_workspace_bytes(int64_t n, int32_t width) {
     return (total + (total + kSortScanTile - 1) / kSortScanTile + 64) * 4;
 }
 
-// order[k] (int64, as torch.argsort returns) = index of the k-th sample in ascending image column (pi % width), ties in drawing order
-int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int32_t width, void* workspace, int64_t workspace_bytes, void* stream) {
-    if (!pi || !order || !workspace || n < 0 || width < 1) return NVP_ERR_BADARG;
-    if (width > 12288 || n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;          // the per-chunk table lives in LDS
-    if (workspace_bytes < nvp_sample_order_workspace_bytes(n, width)) return NVP_ERR_BADARG;
-    if (n == 0) return 0;
+// stable counting sort of n samples by key_of(i) in [0, width): order[k] = index of the k-th sample, ties in input order
+static int stable_order(const int64_t* pi, const unsigned* keys, int64_t* order, int64_t n, int32_t width, void* workspace, hipStream_t stream) {
     const int nchunks = (int)((n + kSortChunk - 1) / kSortChunk);
     const int64_t total = (int64_t)nchunks * width;
     const unsigned ntiles = (unsigned)((total + kSortScanTile - 1) / kSortScanTile);
@@ -201,12 +214,59 @@ int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int
     unsigned* tsum = cnt + total;
     int key_bits = 1;
     while ((1 << key_bits) < width) ++key_bits;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nchunks), dim3(256), (size_t)width * 4, (hipStream_t)stream, pi, cnt, n, width, nchunks);
-    hipLaunchKernelGGL(sort_tilesum_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const unsigned*)cnt, tsum, total);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, cnt, (const unsigned*)tsum, total);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nchunks), dim3(64), (size_t)width * 4, (hipStream_t)stream, pi, (const unsigned*)cnt, order, n, width, nchunks, key_bits);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nchunks), dim3(256), (size_t)width * 4, stream, pi, keys, cnt, n, width, nchunks);
+    hipLaunchKernelGGL(sort_tilesum_kernel, dim3(ntiles), dim3(256), 0, stream, (const unsigned*)cnt, tsum, total);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(ntiles), dim3(256), 0, stream, cnt, (const unsigned*)tsum, total);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nchunks), dim3(64), (size_t)width * 4, stream, pi, keys, (const unsigned*)cnt, order, n, width, nchunks, key_bits);
     NVP_LAUNCH_CHECK();
     return 0;
+}
+
+// order[k] (int64, as torch.argsort returns) = index of the k-th sample in ascending image column (pi % width), ties in drawing order
+int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int32_t width, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!pi || !order || !workspace || n < 0 || width < 1) return NVP_ERR_BADARG;
+    if (width > 12288 || n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;          // the per-chunk table lives in LDS
+    if (workspace_bytes < nvp_sample_order_workspace_bytes(n, width)) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    return stable_order(pi, nullptr, order, n, width, workspace, (hipStream_t)stream);
+}
+
+// ---- row order of an arbitrary batch (a drop-in caller's: the reference sampler's raw order, dataio.py:104-120) ------------------
+// What the gradient scatter needs from a "y-sorted" batch is that the grid ROW index of the xy and of the yt plane (both indexed
+// by the y coordinate, modules.py:61,63) is non-decreasing at EVERY level - not that y itself is.  key(y) = sum over the levels of
+// row_l(y) is a non-decreasing step function of y that steps exactly where some level's row steps (the scatter's own keys_kernel,
+// encode_bwd.hip, uses the same key): 13-14 bits, ONE stable counting sort instead of a four-pass float radix sort.  When both
+// planes have the same level geometry (the reference's configs) the key is taken over one of them.
+static bool same_levels(const nvp_levels* a, const nvp_levels* b) {
+    if (a->n_levels != b->n_levels || a->flags != b->flags) return false;
+    for (int l = 0; l < a->n_levels; ++l) if (a->scale[l] != b->scale[l] || a->res[l] != b->res[l]) return false;
+    return true;
+}
+static int row_key_count(const nvp_levels* lv_xy, const nvp_levels* lv_yt) {
+    int64_t k = 1;
+    for (int l = 0; l < lv_xy->n_levels; ++l) k += lv_xy->res[l] + 1;
+    if (!same_levels(lv_xy, lv_yt)) for (int l = 0; l < lv_yt->n_levels; ++l) k += lv_yt->res[l] + 1;
+    return k > (1 << 30) ? (1 << 30) : (int)k;
+}
+
+int64_t nvp_order_by_rows_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt) {
+    if (n < 0 || !lv_xy || !lv_yt) return NVP_ERR_BADARG;
+    const int nk = row_key_count(lv_xy, lv_yt);
+    return nvp_sample_order_workspace_bytes(n, nk) + ((n + 63) / 64) * 256;             // counting-sort tables + the keys
+}
+
+int nvp_order_by_rows(const float* coords, int64_t* order, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!coords || !order || !workspace || !lv_xy || !lv_yt || n < 0) return NVP_ERR_BADARG;
+    if (lv_xy->n_levels < 1 || lv_xy->n_levels > NVP_MAX_LEVELS || lv_yt->n_levels < 1 || lv_yt->n_levels > NVP_MAX_LEVELS) return NVP_ERR_BADARG;
+    const int nk = row_key_count(lv_xy, lv_yt);
+    if (nk > 12288 || n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;
+    if (workspace_bytes < nvp_order_by_rows_workspace_bytes(n, lv_xy, lv_yt)) return NVP_ERR_BADARG;
+    if (n == 0) return 0;
+    unsigned* keys = (unsigned*)((char*)workspace + nvp_sample_order_workspace_bytes(n, nk));
+    hipLaunchKernelGGL(row_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, coords, keys, *lv_xy, *lv_yt,
+                       same_levels(lv_xy, lv_yt) ? 0 : 1, n);
+    return stable_order(nullptr, keys, order, n, nk, workspace, (hipStream_t)stream);
 }
 
 int nvp_mse_u8(const float* rgb, const uint8_t* gt_u8, float* drgb, float* loss_sum, int64_t n, void* stream) {

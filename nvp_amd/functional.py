@@ -99,6 +99,7 @@ _NO_HOOKS = StepHooks()
 # caller's order: the grid gathers get row locality (encode 1.07 -> 0.75 ms at N = 1.2 M) and the scatter skips a
 # sort.  Only worth it for training-size batches; 0 disables.
 AUTO_SORT_MIN = int(os.environ.get("NVP_AUTO_SORT_MIN", "65536"))
+ROW_ORDER = os.environ.get("NVP_ROW_ORDER", "nvp")            # "torch": torch.argsort of y instead of nvp_order_by_rows (A/B)
 
 # model_input['sorted_by_y'] is a promise by the caller (nvp_amd's own sampler makes it): the gradient scatter then skips
 # its y radix sort and binary-searches row starts in the batch as delivered, so a wrong hint gives silently wrong keyframe
@@ -114,6 +115,21 @@ FUSED_FWD = os.environ.get("NVP_FUSED_FWD", "1") != "0"
 # layout (nvp_encode_bwd_prepare / NVP_DZ_PLANES_READY): 2/3 of the scatter's permute pass disappear.  NVP_DZ_LEVEL_MAJOR=0 keeps
 # the row-major hand-over for every plane (bit-identical gradients either way).
 DZ_LEVEL_MAJOR = os.environ.get("NVP_DZ_LEVEL_MAJOR", "1") != "0"
+
+def _row_order(lib, coords: torch.Tensor, n: int, lv_xy, lv_yt) -> torch.Tensor:
+    """Permutation that puts a caller-order batch into non-decreasing grid-row order at every level of the xy / yt planes (what
+    `y_sorted` promises the scatter): one stable counting sort on a 13-bit row key (nvp_order_by_rows) - no library sort on the
+    reference-surface path.  Exotic level geometries (key space > 12 288) fall back to a stable argsort of y."""
+    ws_bytes = lib.nvp_order_by_rows_workspace_bytes(n, C.byref(lv_xy), C.byref(lv_yt))
+    if ws_bytes >= 0 and ROW_ORDER != "torch":
+        ws = torch.empty(max(int(ws_bytes), 4), device=coords.device, dtype=torch.uint8)
+        order = torch.empty(n, device=coords.device, dtype=torch.int64)
+        rc = lib.nvp_order_by_rows(L.ptr(coords), L.ptr(order, torch.int64), n, C.byref(lv_xy), C.byref(lv_yt), L.ptr(ws, torch.uint8), ws.numel(), L.stream_ptr())
+        if rc != L.ERR_UNSUPPORTED:
+            L.check(rc, "nvp_order_by_rows")
+            return order
+    return torch.argsort(coords[:, 2], stable=True)
+
 
 def _grad_buffer(param: torch.Tensor, sink=None) -> torch.Tensor:
     if sink is not None:
@@ -377,7 +393,7 @@ class NVPFused(torch.autograd.Function):
                                "(the gradient scatter would produce wrong keyframe gradients)")
         order = None
         if need_grad and not y_sorted and not temporal_interp and AUTO_SORT_MIN > 0 and n >= AUTO_SORT_MIN:
-            order = torch.argsort(coords[:, 2])
+            order = _row_order(lib, coords, n, lv_xy, lv_yt)
             coords, steps, y_sorted = coords[order], steps[order], True
         fused = bool(n) and FUSED_FWD and not temporal_interp and bool(lib.nvp_encode_mlp_fwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh)))
         # the latent tensor: an intermediate of the two-kernel path; with the fused forward it only exists for the backward pass

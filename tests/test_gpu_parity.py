@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import nvp_oracle as O
-from conftest import GOLDEN, relerr_l2, relerr_max, report, small_cfg
+from conftest import GOLDEN, full_cfg, relerr_l2, relerr_max, report, small_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -763,7 +763,7 @@ def _ulp_perturbed(sd, seed):
     return out
 
 
-def _psnr_trajectories(seed, steps_total, n_levels=16, log=None):
+def _psnr_trajectories(seed, steps_total, n_levels=16, log=None, ulp_twin=True):
     """Train (a) the oracle, (b) the oracle started <= 1 ulp away, (c) the HIP path with the product's own AdamW kernel on
     IDENTICAL batches drawn with the reference's sampler; returns per-step train PSNRs (training.py:58) and the three
     final parameter sets' full-frame eval PSNRs (eval.py:243-256)."""
@@ -794,7 +794,7 @@ def _psnr_trajectories(seed, steps_total, n_levels=16, log=None):
     for it in range(steps_total):
         ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)          # the reference's sampler order
         gt_u8 = flat[ti, pi].unsqueeze(0)
-        for ref, opt, sch, acc in ((ref_a, opt_a, sch_a, pa), (ref_b, opt_b, sch_b, pb)):
+        for ref, opt, sch, acc in ((ref_a, opt_a, sch_a, pa), (ref_b, opt_b, sch_b, pb))[:2 if ulp_twin else 1]:
             out_r = O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg)        # training.py:50-76 order
             loss_r = O.image_mse(out_r, O.normalise_gt(gt_u8))
             opt.zero_grad(); loss_r.backward(); opt.step(); sch.step()
@@ -806,7 +806,7 @@ def _psnr_trajectories(seed, steps_total, n_levels=16, log=None):
         pg.append(10 * math.log10(4 / float(loss_g)))
         if log:
             with open(log, "a") as f:
-                f.write(f'{{"seed": {seed}, "step": {it + 1}, "psnr_oracle": {pa[-1]:.4f}, "psnr_oracle_1ulp": {pb[-1]:.4f}, "psnr_hip": {pg[-1]:.4f}}}\n')
+                f.write(f'{{"seed": {seed}, "step": {it + 1}, "psnr_oracle": {pa[-1]:.4f}, "psnr_oracle_1ulp": {(pb[-1] if pb else float("nan")):.4f}, "psnr_hip": {pg[-1]:.4f}}}\n')
     # evaluation PSNR on full frames (eval.py:243-256) with the final parameter sets
     frames = (0, 7, 15)
     data = harness.DeviceVideo(video.to(dev()), n_samples=n, seed=0)
@@ -822,7 +822,7 @@ def _psnr_trajectories(seed, steps_total, n_levels=16, log=None):
                 ps.append(10 * math.log10(1 / float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())))
             return sum(ps) / len(ps)
 
-    return pa, pb, pg, eval_ref(ref_a), eval_ref(ref_b), ev_g
+    return pa, pb, pg, eval_ref(ref_a), (eval_ref(ref_b) if ulp_twin else float("nan")), ev_g
 
 
 @pytest.mark.parametrize("seed", [3, 4, 5])
@@ -850,6 +850,28 @@ def test_psnr_at_equal_steps_matches_oracle(seed):
     # own 1-ulp twin on the same batches is reported next to it (envelope), it does not widen the bound.
     assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB over {steps_total} steps (1-ulp envelope {max(env):.4f} dB)"
     assert abs(ev_g - ev_a) <= 0.02, f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
+
+
+
+def test_psnr_after_1000_steps_matches_oracle():
+    """the HIP path against the ORACLE (not against its own fp32-MFMA twin) over a whole cosine schedule of
+    1 000 steps (NVP_PSNR_STEPS_LONG) at the small size (64x64x16 clip, 8 192-pixel batches, 12 keyframe levels, identical
+    batches, the product's AdamW kernel).  north_star's bound is asserted where it is defined - at EQUAL STEP COUNT at the end of
+    the schedule: final train PSNR and full-frame eval PSNR within +-0.02 dB.  During the high-learning-rate phase the
+    instantaneous PSNR of any two fp32 trainings of this model jitters apart (the sine layers amplify rounding differences; see
+    test_psnr_at_equal_steps_matches_oracle's 1-ulp envelope and tests/test_gpu_long_horizon.py): the largest intermediate gap
+    is reported, and bounded loosely (0.25 dB) so that a real divergence still fails."""
+    import math
+    steps_total = int(os.environ.get("NVP_PSNR_STEPS_LONG", "1000"))
+    pa, _, pg, ev_a, _, ev_g = _psnr_trajectories(7, steps_total, 12, log=os.environ.get("NVP_PSNR_LOG"), ulp_twin=False)
+    gap = [abs(a - g) for a, g in zip(pa, pg)]
+    tail = gap[-max(steps_total // 20, 1):]                  # the last 5 % of the schedule: lr < 1e-4
+    report("psnr_equal_steps_long", steps=steps_total, final_gap=gap[-1], tail_gap=max(tail), max_gap=max(gap), argmax=gap.index(max(gap)) + 1,
+           eval_hip_minus_oracle=ev_g - ev_a, final_psnr_oracle=pa[-1], final_psnr_hip=pg[-1])
+    assert pg[-1] > 10 * math.log10(4 / 0.34) + 6, "training did not make progress"
+    assert gap[-1] <= 0.02, f"final train-PSNR gap {gap[-1]:.4f} dB after {steps_total} steps"
+    assert abs(ev_g - ev_a) <= 0.02, f"final eval-PSNR gap {abs(ev_g - ev_a):.4f} dB after {steps_total} steps"
+    assert max(gap) <= 0.25, f"intermediate train-PSNR gap {max(gap):.4f} dB at step {gap.index(max(gap)) + 1}"
 
 
 def test_psnr_at_equal_steps_full_levels():
@@ -1047,6 +1069,42 @@ def test_sample_order_is_the_stable_sort_by_column(n, width):
     want = torch.argsort(pi % width, stable=True)
     assert torch.equal(order, want)
     assert lib.nvp_sample_order_by_column(L.ptr(pi, torch.int64), L.ptr(order, torch.int64), n, 20000, L.ptr(ws, torch.uint8), ws.numel(), L.stream_ptr()) == L.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n,F", [(1, 2), (63, 2), (70001, 2), (300000, 4)])
+def test_row_order_is_the_stable_sort_by_the_row_key(n, F):
+    """nvp_order_by_rows (the counting sort NVPFused applies to caller-order batches instead of a library argsort): the permutation is
+    the STABLE sort by key(y) = sum over the levels of floor(fmaf(scale_l, y, 0.5)) - recomputed here in float64-free numpy fp32 - and
+    a batch gathered in that order has non-decreasing grid rows at every level (what NVP_COORDS_SORTED_BY_Y promises the scatter)."""
+    import ctypes as C
+    from nvp_amd import _lib as L
+    lib = L.load()
+    cfg = full_cfg(F=F)
+    lv = L.make_levels(cfg["2d_encoding_xy"])
+    g = torch.Generator().manual_seed(n)
+    coords = torch.rand((n, 3), generator=g)
+    coords[: min(n, 5), 2] = torch.tensor([0.0, 1.0, 0.5, 1.0, 0.0])[: min(n, 5)]
+    if n > 1000:                                       # the reference sampler's lattice: many exact ties
+        coords[1000:, 2] = torch.randint(0, 1920, (n - 1000,), generator=g).float() / 1919.0
+    cd = coords.to(dev())
+    ws = torch.empty(int(lib.nvp_order_by_rows_workspace_bytes(n, C.byref(lv), C.byref(lv))), device=dev(), dtype=torch.uint8)
+    order = torch.empty(n, device=dev(), dtype=torch.int64)
+    L.check(lib.nvp_order_by_rows(L.ptr(cd), L.ptr(order, torch.int64), n, C.byref(lv), C.byref(lv), L.ptr(ws, torch.uint8), ws.numel(), L.stream_ptr()), "nvp_order_by_rows")
+    y = coords[:, 2].numpy()
+    rows = []
+    key = np.zeros(n, dtype=np.int64)
+    for l in range(lv.n_levels):
+        # fmaf(scale, y, 0.5) in one rounding == the float64 product-sum rounded once to fp32 (24 x 24-bit product is exact in float64)
+        pos = (np.float64(np.float32(lv.scale[l])) * y.astype(np.float64) + 0.5).astype(np.float32)
+        r = np.clip(np.floor(pos).astype(np.int64), 0, lv.res[l] + 1)
+        rows.append(r)
+        key += r
+    want = torch.argsort(torch.from_numpy(key), stable=True)
+    got = order.cpu()
+    assert torch.equal(got, want)
+    for r in rows:
+        rr = r[got.numpy()]
+        assert (np.diff(rr) >= 0).all()
 
 
 def test_eval_drivers_t_interp_and_s_interp_vs_oracle():

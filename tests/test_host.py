@@ -347,3 +347,16 @@ def test_bench_plain_multi_gpu_launch_needs_the_devices():
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
     assert r.returncode == 2 and "no result line" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_cpu_baseline_worker_reports_its_thread_and_numa_policy():
+    """VERDICT r3 item 9: the cpu_baseline leg runs in its own process under a stated policy (one thread per physical core, bound;
+    memory interleaved across NUMA nodes where there are several) and reports it next to the rate."""
+    import json
+    r = _run_bench(["--cpu-baseline-only", "--cpu-sample", "2048", "--cpu-reps", "1"], {})
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["kind"] == "port" and d["unit"] == "Mpixels/s" and d["value"] > 0
+    pol = d["policy"]
+    assert pol["threads"] == d["cores"] >= 1 and pol["physical_cores"] <= pol["allowed_cpus"]
+    assert "memory" in pol and "binding" in pol and any("get_num_threads" in ln for ln in d["torch_parallel_info"])
