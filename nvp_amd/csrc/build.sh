@@ -1,5 +1,12 @@
 #!/usr/bin/env bash
-# Build libnvp_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU), plus its all-fp32-MFMA twin
+# Build libnvp_hip.so - the PRODUCT library, ten sources - for gfx950 in-tree (hipcc cross-compiles without a GPU), plus two pieces of
+# TEST INFRASTRUCTURE built from the same sources:
+#   libnvp_hip_experiments.so  -DNVP_EXPERIMENTS=1 + four more sources: the measured-slower kernel variants kept as A/B evidence (LDS-staged
+#                              gather, forward weight ring, per-wave backward chain, merged / paired / grouped / DMA-fed dW jobs) and the
+#                              NVP_* environment switches that select them; tests/test_gpu_parity.py::test_kernel_variants_are_bit_identical
+#                              loads it through NVP_HIP_LIB and compares every variant with the product library bit for bit.
+#                              NVP_SKIP_EXPERIMENTS=1 skips it.
+# and its all-fp32-MFMA twin
 # libnvp_hip_fp32mfma.so (same sources, -DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0: every MLP GEMM on v_mfma_f32_32x32x2_f32).
 # The twin is TEST INFRASTRUCTURE: tests/test_gpu_long_horizon.py trains both builds on identical batches to bound what the
 # split-operand 16-bit MFMA arithmetic of the default build does to the PSNR trajectory.  NVP_SKIP_TWIN=1 skips it.
@@ -8,11 +15,12 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-SRCS="encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r mlp_bwd mlp_bwd_b3 mlp_bwd_b3r mlp_dw mlp_dw_glds harness optim"
+SRCS_PRODUCT="encode encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_bwd mlp_bwd_b3r mlp_dw harness optim"
+SRCS_EXPERIMENTS="$SRCS_PRODUCT encode_fwd_lds mlp_fwd_b3r mlp_bwd_b3 mlp_dw_glds"
 
-# build_lib OUT.so OBJDIR "extra flags"
+# build_lib OUT.so OBJDIR "extra flags" "sources"
 build_lib() {
-  local out=$1 objdir=$2 extra=$3
+  local out=$1 objdir=$2 extra=$3 SRCS=$4
   local FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -Wno-constant-logical-operand ${NVP_EXTRA_FLAGS:-} $extra"
   local OBJS=() PIDS=() NAMES=()
   mkdir -p "$objdir"
@@ -40,7 +48,10 @@ build_lib() {
   echo "built $(pwd)/$out"
 }
 
-build_lib libnvp_hip.so obj ""
+build_lib libnvp_hip.so obj "" "$SRCS_PRODUCT"
 if [ -z "${NVP_SKIP_TWIN:-}" ]; then
-  build_lib libnvp_hip_fp32mfma.so obj_fp32mfma "-DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0"
+  build_lib libnvp_hip_fp32mfma.so obj_fp32mfma "-DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0" "$SRCS_PRODUCT"
+fi
+if [ -z "${NVP_SKIP_EXPERIMENTS:-}" ]; then
+  build_lib libnvp_hip_experiments.so obj_experiments "-DNVP_EXPERIMENTS=1" "$SRCS_EXPERIMENTS"
 fi

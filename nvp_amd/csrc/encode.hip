@@ -439,6 +439,7 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
     // OFF by default: measured on MI355X at N = 1 245 184 the staged kernel takes 0.41 ms for the two planes the global gather
     // below does in ~0.25 ms - with y-sorted batches those planes' rows already sit in L1/L2 and both kernels are bound by the
     // per-level index arithmetic (~100 VALU instructions per pixel and level), not by the fetches the staging removes.
+#if NVP_EXPERIMENTS
     static const bool lds_on = [] { const char* e = getenv("NVP_ENCODE_LDS"); return e && e[0] == '1'; }();
     const int F = a.lv[0].n_features;
     const bool lds = lds_on && (flags & NVP_COORDS_SORTED_BY_Y) && a.lv[1].n_features == F && (F == 1 || ((a.col0[0] | a.col0[1]) & 3) == 0);
@@ -447,6 +448,9 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
         if (rc) return rc;
         a.s_first = a.slots[0] + a.slots[1];
     }
+#else
+    (void)flags;
+#endif
     dim3 grid((unsigned)((npad + kThreads - 1) / kThreads), a.slots[0] + a.slots[1] + a.slots[2] + 1 - a.s_first);
     rc = dispatch_f(a.lv[0].n_features, [&](auto f) {
         hipLaunchKernelGGL((encode_fwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream,

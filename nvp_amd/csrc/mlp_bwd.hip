@@ -359,9 +359,11 @@ extern "C" int nvp_mlp_bwd_dx(const float* drgb, const float* steps, const float
     if (NVP_BWD_B3 && nvp_bwd_b3_ok(d)) {
         // NVP_MLP_RING_BWD=0 (environment, read once): per-wave weight streaming (mlp_bwd_b3.hip) instead of the workgroup-shared LDS
         // weight ring (mlp_bwd_b3r.hip, default for fused-dz latents).  Bit-identical results; measured 2.28-2.35 ms vs 2.43-2.46 ms.
+#if NVP_EXPERIMENTS
         static const bool ring = [] { const char* e = getenv("NVP_MLP_RING_BWD"); return !(e && e[0] == '0'); }();
-        if (ring) return nvp_mlp_bwd_b3r_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, lm, n, d, stream);
-        return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, lm, n, d, stream);
+        if (!ring) return nvp_mlp_bwd_b3_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, lm, n, d, stream);
+#endif
+        return nvp_mlp_bwd_b3r_launch(drgb, steps, saved, p, packed_bwd, dy, dz_rows, lm, n, d, stream);
     }
     const int64_t ntiles = nvp_ntiles(n);
     const int zt = nvp_bwd_layout(d).zt;

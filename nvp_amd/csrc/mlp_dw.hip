@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
     }
 }
 
+#if NVP_EXPERIMENTS
 // ---- paired jobs: dp_k x [B | BB] in ONE 256-thread workgroup ---------------------------------------------------------------------
 // Two jobs that share their A operand (dp_k x h_{k-1} and dp_k x z; for wide latents also dp_0 x z[0:128] and dp_0 x z[128:]) as
 // one workgroup that stages the dp_k tile ONCE: wave (wr, wc) owns the 64 x 64 sub-block (wr, wc) of BOTH outputs (128
@@ -884,6 +885,8 @@ __global__ __launch_bounds__(kGroupThreads, 1) void mlp_dw_group_kernel(DwGroupA
     }
 }
 
+#endif  // NVP_EXPERIMENTS
+
 // Sum the per-tile small-gradient records of one pixel chunk into that chunk's partial (the chain kernel
 // wrote one kRecFloats record per 32-pixel tile into stream 3 of `dy`).  Thread = one record element:
 // consecutive threads read consecutive floats of a record, tiles are visited in order -> deterministic.
@@ -944,8 +947,10 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
 
 }  // namespace
 
+#if NVP_EXPERIMENTS
 int nvp_mlp_dw_glds_launch(const float* steps, const float* zt, const float* saved, const float* dy, const nvp_mlp_params* p,
                            float* partials, int32_t n_chunks, int64_t n, int32_t d, void* stream);        // mlp_dw_glds.hip
+#endif
 
 extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const float* saved,
                               const float* dy, const nvp_mlp_params* p, float* partials, int32_t n_chunks,
@@ -961,12 +966,20 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // 512-thread job each, so dp_1 / dp_2 are staged once instead of twice (-14 % operand bytes).  Bit-identical; measured
     // SLOWER in the step (2.225 vs 2.152 ms): one 8-wave workgroup with 108 KiB of LDS per CU loses more than the saved reads
     // (which the XCD-local L2 partly served anyway) give back.  OFF by default; kept as the A/B evidence.
+#if NVP_EXPERIMENTS
     static const bool merge_on = [] { const char* e = getenv("NVP_DW_MERGE"); return e && e[0] == '1'; }();
+#else
+    constexpr bool merge_on = false;              // (the switches below exist in the experiments build only)
+#endif
     const bool merge = merge_on && d <= 128;          // one latent column block: [h ; z] = exactly two B tiles
     // NVP_DW_PAIR (environment, read once): dp_k x h_{k-1} and dp_k x z (wide latents: also the two column blocks of dp_0 x z) as ONE
     // 256-thread workgroup that stages dp_k once (mlp_dw_pair_kernel); bit-identical to the separate jobs
+#if NVP_EXPERIMENTS
     static const bool pair_on = [] { const char* e = getenv("NVP_DW_PAIR"); return e ? e[0] == '1' : (NVP_DW_PAIR_DEFAULT != 0); }();
     const bool pair = pair_on && NVP_DW_B3 && !merge && !getenv_on("NVP_DW_GLDS") && !getenv_on("NVP_DW_GROUP") && !getenv_on("NVP_DW_ONE_LAUNCH");
+#else
+    constexpr bool pair = false;
+#endif
     DwArgs P0, P2, P1, PP;                            // plain single-tile jobs, merged two-tile jobs, transform jobs, paired jobs
     int n0 = 0, n2 = 0, n1 = 0, np = 0;
     auto plain = [&](DwJob& J, int k, const float* b, int b_rows, int b_row0, int n_cols, int64_t w_off, int ld, int64_t bias_off) {
@@ -1019,16 +1032,28 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // of a pixel chunk sit on one XCD together and h_0 / h_1 (read by a modulator job AND by a SIREN job) could be fetched from
     // HBM once instead of once per launch (PMC: 8.0 GB per step against 5.7 GB of distinct operand streams).  Bit-identical;
     // measured SLOWER (1.87 vs 1.71 ms): the plain jobs run on the heavier instantiation.  OFF by default.
+#if NVP_EXPERIMENTS
     static const bool one_launch = [] { const char* e = getenv("NVP_DW_ONE_LAUNCH"); return e && e[0] == '1'; }();
+#else
+    constexpr bool one_launch = false;
+#endif
     // NVP_DW_GROUP=1 (environment, read once; default 0): layers 1 and 2 run as register-staged GROUPED workgroups that stage every operand stream once
     // (mlp_dw_group_kernel); only dp_0 x z stays a plain job.  0: the seven per-job workgroups (bit-identical results).
+#if NVP_EXPERIMENTS
     static const bool group_on = [] { const char* e = getenv("NVP_DW_GROUP"); return e && e[0] == '1'; }();      // register-staged grouping: measured slower, off
+#else
+    constexpr bool group_on = false;
+#endif
     // NVP_DW_GLDS=1 (environment, read once; default 0): layers 1 and 2 as grouped workgroups fed by LDS DMA, every operand stream
     // read once and split once (mlp_dw_glds.hip).  Correct (same tolerances; not bit-identical: other summation order) and
     // MEASURED SLOWER on MI355X - 0.99 + 0.92 ms for the two launches against 1.30 ms for the six jobs they replace: the DMA
     // skeleton alone streams at 6 TB/s (0.5 ms per launch) and the MFMA phase hides under it, but the staging pass between them
     // (three barriers and an LDS latency chain per 16-pixel step) adds 0.4 ms per launch.  Kept as the measured alternative.
+#if NVP_EXPERIMENTS
     static const bool glds_on = [] { const char* e = getenv("NVP_DW_GLDS"); return e && e[0] == '1'; }();
+#else
+    constexpr bool glds_on = false;
+#endif
     const bool glds = glds_on && NVP_DW_B3 && NVP_SPLIT_H2 && d <= 128 && (n & 3) == 0 && !merge && !one_launch;
     const bool group = !glds && group_on && d <= 128 && !merge && !one_launch;
     if (one_launch && n0 + n1 <= 12) {
@@ -1042,9 +1067,14 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
     // The transform jobs (SIREN layers 1, 2: two workgroups per CU, two jobs) fill the chip with 256 chunks exactly; the five plain
     // jobs (three workgroups per CU) want 5 n_chunks close below a multiple of 768 (304: 1520 of 1536 slots in two rounds, instead
     // of 1280 = one round and two thirds).  NVP_DW_CHUNKS_XF (environment, read once) caps the transform jobs' chunk count.
+#if NVP_EXPERIMENTS
     static const int xf_cap = [] { const char* e = getenv("NVP_DW_CHUNKS_XF"); return e ? atoi(e) : 256; }();
+#else
+    constexpr int xf_cap = 256;
+#endif
     const int nch1 = (xf_cap > 0 && xf_cap < n_chunks) ? xf_cap : n_chunks;
     const int tiles_per_chunk1 = (int)((ntiles + nch1 - 1) / nch1);
+#if NVP_EXPERIMENTS
     if (glds) {
         // dp_0 x z as the one remaining plain job, then the two DMA-fed grouped launches
         DwArgs Q0 = P0;
@@ -1077,20 +1107,29 @@ extern "C" int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float
         }
         n0 = n2 = n1 = 0;                           // nothing left for the per-job launches
     }
+#else
+    (void)glds; (void)group;
+#endif
     // GEMM launches: plain jobs, merged jobs (512 threads, three LDS tiles per buffer), transform jobs; plus the record sums
     // tile buffers (the kernel places the tile maxima and the table behind them), 4 kMxW maxima
     const size_t lds_bytes = (2 * 2 * kTileFloats + 4 * kMxW + 2 * NVP_H) * sizeof(float);
     const size_t lds_bytes0 = ((NVP_DW_BUFS == 1 ? 1 : 2) * 2 * kTileFloats + 4 * kMxW) * sizeof(float);
     const size_t lds_bytes2 = (2 * 3 * kTileFloats + 4 * kMxW) * sizeof(float);          // 108 KiB: one 8-wave workgroup per CU
+#if NVP_EXPERIMENTS
     if (np) {
         const size_t lds_pair = (3 * kTileFloats + 24) * sizeof(float);                     // 54 KiB: two workgroups per CU
         hipLaunchKernelGGL(mlp_dw_pair_kernel, dim3(n_chunks * np), dim3(256), lds_pair, (hipStream_t)stream, PP, partials, n, ntiles, tiles_per_chunk, n_chunks);
         NVP_LAUNCH_CHECK();
     }
+#endif
     if (n0) hipLaunchKernelGGL((mlp_dw_kernel<0, 1>), dim3(n_chunks * n0), dim3(256), lds_bytes0, (hipStream_t)stream, P0, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
+#if NVP_EXPERIMENTS
     if (n2) hipLaunchKernelGGL((mlp_dw_kernel<0, 2>), dim3(n_chunks * n2), dim3(512), lds_bytes2, (hipStream_t)stream, P2, partials, n, ntiles, tiles_per_chunk, n_chunks);
     NVP_LAUNCH_CHECK();
+#else
+    (void)lds_bytes2; (void)np; (void)n2;
+#endif
     const bool xf_own = n1 > 0 && !one_launch;       // (one launch: the plain jobs ride in P1 and share its chunking)
     if (n1) hipLaunchKernelGGL((mlp_dw_kernel<1, 1>), dim3((xf_own ? nch1 : n_chunks) * n1), dim3(256), lds_bytes, (hipStream_t)stream, P1, partials, n, ntiles,
                                xf_own ? tiles_per_chunk1 : tiles_per_chunk, xf_own ? nch1 : n_chunks);

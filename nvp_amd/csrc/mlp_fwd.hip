@@ -158,8 +158,10 @@ extern "C" int nvp_mlp_fwd(const float* zt, const float* steps, const nvp_mlp_pa
         // NVP_MLP_RING_FWD=1 (environment, read once): workgroup-shared LDS weight ring (mlp_fwd_b3r.hip) instead of per-wave weight
         // streaming.  Bit-identical results; measured 1.88-1.95 ms vs 1.77-1.85 ms on MI355X (the per-k-step barrier costs more
         // than the 4x lower vector-memory traffic buys in this kernel), so it is OFF by default - kept as the A/B evidence.
+#if NVP_EXPERIMENTS
         static const bool ring = [] { const char* e = getenv("NVP_MLP_RING_FWD"); return e && e[0] == '1'; }();
         if (ring) return nvp_mlp_fwd_b3r_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
+#endif
         return nvp_mlp_fwd_b3_launch(zt, steps, p, packed_fwd, rgb, saved, n, d, stream);
     }
     const int64_t ntiles = nvp_ntiles(n);

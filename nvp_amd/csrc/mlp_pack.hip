@@ -361,7 +361,11 @@ int nvp_mlp_pack_fwd(const nvp_mlp_params* p, float* packed, int32_t d, void* st
     if (NVP_FWD_B3 && nvp_fwd_b3_ok(d)) {
         const int64_t nb = nvp_fwd_layout_b3(d).off[5];
         // NVP_PACK_ONE_LAUNCH=0 (environment, read once): the three-launch version (same bits)
+#if NVP_EXPERIMENTS
         static const bool one = [] { const char* e = getenv("NVP_PACK_ONE_LAUNCH"); return !(e && e[0] == '0'); }();
+#else
+        constexpr bool one = true;
+#endif
         if (one) {
             hipLaunchKernelGGL(pack_fwd_b3_all_kernel, dim3((unsigned)(nb / kB3StepU32 + 1)), dim3(1024), 0, (hipStream_t)stream, *p, reinterpret_cast<unsigned*>(packed), d);
             NVP_LAUNCH_CHECK();

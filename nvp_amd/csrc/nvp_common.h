@@ -4,6 +4,13 @@
 #include <stdint.h>
 #include "../../include/nvp_hip.h"
 
+// NVP_EXPERIMENTS=1 (build.sh's libnvp_hip_experiments.so only): compile the measured-slower kernel variants kept as A/B evidence -
+// LDS-staged gather, forward weight ring, per-wave backward chain, merged / paired / grouped / DMA-fed dW jobs - and the NVP_*
+// environment switches that select them.  The product library (libnvp_hip.so) has neither the kernels nor the switches.
+#ifndef NVP_EXPERIMENTS
+#define NVP_EXPERIMENTS 0
+#endif
+
 #define NVP_H NVP_HIDDEN
 #define NVP_T NVP_TILE
 

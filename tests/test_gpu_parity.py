@@ -1188,15 +1188,29 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the variants live in libnvp_hip_experiments.so only (build.sh; -DNVP_EXPERIMENTS=1): run 0 below is the PRODUCT library, every
+    # other run loads the experiments library - with its switches at their defaults it must reproduce the product bit for bit too
+    exp = os.path.join(root, "nvp_amd", "csrc", "libnvp_hip_experiments.so")
+    assert os.path.exists(exp), f"{exp} missing: run nvp_amd/csrc/build.sh"
+    _run_dump = subprocess.run
+
+    def run_variant(args, env, **kw):
+        e = {**os.environ, **env}
+        e.pop("NVP_HIP_LIB", None)
+        if env.get("_lib", "exp") == "exp":
+            e["NVP_HIP_LIB"] = exp
+        e.pop("_lib", None)
+        return _run_dump(args, env=e, **kw)
+
     outs = []
-    for k, env in enumerate(({"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # the defaults
+    for k, env in enumerate(({"_lib": "product"},                                                                        # the product library
+                             {"NVP_ENCODE_LDS": "0", "NVP_MLP_RING_FWD": "0", "NVP_MLP_RING_BWD": "1"},          # experiments library, defaults
                              {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1",
                               "NVP_DZ_LEVEL_MAJOR": "0"},                                                                # every alternative
                              {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1", "NVP_SCATTER_PRESORT": "0", "NVP_PACK_ONE_LAUNCH": "0"},            # launch / stream experiments
                              {"NVP_FUSED_FWD": "0"})):                                                                      # the seven per-job dW workgroups instead of the grouped ones
         out = str(tmp_path / f"v{k}.npz")
-        subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300,
-                       env={**os.environ, **env})
+        run_variant([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], env, check=True, timeout=300)
         outs.append(np.load(out))
     a = outs[0]
     for b in outs[1:]:
@@ -1206,9 +1220,9 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     # nvp_l's 228-row latent (F = 4): the ring variants of the backward chain and of the eight-tile latent-gradient kernel against
     # the per-wave kernels (NVP_MLP_RING_BWD=0)
     wide = []
-    for k, env in enumerate(({"NVP_MLP_RING_BWD": "1", "NVP_DW_PAIR": "0"}, {"NVP_MLP_RING_BWD": "0", "NVP_DW_PAIR": "1"})):
+    for k, env in enumerate(({"_lib": "product"}, {"NVP_MLP_RING_BWD": "0", "NVP_DW_PAIR": "1"})):
         out = str(tmp_path / f"w{k}.npz")
-        subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "4", "50001"], check=True, timeout=300, env={**os.environ, **env})
+        run_variant([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "4", "50001"], env, check=True, timeout=300)
         wide.append(np.load(out))
     for k in wide[0].files:
         assert np.array_equal(wide[0][k], wide[1][k], equal_nan=True), f"{k} differs between the ring and the per-wave backward (F = 4)"
@@ -1216,7 +1230,7 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     # (NVP_DW_GLDS=1: another summation order, so equal to the gradient tolerance, not bit for bit) - measured slower, off by default
     for env, exact in (({"NVP_DW_GROUP": "1"}, True), ({"NVP_DW_GLDS": "1"}, False), ({"NVP_DW_PAIR": "1"}, True), ({"NVP_DW_PAIR": "0"}, True)):
         out = str(tmp_path / ("g_" + "_".join(env) + ".npz"))
-        subprocess.run([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], check=True, timeout=300, env={**os.environ, **env})
+        run_variant([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], env, check=True, timeout=300)
         b = np.load(out)
         for k in a.files:
             if exact:

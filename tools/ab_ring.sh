@@ -3,6 +3,8 @@
 # global-gather kernels: (1) outputs and gradients must be BIT-identical, (2) bench stage times of each variant.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+# the kernel variants these switches select live in the experiments library (nvp_amd/csrc/build.sh)
+export NVP_HIP_LIB=${NVP_HIP_LIB:-$PWD/nvp_amd/csrc/libnvp_hip_experiments.so}
 mkdir -p gpurun_out
 TAG=${1:-ab}
 for F in 2 4; do

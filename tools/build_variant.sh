@@ -5,7 +5,7 @@ set -euo pipefail
 cd "$(dirname "$0")/../nvp_amd/csrc"
 NAME=$1; shift
 OUT=../../tools/bin; mkdir -p $OUT
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed $*"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -DNVP_EXPERIMENTS=1 $*"     # variants are experiments builds (every source, every switch)
 objs=""; pids=()
 for f in encode encode_fwd_lds encode_bwd mlp_pack mlp_fwd mlp_fwd_b3 mlp_fwd_b3r mlp_bwd mlp_bwd_b3 mlp_bwd_b3r mlp_dw mlp_dw_glds harness optim; do
   EXTRA=""; case "$f" in encode|encode_fwd_lds|encode_bwd|harness|optim) EXTRA="-ffp-contract=off";; esac

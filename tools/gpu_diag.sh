@@ -2,6 +2,8 @@
 # short, bounded diagnosis stages; every stage has its own timeout and log under gpurun_out/
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+# the kernel variants these switches select live in the experiments library (nvp_amd/csrc/build.sh)
+export NVP_HIP_LIB=${NVP_HIP_LIB:-$PWD/nvp_amd/csrc/libnvp_hip_experiments.so}
 mkdir -p gpurun_out
 TAG=${1:-diag}
 export NVP_PARITY_REPORT=1

@@ -17,6 +17,9 @@ for P in $PASSES; do
   case $P in
     sq1) run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY;;
     sq2) run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE;;
+    sq3) run sq3 SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES;;
+    sq4) run sq4 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS;;
+    tcc) run tcc TCC_HIT TCC_MISS TCC_REQ TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_READ;;
     fetch) run fetch FETCH_SIZE;;
     write) run write WRITE_SIZE;;
   esac

@@ -44,7 +44,7 @@ for k in sorted(set(fetch) | set(write)):
     fb = 2 * 1024 * sum(f) / max(len(f), 1); wb = 1024 * sum(w) / max(len(w), 1)
     stage[stage_of(k)] += fb + wb            # each distinct kernel runs once per step
     out.append(f"{k:28s} fetch(x2) {fb/1e9:7.3f} GB  write {wb/1e9:7.3f} GB  per launch")
-for p in ("sq1", "sq2"):
+for p in ("sq1", "sq2", "sq3", "sq4", "tcc"):
     d = load(p)
     for k in d:
         vals = {c: sum(v) / len(v) for c, v in d[k].items()}
