@@ -199,6 +199,7 @@ def cpu_baseline_worker(n_sample: int, reps: int = 3):
     sample: zero-filling and accumulating the 543 MB of dense gradients)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nvp_oracle as O
+    load0 = os.getloadavg()              # the GPU boxes are multi-tenant hosts: other jobs' CPU load is the main source of run-to-run spread
     cfg = CONFIG_NVP_S
     sd = O.init_state(cfg, seed=0)
     for v in sd.values():
@@ -223,6 +224,7 @@ def cpu_baseline_worker(n_sample: int, reps: int = 3):
     rate = lambda t: round(n_sample / t / 1e6, 6)      # noqa: E731
     par = [ln.strip() for ln in torch.__config__.parallel_info().splitlines() if any(k in ln for k in ("get_num_threads", "omp_get_max_threads", "mkl_get_max_threads", "ATen parallel backend"))]
     return {"value": rate(med), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port", "policy": CPU_POLICY, "torch_parallel_info": par,
+            "host_loadavg_before_after": [round(load0[0], 1), round(os.getloadavg()[0], 1)],
             "min": rate(times[-1]), "median": rate(med), "max": rate(times[0]),
             "seconds_per_sample_step": [round(t, 3) for t in times], "extrapolated_seconds_per_full_step": round(med * N_PX / n_sample, 1),
             "cpu": cpu_model(),
@@ -395,6 +397,9 @@ def main():
     if (world == 1 and not (os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1") and harness.EARLY_ADAMW
             and harness.FUSED_SPARSE_ADAMW and os.environ.get("NVP_BENCH_UNSORTED", "0") != "1"):
         fused_sparse_bytes_per_px = 6 * 4 * T * 300 * 300 * F / N_PX
+        if harness.FUSED_DENSE_ADAMW:             # ... and the three dense planes' (nvp_encode_bwd_dense_adamw): p, m, v of 3 x Sum res_l^2 x F cells
+            from nvp_amd import _lib as _L
+            fused_sparse_bytes_per_px += 6 * 4 * 3 * _L.levels_n_params(_L.make_levels(cfg["2d_encoding_xy"])) / N_PX
         BYTES_PX = dict(BYTES_PX, nvp_encode_bwd=BYTES_PX["nvp_encode_bwd"] + fused_sparse_bytes_per_px)
     model = NVP(out_features=3, encoding_config=cfg, verbose=False).to(dev)
     parallel.broadcast_parameters(model)
@@ -596,7 +601,7 @@ def main():
         rdt = (time.perf_counter() - t0) / args.steps * 1e3
         ref_surface = {"what": "same workload through the reference's own loop shape (training.py:42-76): raw-order batches, model(mi)['model_out'], torch-expression "
                                "MSE, zero_grad / backward / torch.optim.AdamW.step / CosineAnnealingLR.step; no StepHooks, no nvp_amd.harness / nvp_amd.optim",
-                       "ms_per_step": round(rdt, 3), "mpx_s": round(N_PX / (rdt * 1e-3) / 1e6, 3), "steps": args.steps, "final_loss": float(rloss),
+                       "ms_per_step": round(rdt, 3), "mpx_s": round(N_PX / (rdt * 1e-3) / 1e6, 3), "steps": args.steps, "final_loss": float(rloss.detach()),
                        "optimizer": "torch.optim.AdamW (default implementation)", "row_order": functional.ROW_ORDER}
         del ropt, rsched, rdata
     verify_replicas(mode + " (after the timed steps)")

@@ -200,6 +200,16 @@ int nvp_encode_bwd_sparse_adamw(const float* coords, const float* dz, int32_t dz
                                 const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
                                 float* emb, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
                                 double weight_decay, int64_t step, void* stream);
+
+/* The dense planes' half of the split scatter (NVP_SCATTER_DENSE_ONLY semantics; flags must carry NVP_COORDS_SORTED_BY_Y |
+ * NVP_DZ_PLANES_READY) with torch.optim.AdamW's step (training.py:13-14) applied in the scatter's flushes: no gradient tensor is
+ * produced for the three planes; params[q] / exp_avg[q] / exp_avg_sq[q] (q = 0 xy, 1 yt, 2 xt; each Sum res_l^2 * F floats) are updated in
+ * place, bit-identical to nvp_encode_bwd(NVP_SCATTER_DENSE_ONLY) followed by nvp_adamw_step on its output.  step[q]: 1-based step count. */
+int nvp_encode_bwd_dense_adamw(const float* coords, const float* dz, int32_t dz_stride, int64_t n,
+                               const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                               const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
+                               float* const* params, float* const* exp_avg, float* const* exp_avg_sq, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, const int64_t* step, void* stream);
 int32_t nvp_dz_lm_supported(int32_t latent_dim);   /* does nvp_mlp_bwd_dx honour `lm` for this latent width in this build? */
 int nvp_encode_bwd(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,

@@ -93,6 +93,9 @@ SIGNATURES = {
     "nvp_encode_bwd_presort": [_p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64, _i32, _vp],
     "nvp_encode_bwd_sparse_adamw": [_p, _p, _i32, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64, _i32,
                                     _p, _p, _p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i64, _vp],
+    "nvp_encode_bwd_dense_adamw": [_p, _p, _i32, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp, _i64, _i32,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.POINTER(C.c_int64), _vp],
     "nvp_dz_lm_supported": [_i32],
     "nvp_mlp_bwd_dw": [_p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _i32, C.POINTER(MlpGrads), _i64, _i32, _vp],
     "nvp_mse_u8": [_p, _p, _p, _p, _i64, _vp],

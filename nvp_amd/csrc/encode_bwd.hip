@@ -428,7 +428,13 @@ __device__ __forceinline__ long long to_fixed(float v, const FixedScale& fs) {
 #endif
 }
 
+// The three dense planes' optimizer step applied in the flushes (band_kernel: exclusive bands; slab_reduce_kernel: split levels): the
+// gradient of a cell goes from the int64 table / slab sum straight into torch.optim.AdamW's update (adamw.h, same arithmetic as
+// nvp_adamw_step) - it is never written to HBM, and no optimizer launch is left for the planes.  on == 0: plain gradient output.
+struct DenseAdam { float* p[3]; float* m[3]; float* v[3]; AdamScalars S[3]; int on; };
+
 struct BandArgs {
+    DenseAdam ad;
     Plan plan;
     nvp_levels lv[3];
     const float2* cs[3];
@@ -575,15 +581,27 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     }
     const double inv = ldexp(1.0, -s_k);
     const int64_t lvl_off = (int64_t)A.lv[plane].offset[level] * F;
-    float* dst = A.grad[plane] + lvl_off + (int64_t)r0 * res * F;
-    if (s_poison) {          // non-finite dz: the reference's index_put / atomics would carry NaN / Inf; fixed point cannot, so say so loudly
+    float* dst = A.ad.on ? nullptr : A.grad[plane] + lvl_off + (int64_t)r0 * res * F;
+    if (s_poison && !A.ad.on) {          // non-finite dz: the reference's index_put / atomics would carry NaN / Inf; fixed point cannot, so say so loudly
         for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    if (A.ad.on) {
+        float* pp = A.ad.p[plane] + lvl_off + (int64_t)r0 * res * F;
+        float* pm = A.ad.m[plane] + lvl_off + (int64_t)r0 * res * F;
+        float* pv = A.ad.v[plane] + lvl_off + (int64_t)r0 * res * F;
+        for (int i = threadIdx.x; i < entries; i += kBandThreads) {
+            float x = pp[i], m = pm[i], v = pv[i];
+            adam1(x, s_poison ? __uint_as_float(0x7fc00000u) : (float)((double)(long long)tab[i] * inv), m, v, A.ad.S[plane]);       // (a NaN gradient poisons the
+            pp[i] = x; pm[i] = m; pv[i] = v;                                                                                    // parameter, as the gradient route would)
+        }
         return;
     }
     for (int i = threadIdx.x; i < entries; i += kBandThreads) dst[i] = (float)((double)(long long)tab[i] * inv);
 }
 
 struct ReduceArgs {
+    DenseAdam ad;
     Plan plan;
     nvp_levels lv[3];
     float* grad[3];
@@ -606,14 +624,22 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceArgs A) {
     const LevelPlan L = A.plan.lp[plane][level];
     const int F = A.lv[plane].n_features;
     const int64_t cells = (int64_t)A.lv[plane].res[level] * A.lv[plane].res[level] * F;
-    float* dst = A.grad[plane] + (int64_t)A.lv[plane].offset[level] * F;
+    const int64_t lvl_off = (int64_t)A.lv[plane].offset[level] * F;
+    float* dst = A.ad.on ? nullptr : A.grad[plane] + lvl_off;
     const long long* src = A.slabs + L.slab_off;
     const double inv = ldexp(1.0, -s_k);
     const bool poison = s_poison;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
         long long sum = 0;
         for (int sp = 0; sp < L.splits; ++sp) sum += src[(int64_t)sp * cells + i];
-        dst[i] = poison ? __uint_as_float(0x7fc00000u) : (float)((double)sum * inv);
+        const float g = poison ? __uint_as_float(0x7fc00000u) : (float)((double)sum * inv);
+        if (A.ad.on) {
+            float x = A.ad.p[plane][lvl_off + i], m = A.ad.m[plane][lvl_off + i], v = A.ad.v[plane][lvl_off + i];
+            adam1(x, g, m, v, A.ad.S[plane]);
+            A.ad.p[plane][lvl_off + i] = x; A.ad.m[plane][lvl_off + i] = m; A.ad.v[plane][lvl_off + i] = v;
+        } else {
+            dst[i] = g;
+        }
     }
 }
 
@@ -822,10 +848,30 @@ int presort(const float* coords, int64_t n, const nvp_levels* lv[3], const nvp_s
     return csort(sk, n, sh->t_res * sh->x_res, (int*)(ws + W.srowstart), (unsigned*)(ws + W.scursor), (unsigned*)(ws + W.tsum), (int*)(ws + W.sorder), s);
 }
 
+// Geometry of the sparse band kernel's LDS table and every "this layout is not supported" decision of the sparse half, in ONE place:
+// launch_all runs it BEFORE anything is enqueued, and nvp_encode_bwd_sparse_adamw's "NVP_ERR_UNSUPPORTED = nothing enqueued" promise
+// rests on the same function (same clamp of `rows` to x_res).
+struct SparseGeom { int sentries, rows; };
+int sparse_geom(const nvp_sparse_shape* sh, const SparseAdam* adam, SparseGeom& G) {
+    const int row_floats = sh->y_res * sh->n_features;
+    if (row_floats < 1 || sh->x_res < 1 || sh->t_res < 1) return NVP_ERR_BADARG;
+    if (sh->n_features != 1 && sh->n_features != 2 && sh->n_features != 4 && sh->n_features != 8) return NVP_ERR_UNSUPPORTED;
+    G.sentries = kSparseEntries > row_floats ? kSparseEntries : row_floats;
+    if (G.sentries > kMaxLdsEntries) return NVP_ERR_UNSUPPORTED;              // one x-row does not fit the LDS
+    G.rows = G.sentries / row_floats;
+    if (G.rows > sh->x_res) G.rows = sh->x_res;
+    if (adam) {
+        // whole float4 per table quad, 16-B aligned tensors, the item's table within kAdamTrips trips of the workgroup
+        if ((row_floats & 3) || G.rows * row_floats > 4 * kSparseThreads * kAdamTrips ||
+            (((uintptr_t)adam->p | (uintptr_t)adam->m | (uintptr_t)adam->v) & 15)) return NVP_ERR_UNSUPPORTED;
+    }
+    return 0;
+}
+
 template <int F>
 int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, float* g1, float* g2, float* demb, int64_t n,
                const nvp_levels* lv[3], const nvp_sparse_shape* sh, char* ws, const Ws& W, const Plan& P, int flags, hipStream_t s,
-               const SparseAdam* adam = nullptr) {
+               const SparseAdam* adam = nullptr, const DenseAdam* dadam = nullptr) {
     const bool y_sorted = (flags & NVP_COORDS_SORTED_BY_Y) != 0;
     // xy / yt latent gradients already level-major in ws AND the sparse columns' max|dz| already in its slots (chain kernel)
     const bool planes_ready = y_sorted && (flags & NVP_DZ_PLANES_READY) != 0;
@@ -841,6 +887,11 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
     const int scol0 = col, scols = 9 * sh->n_features;
     if ((scol0 & 3) != 0 || scol0 + ((scols + 3) & ~3) > dz_stride) return NVP_ERR_UNSUPPORTED;
     if (scols > 16 * F) return NVP_ERR_UNSUPPORTED;            // the sparse columns are scanned by the xt plane's own lanes
+    SparseGeom SG{0, 0};
+    if (do_sparse) {                                                  // every support decision of the sparse half BEFORE anything is enqueued
+        const int rcg = sparse_geom(sh, adam, SG);
+        if (rcg) return rcg;
+    }
     const bool presorted = (flags & NVP_SCATTER_PRESORTED) != 0;      // nvp_encode_bwd_presort already ran on this workspace
     if (!presorted) {
         int rc0 = presort(coords, n, lv, sh, ws, W, P, flags, s);
@@ -871,6 +922,8 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
                            (size_t)PermCfg<F>::PIX * PermCfg<F>::STRIDE * sizeof(float), s, coords, dz, dz_stride, PA, (unsigned*)(ws + W.dzmax), n);
 
         BandArgs BA;
+        memset(&BA.ad, 0, sizeof(BA.ad));
+        if (dadam) BA.ad = *dadam;
         BA.plan = P;
         float* grads[3] = {g0, g1, g2};
         for (int p = 0; p < 3; ++p) {
@@ -887,6 +940,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
 
         if (P.reduce_items > 0) {
             ReduceArgs R;
+            R.ad = BA.ad;
             R.plan = P;
             for (int p = 0; p < 3; ++p) { R.lv[p] = *lv[p]; R.grad[p] = grads[p]; }
             R.slabs = (const long long*)(ws + W.slabs);
@@ -902,11 +956,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         int* sorder = (int*)(ws + W.sorder);
         int* srs = (int*)(ws + W.srowstart);
         unsigned* sdzmax = (unsigned*)(ws + W.sdzmax);
-        int sentries = kSparseEntries;
-        if (sh->y_res * sh->n_features > sentries) sentries = sh->y_res * sh->n_features;
-        if (sentries > kMaxLdsEntries) return NVP_ERR_UNSUPPORTED;          // one x-row does not fit the LDS
-        int rows = sentries / (sh->y_res * sh->n_features);
-        if (rows > sh->x_res) rows = sh->x_res;
+        const int sentries = SG.sentries, rows = SG.rows;                  // sparse_geom(), checked before the presort
         const int bands = (sh->x_res + rows - 1) / rows;
         const int n_items = sh->t_res * bands;
         // persistent workgroups: as many as fit the chip at once (LDS: 160 KB / table, at most 8 per CU of 256 CUs)
@@ -916,12 +966,7 @@ int launch_all(const float* coords, const float* dz, int dz_stride, float* g0, f
         const int grid = n_items < 256 * per_cu ? n_items : 256 * per_cu;
         const size_t lds = (size_t)rows * sh->y_res * sh->n_features * 8;
         SparseAdam ad{};
-        if (adam) {
-            // whole float4 per table quad, 16-B aligned tensors, the item's table within kAdamTrips trips of the workgroup
-            if ((sh->y_res * sh->n_features) & 3 || rows * sh->y_res * sh->n_features > 4 * kSparseThreads * kAdamTrips ||
-                (((uintptr_t)adam->p | (uintptr_t)adam->m | (uintptr_t)adam->v) & 15)) return NVP_ERR_UNSUPPORTED;
-            ad = *adam;
-        }
+        if (adam) ad = *adam;
         switch (sh->n_features) {
 #define NVP_SPARSE_CASE(FF) case FF: \
             if (adam) hipLaunchKernelGGL((sparse_band_kernel<FF, true>), dim3((unsigned)grid), dim3(kSparseThreads), lds, s, coords, dz, dz_stride, scol0, \
@@ -1010,7 +1055,8 @@ int nvp_encode_bwd_presort(const float* coords, int64_t n, const nvp_levels* lv_
 static int encode_bwd_impl(const float* coords, const float* dz, int32_t dz_stride,
                    float* d_kf_xy, float* d_kf_yt, float* d_kf_xt, float* d_emb, int64_t n,
                    const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
-                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream, const SparseAdam* adam) {
+                   const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags, void* stream, const SparseAdam* adam,
+                   const DenseAdam* dadam = nullptr) {
     if (!levels_ok(lv_xy) || !levels_ok(lv_yt) || !levels_ok(lv_xt) || !sh || n < 0) return NVP_ERR_BADARG;
     if (lv_xy->n_features != lv_yt->n_features || lv_xy->n_features != lv_xt->n_features) return NVP_ERR_UNSUPPORTED;
     if (n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;
@@ -1027,7 +1073,7 @@ static int encode_bwd_impl(const float* coords, const float* dz, int32_t dz_stri
         return (int)e;
     }
     // a split call only needs the outputs it produces; the fused-optimizer call produces no d_emb at all
-    const bool want_dense = !(flags & NVP_SCATTER_SPARSE_ONLY), want_emb = !(flags & NVP_SCATTER_DENSE_ONLY) && !adam;
+    const bool want_dense = !(flags & NVP_SCATTER_SPARSE_ONLY) && !dadam, want_emb = !(flags & NVP_SCATTER_DENSE_ONLY) && !adam;
     if (!coords || !dz || !workspace || (want_dense && (!d_kf_xy || !d_kf_yt || !d_kf_xt)) || (want_emb && !d_emb)) return NVP_ERR_BADARG;
     Plan P;
     make_plan(P, lv, n);
@@ -1041,10 +1087,10 @@ static int encode_bwd_impl(const float* coords, const float* dz, int32_t dz_stri
     if ((lv_xy->n_levels * lv_xy->n_features) & 3 || (lv_yt->n_levels * lv_yt->n_features) & 3 || (lv_xt->n_levels * lv_xt->n_features) & 3)
         return NVP_ERR_UNSUPPORTED;             // 16-B aligned per-plane row segments (true for every 4-level-multiple config)
     switch (lv_xy->n_features) {
-        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
-        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
-        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
-        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam); break;
+        case 1: rc = launch_all<1>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam, dadam); break;
+        case 2: rc = launch_all<2>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam, dadam); break;
+        case 4: rc = launch_all<4>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam, dadam); break;
+        case 8: rc = launch_all<8>(coords, dz, dz_stride, d_kf_xy, d_kf_yt, d_kf_xt, d_emb, n, lv, sh, (char*)workspace, W, P, flags, s, adam, dadam); break;
         default: return NVP_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
@@ -1071,18 +1117,38 @@ int nvp_encode_bwd_sparse_adamw(const float* coords, const float* dz, int32_t dz
                                 double weight_decay, int64_t step, void* stream) {
     if (!emb || !exp_avg || !exp_avg_sq || step < 1 || n < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1)) return NVP_ERR_BADARG;
     if (!(flags & NVP_DZ_PLANES_READY) || !(flags & NVP_COORDS_SORTED_BY_Y) || (flags & NVP_SCATTER_DENSE_ONLY)) return NVP_ERR_BADARG;
-    if (!sh || (sh->y_res * sh->n_features) & 3 || (((uintptr_t)emb | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)) return NVP_ERR_UNSUPPORTED;
-    {
-        int sentries = kSparseEntries;
-        if (sh->y_res * sh->n_features > sentries) sentries = sh->y_res * sh->n_features;
-        int rows = sentries / (sh->y_res * sh->n_features);
-        if (rows * sh->y_res * sh->n_features > 4 * kSparseThreads * kAdamTrips) return NVP_ERR_UNSUPPORTED;
-    }
+    if (!sh) return NVP_ERR_BADARG;
     SparseAdam ad;
     ad.p = emb; ad.m = exp_avg; ad.v = exp_avg_sq;
     ad.S = adam_scalars(lr, beta1, beta2, eps, weight_decay, step, 1.0);
+    // (launch_all repeats this check - the same function - before its first launch: UNSUPPORTED always means nothing was enqueued)
+    SparseGeom G;
+    const int rcg = sparse_geom(sh, &ad, G);
+    if (rcg) return rcg;
     return encode_bwd_impl(coords, dz, dz_stride, nullptr, nullptr, nullptr, nullptr, n, lv_xy, lv_yt, lv_xt, sh, workspace, workspace_bytes,
                            flags | NVP_SCATTER_SPARSE_ONLY, stream, &ad);
+}
+
+// The dense planes' half of the split scatter (NVP_SCATTER_DENSE_ONLY semantics: needs NVP_COORDS_SORTED_BY_Y | NVP_DZ_PLANES_READY)
+// with the optimizer step applied in the flushes: no d_kf_* is produced; params[q] / exp_avg[q] / exp_avg_sq[q] (q = xy, yt, xt) are
+// updated in place exactly as nvp_adamw_step would update them from that gradient (adamw.h).  step[q]: the 1-based step count of
+// plane q.  Together with nvp_encode_bwd_sparse_adamw no optimizer launch is left for the four grids (one GPU).
+int nvp_encode_bwd_dense_adamw(const float* coords, const float* dz, int32_t dz_stride, int64_t n,
+                               const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
+                               const nvp_sparse_shape* sh, void* workspace, int64_t workspace_bytes, int32_t flags,
+                               float* const* params, float* const* exp_avg, float* const* exp_avg_sq, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, const int64_t* step, void* stream) {
+    if (!params || !exp_avg || !exp_avg_sq || !step || n < 1 || !(beta1 >= 0 && beta1 < 1) || !(beta2 >= 0 && beta2 < 1)) return NVP_ERR_BADARG;
+    if (!(flags & NVP_DZ_PLANES_READY) || !(flags & NVP_COORDS_SORTED_BY_Y) || (flags & NVP_SCATTER_SPARSE_ONLY)) return NVP_ERR_BADARG;
+    DenseAdam ad;
+    for (int q = 0; q < 3; ++q) {
+        if (!params[q] || !exp_avg[q] || !exp_avg_sq[q] || step[q] < 1) return NVP_ERR_BADARG;
+        ad.p[q] = params[q]; ad.m[q] = exp_avg[q]; ad.v[q] = exp_avg_sq[q];
+        ad.S[q] = adam_scalars(lr, beta1, beta2, eps, weight_decay, step[q], 1.0);
+    }
+    ad.on = 1;
+    return encode_bwd_impl(coords, dz, dz_stride, nullptr, nullptr, nullptr, nullptr, n, lv_xy, lv_yt, lv_xt, sh, workspace, workspace_bytes,
+                           flags | NVP_SCATTER_DENSE_ONLY, stream, nullptr, &ad);
 }
 
 }  // extern "C"

@@ -81,15 +81,17 @@ class StepHooks:
       fused_sparse  an optimizer with fused_peek(tensor) / fused_commit(tensor) (optim.AdamW; one GPU, no grad_sink): the sparse
                     grid's AdamW step is applied INSIDE the scatter's flush (nvp_encode_bwd_sparse_adamw) - its gradient is never
                     written to HBM, backward returns None for it.  Falls back to the gradient + early_grads route when the
-                    optimizer declines (peek returns None) or the kernel does not support the layout."""
-    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse")
+                    optimizer declines (peek returns None) or the kernel does not support the layout;
+      fused_dense   the same for the three dense planes (nvp_encode_bwd_dense_adamw: the update runs in band_kernel's /
+                    slab_reduce_kernel's flushes).  With both set, no optimizer launch is left for the four grids."""
+    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse", "fused_dense")
 
-    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None, fused_sparse=None):
+    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None, fused_sparse=None, fused_dense=None):
         self.grad_sink, self.sparse_ready, self.grids_ready, self.early_grads = grad_sink, sparse_ready, grids_ready, early_grads
-        self.fused_sparse = fused_sparse
+        self.fused_sparse, self.fused_dense = fused_sparse, fused_dense
 
     def clear(self) -> None:
-        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = self.fused_sparse = None
+        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = self.fused_sparse = self.fused_dense = None
 
 
 _NO_HOOKS = StepHooks()
@@ -407,7 +409,10 @@ class NVPFused(torch.autograd.Function):
         ctx.ws = ctx.presorted = ctx.packed_bwd = None
         packed_fwd = None
         bwd_follows = need_grad and n and not temporal_interp
-        if n and SIDE_WORK:
+        # the side stream is only worth its hand-over (two event markers on the compute queue + one deferred-free event per buffer)
+        # when something runs on it: the scatter's presort / backward pack (a backward pass follows) or the forward pack underneath
+        # the gather kernel of the two-kernel path.  Fused inference (eval: 100 slices per frame) packs in line, below.
+        if n and SIDE_WORK and (bwd_follows or not fused):
             L.ptr(coords)                      # CPU tensors are refused here, before any stream is touched (no CPU path)
             side = _side_stream(dev)
             pstruct = L.mlp_params_struct(mlp)
@@ -450,7 +455,7 @@ class NVPFused(torch.autograd.Function):
             if DZ_LEVEL_MAJOR and y_sorted and lib.nvp_dz_lm_supported(d):
                 bflags |= L.DZ_PLANES_READY
             ctx.bflags = bflags
-            if SIDE_WORK:
+            if SIDE_WORK:                      # (bwd_follows: the hand-over above has run, `side` / `pstruct` / `pk_b` exist)
                 ctx.ws.record_stream(side)
                 with torch.cuda.stream(side):
                     L.check(lib.nvp_encode_bwd_presort(L.ptr(coords), n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh),
@@ -515,11 +520,18 @@ class NVPFused(torch.autograd.Function):
         # every gradient element is written exactly once by the sorted-band scatter: no zero-fill
         hk = ctx.hooks if ctx.hooks is not None else _NO_HOOKS
         sink = hk.grad_sink
-        # one GPU: the sparse grid's optimizer step inside the scatter's flush (no gradient tensor for it at all)
-        fused_st = None
-        if hk.fused_sparse is not None and sink is None and (ctx.bflags & L.DZ_PLANES_READY) and ctx.needs_input_grad[5]:       # [5]: emb
+        # one GPU: the grids' optimizer steps inside the scatter's flushes (no gradient tensors for them at all)
+        fused_st, fused_dn = None, None
+        split_ok = bool(ctx.bflags & L.DZ_PLANES_READY)
+        if hk.fused_sparse is not None and sink is None and split_ok and ctx.needs_input_grad[5]:       # [5]: emb
             fused_st = hk.fused_sparse.fused_peek(emb)
-        d_xy, d_yt, d_xt = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt))
+        if hk.fused_dense is not None and sink is None and split_ok and all(ctx.needs_input_grad[2:5]):  # [2:5]: the three planes
+            fused_dn = [hk.fused_dense.fused_peek(t) for t in (kf_xy, kf_yt, kf_xt)]
+            if any(f is None for f in fused_dn) or len({(f["lr"], f["beta1"], f["beta2"], f["eps"], f["weight_decay"]) for f in fused_dn}) != 1:
+                fused_dn = None             # the kernel takes one set of hyper-parameters for the three planes
+        d_xy = d_yt = d_xt = None
+        if fused_dn is None:
+            d_xy, d_yt, d_xt = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt))
         d_emb = _grad_buffer(emb, sink) if fused_st is None else None
 
         # scatter workspace: allocated (and its coordinate-only part started) in forward
@@ -554,38 +566,52 @@ class NVPFused(torch.autograd.Function):
             # for in front of the chain kernel: a second wait would only be one more marker on the compute queue
             if presorted is not None and packed_bwd is None:
                 torch.cuda.current_stream(coords.device).wait_event(presorted)
-            nonlocal d_emb, fused_st
-            if fused_st is not None:
-                f = fused_st
-                rc = _call("nvp_encode_bwd", lib.nvp_encode_bwd_sparse_adamw, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1], n,
-                           C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.ptr(ws, torch.uint8), ws_bytes, flags,
-                           L.ptr(emb), L.ptr(f["exp_avg"]), L.ptr(f["exp_avg_sq"]), f["lr"], f["beta1"], f["beta2"], f["eps"],
-                           f["weight_decay"], f["step"], L.stream_ptr())
-                if rc == L.ERR_UNSUPPORTED:             # layout the fused flush does not take: the gradient route after all
-                    fused_st = None
-                    d_emb = _grad_buffer(emb, sink)
-                else:
-                    L.check(rc, "nvp_encode_bwd_sparse_adamw")
-                    hk.fused_sparse.fused_commit(emb)
-            if fused_st is not None:
-                scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
-                if hk.early_grads is not None:
-                    hk.early_grads([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
-            elif (hk.sparse_ready is not None or hk.early_grads is not None) and (flags & L.DZ_PLANES_READY):
-                # the sparse grid (80 % of the gradient bytes) is scattered first and handed on - to the data-parallel exchange, or
-                # to the optimizer - while the dense planes are still being scattered
-                scatter_call(flags | L.SCATTER_SPARSE_ONLY)
-                if hk.sparse_ready is not None:
-                    hk.sparse_ready()
-                if hk.early_grads is not None:
-                    hk.early_grads([(emb, d_emb)])
-                scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
-                if hk.early_grads is not None:
-                    hk.early_grads([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
-            else:
-                scatter_call(flags)
+            nonlocal d_emb, fused_st, fused_dn, d_xy, d_yt, d_xt
+            if not (split_ok and (fused_st is not None or fused_dn is not None or hk.sparse_ready is not None or hk.early_grads is not None)):
+                scatter_call(flags)         # one call: sparse grid and planes
                 if hk.early_grads is not None:
                     hk.early_grads([(emb, d_emb), (kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
+            else:
+                # split scatter.  The sparse grid (80 % of the gradient bytes) first: fused with its AdamW step, or scattered and handed
+                # on - to the data-parallel exchange, or to the optimizer - while the dense planes are still being scattered
+                if fused_st is not None:
+                    f = fused_st
+                    rc = _call("nvp_encode_bwd", lib.nvp_encode_bwd_sparse_adamw, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1], n,
+                               C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.ptr(ws, torch.uint8), ws_bytes, flags,
+                               L.ptr(emb), L.ptr(f["exp_avg"]), L.ptr(f["exp_avg_sq"]), f["lr"], f["beta1"], f["beta2"], f["eps"],
+                               f["weight_decay"], f["step"], L.stream_ptr())
+                    if rc == L.ERR_UNSUPPORTED:             # layout the fused flush does not take (nothing enqueued): the gradient route after all
+                        fused_st = None
+                        d_emb = _grad_buffer(emb, sink)
+                    else:
+                        L.check(rc, "nvp_encode_bwd_sparse_adamw")
+                        hk.fused_sparse.fused_commit(emb)
+                if fused_st is None:
+                    scatter_call(flags | L.SCATTER_SPARSE_ONLY)
+                    if hk.sparse_ready is not None:
+                        hk.sparse_ready()
+                    if hk.early_grads is not None:
+                        hk.early_grads([(emb, d_emb)])
+                # then the three dense planes (the sparse call above ran the presort if nobody had)
+                if fused_dn is not None:
+                    f0 = fused_dn[0]
+                    arr = lambda key: (C.c_void_p * 3)(*[L.ptr(f[key]) for f in fused_dn])      # noqa: E731
+                    steps3 = (C.c_int64 * 3)(*[f["step"] for f in fused_dn])
+                    rc = _call("nvp_encode_bwd", lib.nvp_encode_bwd_dense_adamw, L.ptr(coords), L.ptr(dz_rows), dz_rows.shape[1], n,
+                               C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh), L.ptr(ws, torch.uint8), ws_bytes,
+                               flags | L.SCATTER_PRESORTED, arr("param"), arr("exp_avg"), arr("exp_avg_sq"), f0["lr"], f0["beta1"], f0["beta2"],
+                               f0["eps"], f0["weight_decay"], steps3, L.stream_ptr())
+                    if rc == L.ERR_UNSUPPORTED:
+                        fused_dn = None
+                        d_xy, d_yt, d_xt = (_grad_buffer(t, sink) for t in (kf_xy, kf_yt, kf_xt))
+                    else:
+                        L.check(rc, "nvp_encode_bwd_dense_adamw")
+                        for t in (kf_xy, kf_yt, kf_xt):
+                            hk.fused_dense.fused_commit(t)
+                if fused_dn is None:
+                    scatter_call(flags | L.SCATTER_DENSE_ONLY | L.SCATTER_PRESORTED)
+                    if hk.early_grads is not None:
+                        hk.early_grads([(kf_xy, d_xy), (kf_yt, d_yt), (kf_xt, d_xt)])
             if hk.grids_ready is not None:
                 hk.grids_ready()            # e.g. start the (async) all-reduce of the grid gradients
 

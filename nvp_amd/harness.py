@@ -24,7 +24,10 @@ EARLY_ADAMW = os.environ.get("NVP_EARLY_ADAMW", "1") != "0"
 # one GPU, nvp_amd.optim.AdamW, y-sorted batches: the sparse grid's AdamW step is applied by the scatter kernel's flush
 # (nvp_encode_bwd_sparse_adamw; bit-identical parameters; 0: gradient tensor + early_update)
 FUSED_SPARSE_ADAMW = os.environ.get("NVP_FUSED_SPARSE_ADAMW", "1") != "0"
+# ... and the three dense planes' by band_kernel / slab_reduce_kernel (nvp_encode_bwd_dense_adamw; bit-identical; 0: gradient tensors + early_update)
+FUSED_DENSE_ADAMW = os.environ.get("NVP_FUSED_DENSE_ADAMW", "1") != "0"
 SAMPLER_SORT = os.environ.get("NVP_SAMPLER_SORT", "nvp")        # "torch": torch.argsort for the sampler's column order
+RECORD_STREAM = os.environ.get("NVP_SAMPLER_RECORD_STREAM", "0") == "1"     # DeviceVideo(prefetch=True): record_stream on every batch tensor
 
 
 class ImageMSEU8(torch.autograd.Function):
@@ -51,7 +54,7 @@ class ImageMSEU8(torch.autograd.Function):
         # train_step seeds backward with a cached device scalar 1.0 (unit_gradient): multiplying by it would be an exact no-op that
         # costs a fill, a 30-MB element-wise pass and two launch boundaries per step
         if g.dim() == 0 and g.data_ptr() == _UNIT.get(g.device, (None, 0))[1]:
-            return drgb, None
+            return drgb.detach(), None          # a fresh alias: an in-place op on the returned gradient cannot reach the saved tensor's version counter
         return drgb * g, None
 
 
@@ -65,7 +68,7 @@ def unit_gradient(dev: torch.device) -> torch.Tensor:
     if ent is None:
         t = torch.ones((), device=dev, dtype=torch.float32)
         ent = _UNIT[dev] = (t, t.data_ptr())
-    return ent[0]
+    return ent[0]          # NEVER modify it in place (it is recognised by address, not by value): use it as a backward seed only
 
 
 def image_mse_u8(model_out: torch.Tensor, gt_u8: torch.Tensor) -> torch.Tensor:
@@ -103,6 +106,15 @@ class DeviceVideo:
             self._issue()
         batch, ev = self._next
         cur.wait_event(ev)
+        if RECORD_STREAM:                   # opt-in: consumers on OTHER streams than the one current here (see the contract below)
+            for d_ in batch:
+                for t_ in d_.values():
+                    if torch.is_tensor(t_):
+                        t_.record_stream(cur)
+        # CONTRACT (single consumer stream): a prefetched batch must be consumed on the stream that is current at this call, and
+        # the next sample() must be issued from that same stream - then the block of a freed batch can only be reused by a draw
+        # that was enqueued behind everything that read it.  A caller that reads a batch on another stream (its own copy / eval
+        # stream) sets NVP_SAMPLER_RECORD_STREAM=1, or passes prefetch=False.
         # The batch tensors come from the SIDE stream's allocator pool and are consumed on this stream.  No record_stream (each
         # would cost an event marker on the compute queue when the tensor is freed - ~11 us of queue time apiece): a freed batch
         # can only be handed out again by a later _draw, every _draw is enqueued behind `side.wait_stream(compute stream)` in
@@ -212,6 +224,8 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
             hooks.early_grads = opt.early_update    # the grids' AdamW underneath the rest of backward (one GPU)
             if FUSED_SPARSE_ADAMW:
                 hooks.fused_sparse = opt            # ... and the sparse grid's INSIDE the scatter's flush: its gradient never reaches HBM
+            if FUSED_DENSE_ADAMW:
+                hooks.fused_dense = opt             # ... the three planes' too: no optimizer launch is left for the grids
     try:
         loss.backward(gradient=unit_gradient(loss.device) if loss.is_cuda else None)
     finally:

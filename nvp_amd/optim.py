@@ -6,6 +6,12 @@ It is a regular `torch.optim.Optimizer`: `param_groups[i]['lr']` is what `Cosine
 (training.py:14), `state[p]` holds `step`, `exp_avg`, `exp_avg_sq` under torch's names, `zero_grad()` works.
 Same update rule as torch.optim.AdamW (decoupled weight decay, bias-corrected, no amsgrad/maximize).
 There is no CPU path: parameters must live on a HIP device.
+
+Early / fused updates (harness.train_step on one GPU: `early_update`, `fused_peek` / `fused_commit`) step the grids DURING backward.
+That is only equivalent to the reference's loop when every backward is followed by exactly one `step()` on unmodified gradients:
+loops that clip or accumulate gradients, inspect `.grad` of the grids (the sparse grid has none on the fused route), skip steps or
+recover from exceptions must run with NVP_EARLY_ADAMW=0 NVP_FUSED_SPARSE_ADAMW=0 (then this class is a plain fused AdamW).  An
+iteration whose step() never ran is reported by `begin_step()` (RuntimeWarning, `unfinished_iterations`).
 """
 from __future__ import annotations
 
@@ -36,6 +42,15 @@ class AdamW(torch.optim.Optimizer):
     def begin_step(self) -> None:
         """Start of an iteration: forget the early updates of an earlier iteration whose step() never ran (an exception between
         backward and step would otherwise make the next iteration skip those parameters' early update silently)."""
+        if self._early_done:
+            # The previous iteration applied early / fused updates (their parameters and moments ARE stepped) but its step() never
+            # ran - backward raised half-way, or the caller skipped step().  Nothing can be rolled back; say so instead of letting the
+            # step counts of those parameters drift ahead of the others silently.
+            import warnings
+            self.unfinished_iterations = getattr(self, "unfinished_iterations", 0) + 1
+            warnings.warn(f"nvp_amd.optim.AdamW: {len(self._early_done)} parameter tensor(s) were updated early in an iteration whose step() never "
+                          "ran; they are one optimizer step ahead of the rest (set NVP_EARLY_ADAMW=0 NVP_FUSED_SPARSE_ADAMW=0 for loops that skip or "
+                          "recover from failed steps, clip or accumulate gradients)", RuntimeWarning, stacklevel=2)
         self._early_done.clear()
 
     @torch.no_grad()
