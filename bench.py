@@ -574,36 +574,52 @@ def main():
         torch.cuda.synchronize()
         del state
         torch.cuda.empty_cache()
-        rdata = harness.DeviceVideo(video, n_samples=N_PX, seed=777, sort_by_y=False, prefetch=False)
-        ropt = torch.optim.AdamW(lr=1e-2, params=model.parameters(), weight_decay=0.001)              # training.py:13
-        rsched = torch.optim.lr_scheduler.CosineAnnealingLR(ropt, T_max=max(total, 1), eta_min=1e-5)   # training.py:14
-        for p_ in model.parameters():
-            p_.grad = None
+        from nvp_amd import compat
 
-        def ref_step():
-            mi, gt = rdata.sample()
-            gt_img = (gt["img"].float() - 127.5) / 127.5                                                 # training.py:47-48
-            out = model(mi)                                                                              # training.py:50
-            loss_ = ((out["model_out"] - gt_img) ** 2).mean()                                            # loss_functions.image_mse
-            ropt.zero_grad()                                                                             # training.py:73-76
-            loss_.backward()
-            ropt.step()
-            rsched.step()
-            return loss_
+        def run_reference_loop(opt_label):
+            rdata = harness.DeviceVideo(video, n_samples=N_PX, seed=777, sort_by_y=False, prefetch=False)
+            ropt = torch.optim.AdamW(lr=1e-2, params=model.parameters(), weight_decay=0.001)              # training.py:13
+            rsched = torch.optim.lr_scheduler.CosineAnnealingLR(ropt, T_max=max(total, 1), eta_min=1e-5)   # training.py:14
+            for p_ in model.parameters():
+                p_.grad = None
 
-        for _ in range(3):
-            ref_step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            rloss = ref_step()
-        barrier()
-        rdt = (time.perf_counter() - t0) / args.steps * 1e3
+            def ref_step():
+                mi, gt = rdata.sample()
+                gt_img = (gt["img"].float() - 127.5) / 127.5                                                 # training.py:47-48
+                out = model(mi)                                                                              # training.py:50
+                loss_ = ((out["model_out"] - gt_img) ** 2).mean()                                            # loss_functions.image_mse
+                ropt.zero_grad()                                                                             # training.py:73-76
+                loss_.backward()
+                ropt.step()
+                rsched.step()
+                return loss_
+
+            for _ in range(3):
+                ref_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rloss = ref_step()
+            barrier()
+            rdt = (time.perf_counter() - t0) / args.steps * 1e3
+            res = {"ms_per_step": round(rdt, 3), "mpx_s": round(N_PX / (rdt * 1e-3) / 1e6, 3), "final_loss": float(rloss.detach()),
+                   "optimizer": f"{type(ropt).__module__}.{type(ropt).__name__} ({opt_label})"}
+            del ropt, rsched, rdata
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            return res
+
+        stock = run_reference_loop("the reference's own call, torch's default implementation")
+        compat.install_optimizer()          # opt-in drop-in: the same call returns the one-launch nvp_adamw_step optimizer
+        try:
+            routed = run_reference_loop("the same call with nvp_amd.compat.install(optimizer=True)")
+        finally:
+            compat.uninstall_optimizer()
         ref_surface = {"what": "same workload through the reference's own loop shape (training.py:42-76): raw-order batches, model(mi)['model_out'], torch-expression "
-                               "MSE, zero_grad / backward / torch.optim.AdamW.step / CosineAnnealingLR.step; no StepHooks, no nvp_amd.harness / nvp_amd.optim",
-                       "ms_per_step": round(rdt, 3), "mpx_s": round(N_PX / (rdt * 1e-3) / 1e6, 3), "steps": args.steps, "final_loss": float(rloss.detach()),
-                       "optimizer": "torch.optim.AdamW (default implementation)", "row_order": functional.ROW_ORDER}
-        del ropt, rsched, rdata
+                               "MSE, zero_grad / backward / torch.optim.AdamW(...).step / CosineAnnealingLR.step; no StepHooks, no nvp_amd.harness",
+                       "ms_per_step": stock["ms_per_step"], "mpx_s": stock["mpx_s"], "steps": args.steps, "final_loss": stock["final_loss"],
+                       "optimizer": stock["optimizer"], "row_order": functional.ROW_ORDER,
+                       "with_compat_optimizer": routed}
     verify_replicas(mode + " (after the timed steps)")
     post_ms = sum(a.elapsed_time(b) for a, b in post_bwd) / max(len(post_bwd), 1)
     post_all = [post_ms]
@@ -707,7 +723,9 @@ def main():
             "stage_event_steps": n_inst,
             "prewarm_steps": args.prewarm,
             "isolated": iso_line,
-            "reference_surface": (dict(ref_surface, ratio_to_headline=round(ref_surface["ms_per_step"] / ms_per_step, 3)) if ref_surface else None),
+            "reference_surface": (dict(ref_surface, ratio_to_headline=round(ref_surface["ms_per_step"] / ms_per_step, 3),
+                                       ratio_to_headline_with_compat_optimizer=round(ref_surface["with_compat_optimizer"]["ms_per_step"] / ms_per_step, 3))
+                                  if ref_surface else None),
         }
         if multi:
             # what a rank spends between the end of backward and the end of the optimizer: exposed gradient exchange + its share

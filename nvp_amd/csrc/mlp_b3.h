@@ -260,13 +260,18 @@ __device__ __forceinline__ void load_step(StepOps& o, const u32x4* __restrict__ 
 #pragma unroll
         for (int k = 0; k < kP; ++k) o.q[T][k] = (w + (T * kP + k) * 64)[ul];
 }
+#ifndef NVP_PF_DEPTH
+#define NVP_PF_DEPTH 2           // NVP_CHAIN_PF_STEP == 3: k-steps of weights in flight
+#endif
 #ifndef NVP_CHAIN_PF_STEP
 #define NVP_CHAIN_PF_STEP 0      // experiment: a whole k-step of weights requested one k-step ahead (64 operand registers double-buffered)
 #endif
 
-// 8 k-steps over the previous layer's D registers, scaled by s
-template <bool PF = true>
-__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane) {
+// 8 k-steps over the previous layer's D registers, scaled by s.  post(c) runs after k-step c's MFMAs have been issued (default
+// prefetch scheme only): the forward kernel issues the PREVIOUS layer's stream stores there, a few per k-step, so that no weight
+// fetch ever has a burst of sixteen stores ahead of it in the (in-order) vector-memory return queue.
+template <bool PF = true, typename Post>
+__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane, Post post) {
 #if NVP_CHAIN_PF_STEP == 1
     if (PF) {
         StepOps o[2];
@@ -281,6 +286,27 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
             NVP_CHAIN_FENCE();
 #pragma unroll
             for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[c & 1].q[T], b);
+        }
+        return;
+    }
+#elif NVP_CHAIN_PF_STEP == 3
+    if (PF) {
+        // NVP_PF_DEPTH whole k-steps of weights in flight ahead of the one being multiplied (32 operand registers each): for kernels
+        // built at ONE wave per SIMD (512 registers), where nothing but the wave's own prefetch distance hides the ~700-cycle L2 round trip
+        constexpr int DPT = NVP_PF_DEPTH;
+        StepOps o[DPT + 1];
+#pragma unroll
+        for (int c = 0; c < DPT && c < 8; ++c) load_step(o[c], w + NVP_WSTRIDE(c * kB3StepQuads), lane);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c + DPT < 8) load_step(o[(c + DPT) % (DPT + 1)], w + NVP_WSTRIDE((c + DPT) * kB3StepQuads), lane);
+            float x[8];
+            chain_in8(x, hin, c);
+            BOp b;
+            split8(x, s, b);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[c % (DPT + 1)].q[T], b);
         }
         return;
     }
@@ -321,7 +347,12 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
         BOp b;
         split8(x, s, b);
         step_b3<PF>(acc, w + NVP_WSTRIDE(c * kB3StepQuads), b, lane);
+        post(c);
     }
+}
+template <bool PF = true>
+__device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane) {
+    chain_h_b3<PF>(acc, hin, s, w, lane, [](int) {});
 }
 
 // Two transposed GEMMs over the SAME input registers (the backward chain's dz and dh chains both consume dp): every k-step's

@@ -11,6 +11,9 @@
 #ifndef NVP_SPLIT_ASM
 #define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
 #endif
+#ifdef NVP_FWD_PF_STEP         // forward-only override of the chains' weight prefetch scheme (mlp_b3.h: NVP_CHAIN_PF_STEP)
+#define NVP_CHAIN_PF_STEP NVP_FWD_PF_STEP
+#endif
 #include <cstring>
 #include "mlp_b3.h"
 #include "encode_tile.h"      // in-wave tile gather (FMA contraction off inside, restored after)
@@ -27,9 +30,16 @@ namespace {
 constexpr int kWaves = NVP_FWD_WAVES;
 // `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
 // step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
-__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane) {
+// zg / rg_end (optional, NVP_FWD_LATE_STORES): the latent tensor's tile - the two row-groups this lane reads anyway are written out from
+// here (every row-group of the tile is read by exactly one lane of one k-step), instead of a 15-KB store burst in front of the first layer
+__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane,
+                                                float4* __restrict__ zg = nullptr, int rg_end = 0) {
     const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
     const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+    if (zg) {
+        if (4 * s + 2 * h < rg_end) zg[(4 * s + 2 * h) * 32 + j] = t0;
+        if (4 * s + 2 * h + 1 < rg_end) zg[(4 * s + 2 * h + 1) * 32 + j] = t1;
+    }
     const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
     BOp b;
     split8(x, sc, b);
@@ -37,11 +47,30 @@ __device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* 
 }
 
 // sc: the pixel's operand scale (mlp_b3.h; 1 for bf16 x 3)
-__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane) {
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
+                                           float4* __restrict__ zg = nullptr, int rg_end = 0) {
     const int j = lane & 31, h = lane >> 5;
 #if NVP_B3_ZUNROLL
     if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
-#if NVP_CHAIN_PF_STEP == 2
+#if NVP_CHAIN_PF_STEP == 3
+        constexpr int DPT = NVP_PF_DEPTH;
+        StepOps o[DPT + 1];
+#pragma unroll
+        for (int s = 0; s < DPT && s < 8; ++s) load_step(o[s], w + NVP_WSTRIDE(s * kB3StepQuads), lane);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + DPT < 8) load_step(o[(s + DPT) % (DPT + 1)], w + NVP_WSTRIDE((s + DPT) * kB3StepQuads), lane);
+            const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+            const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            BOp b;
+            split8(x, sc, b);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[s % (DPT + 1)].q[T], b);
+        }
+        return;
+#elif NVP_CHAIN_PF_STEP == 2
         // tile pairs, one pair of operand quads in flight ahead of the pair being multiplied (see chain_h_b3)
         const unsigned ul = (unsigned)lane;
         u32x4 a[2][2][kP];
@@ -71,13 +100,13 @@ __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __res
         return;
 #else
 #pragma unroll
-        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane);
+        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
         return;
 #endif
     }
 #endif
 #pragma unroll 1
-    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane);
+    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
 }
 
 // Stage this wave's latent tile into its LDS region (as stage_z, mlp_chain.h) and return the largest |z| this lane saw: every
@@ -126,7 +155,13 @@ __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __re
 // GATHERS its tile itself (encode_tile.h) - `zt` is then an OUTPUT, written only when SAVE (the dW GEMMs of the backward pass
 // read it) and may be null otherwise.
 template <bool SAVE, int GF>
-__global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __restrict__ zt, const float* __restrict__ steps,
+#ifndef NVP_FWD_LATE_STORES
+#define NVP_FWD_LATE_STORES 0  // 1: the h0 / h1 / h2 stream stores are issued inside the FOLLOWING chain, four per second k-step (bit-identical)
+#endif
+#ifndef NVP_FWD_OCC
+#define NVP_FWD_OCC 2          // workgroups per CU the kernel is built for (1: one wave per SIMD, up to 512 registers)
+#endif
+__global__ __launch_bounds__(kWaves * 64, NVP_FWD_OCC) void mlp_fwd_b3_kernel(float* __restrict__ zt, const float* __restrict__ steps,
                                                                     nvp_mlp_params p, const unsigned* __restrict__ packed,
                                                                     float* __restrict__ rgb, float* __restrict__ saved,
                                                                     int64_t n, int64_t ntiles, int d, NvpTileEnc enc) {
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __res
     const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
     float mz;                                                 // per-pixel max |z|: the latent's share of the operand scale
     if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
-    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
+    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active && !NVP_FWD_LATE_STORES) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -191,12 +226,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __res
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
         bias_b3(hm, w, ps.s, lane);
-        chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+        // fused gather + NVP_FWD_LATE_STORES: the latent tile leaves for the tensor from inside this chain (the whole latent is in LDS: fused_ok)
+        chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,
+                   (GF != 0 && NVP_FWD_LATE_STORES && SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, rg_end);
         if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
         lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
+#if !NVP_FWD_LATE_STORES
         if (SAVE && active) store_ptm(sv + 0 * act, hm, lane);
+#endif
     }
     // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
     {
@@ -224,13 +263,22 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __res
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             const PxScale ps = px_scale(fmaxf(fmaxf(px_absmax(hm), mz), 1.0f));
             bias_b3(acc, w, ps.s, lane);
+#if NVP_FWD_LATE_STORES
+            // h_{k-1} (k = 1: h0) is this chain's input and stays untouched until the epilogue below: its stream stores ride along,
+            // one 32-row tile after every second k-step
+            if (k == 1) chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane, [&](int c) { if (SAVE && active && (c & 1)) store_ptm16(sv + 0 * act, hm[c >> 1], c >> 1, lane); });
+            else chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+#else
             chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+#endif
             chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
             if (GF == 0) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
             lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
+#if !NVP_FWD_LATE_STORES
             if (SAVE && active) store_ptm(sv + (int64_t)k * act, hm, lane);
+#endif
         }
         {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
             const u32x4* w = wp + NVP_WSTRIDE(L.off[2 + k] / 4);
@@ -239,7 +287,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __res
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             const PxScale ps = px_scale(fmaxf(px_absmax(x), 1.0f));
             bias_b3(acc, w, ps.s, lane);
+#if NVP_FWD_LATE_STORES
+            chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,             // h_k (hm) is only read again in the epilogue: its stores ride along here
+                       [&](int c) { if (SAVE && active && (c & 1)) store_ptm16(sv + (int64_t)k * act, hm[c >> 1], c >> 1, lane); });
+#else
             chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+#endif
             scale4(acc, ps.u * winv[2 + k]);
             if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll

@@ -360,3 +360,22 @@ def test_bench_cpu_baseline_worker_reports_its_thread_and_numa_policy():
     pol = d["policy"]
     assert pol["threads"] == d["cores"] >= 1 and pol["physical_cores"] <= pol["allowed_cpus"]
     assert "memory" in pol and "binding" in pol and any("get_num_threads" in ln for ln in d["torch_parallel_info"])
+
+
+def test_compat_optimizer_routing_is_opt_in_and_falls_back_to_the_stock_class():
+    """compat.install(optimizer=True): the reference's `torch.optim.AdamW(lr=..., params=..., weight_decay=...)` call (training.py:13) is
+    routed to nvp_amd.optim.AdamW for fp32 HIP parameters only; CPU parameters (this container) and unusual options keep torch's class,
+    and uninstall restores torch untouched."""
+    from nvp_amd import compat
+    stock = torch.optim.AdamW
+    lin = torch.nn.Linear(4, 3)
+    try:
+        compat.install_optimizer()
+        assert torch.optim.AdamW is not stock
+        opt = torch.optim.AdamW(lr=1e-2, params=lin.parameters(), weight_decay=0.001)       # CPU tensors: the stock optimizer
+        assert isinstance(opt, stock) and opt.defaults["weight_decay"] == 0.001 and opt.defaults["lr"] == 1e-2
+        opt2 = torch.optim.AdamW(lin.parameters(), lr=1e-3, amsgrad=True)
+        assert isinstance(opt2, stock) and opt2.defaults["amsgrad"]
+    finally:
+        compat.uninstall_optimizer()
+    assert torch.optim.AdamW is stock

@@ -54,6 +54,7 @@ tpath = os.path.join(root, "profiles", "pmc_traffic.json")
 allt = json.load(open(tpath)) if os.path.exists(tpath) else {}
 if "nvp_mlp_fwd" in allt or "nvp_mlp_bwd_dw" in allt:        # round-2 flat layout (configs[1]) -> per-config layout
     allt = {"s": allt}
-allt[config] = {k: round(v) for k, v in stage.items() if k}
-json.dump(allt, open(tpath, "w"), indent=1)
+if any(v > 0 for v in stage.values()):          # (a diagnosis-only run - no fetch / write passes - leaves the traffic record alone)
+    allt[config] = {k: round(v) for k, v in stage.items() if k}
+    json.dump(allt, open(tpath, "w"), indent=1)
 print("\n".join(out[:12])); print(dict(stage))
