@@ -143,6 +143,7 @@ def work_per_pixel(F: int):
         "nvp_mlp_bwd_dx": 2 * (3 * 128 * D + 2 * 128 * 128 + 2 * 128 * 128 + 3 * 128),              # dX of every layer but SIREN 0
         "nvp_mlp_bwd_dw": 2 * (128 * D + 2 * 128 * (128 + D) + 2 * 128 * 128 + 3 * 128 + 128),       # dW: same MACs as fwd
     }
+    flop["nvp_encode_mlp_fwd_bwd"] = flop["nvp_encode_mlp_fwd"] + flop["nvp_mlp_bwd_dx"]            # tile-fused step kernel: forward + backward chain
     R = (D + 3) // 4 * 4          # PTM4 rows of the latent
     byts = {
         # gather: coords 12 + 192 corner F-vectors + 9 sparse F-vectors (4F bytes each) + latent write 4D
@@ -156,6 +157,9 @@ def work_per_pixel(F: int):
         "nvp_mlp_bwd_dx": 12 + 4 + 5 * 512 + 5 * 512 + 80 + 4 * R,  # drgb + step + 5 saved streams in; dp0-2 dq1-2, tile records, latent gradient out
         "nvp_mlp_bwd_dw": 5 * 512 + 4 * R + 3 * 512,                # every operand stream once: dp0-2 dq1-2, z, h0 h1 q1 (jobs that share a stream re-read it)
     }
+    # tile-fused forward + backward chain: what has to cross HBM - coords, step, gt in; the gathered cells; latent, h0 h1 q1 (the dW GEMMs read
+    # them), RGB, the five dY streams, the tile records and the latent gradient out.  h2 / q2 exist only between the two halves of a tile.
+    byts["nvp_encode_mlp_fwd_bwd"] = 12 + 4 + 3 + (192 + 9) * 4 * F + 4 * R + 3 * 512 + 12 + 5 * 512 + 80 + 4 * R
     return flop, byts
 
 
@@ -163,7 +167,7 @@ PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 PEAK_MFMA_16 = 2516.6e12        # bf16 / fp16 dense peak (32x32x16 forms)
 # stages that run on split-operand 16-bit MFMA: forward, backward chain and dW GEMMs (latents <= 256 rows); their
 # peak in fp32-equivalent FLOP is the 16-bit dense peak / the products issued per fp32 product (3: fp16 x 2 split, 6: bf16 x 3)
-B3_STAGES = ("nvp_encode_mlp_fwd", "nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
+B3_STAGES = ("nvp_encode_mlp_fwd_bwd", "nvp_encode_mlp_fwd", "nvp_mlp_fwd", "nvp_mlp_bwd_dx", "nvp_mlp_bwd_dw")
 PEAK_HBM = 8.0e12
 
 

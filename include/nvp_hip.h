@@ -255,6 +255,7 @@ int nvp_mlp_bwd_dw(const float* drgb, const float* steps, const float* zt, const
                    const float* dy, const nvp_mlp_params* p, float* partials, int32_t n_chunks,
                    const nvp_mlp_grads* g, int64_t n, int32_t latent_dim, void* stream);
 
+
 /* ---- R13: image_mse (reference loss_functions.py:1-3 with training.py:47-48) ---------
  * gt_u8 [N,3] uint8.  loss_sum[0] += sum((rgb-gt)^2) (caller zeroes, divides by 3N);
  * drgb = 2*(rgb-gt)/(3N) i.e. d(mean)/d(rgb).  drgb may be NULL. */

@@ -116,7 +116,14 @@ SIGNATURES = {
 _RESTYPES = {
     "nvp_packed_fwd_floats": _i64, "nvp_packed_bwd_floats": _i64, "nvp_dw_partial_floats": _i64, "nvp_sample_order_workspace_bytes": _i64, "nvp_order_by_rows_workspace_bytes": _i64,
     "nvp_mlp_param_floats": _i64, "nvp_latent_rows": _i32, "nvp_version": C.c_char_p,
-    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32, "nvp_mlp_mfma_products": _i32, "nvp_encode_mlp_fwd_supported": _i32,
+    "nvp_encode_bwd_workspace_bytes": _i64, "nvp_dz_stride": _i32, "nvp_dz_lm_supported": _i32, "nvp_mlp_mfma_products": _i32, "nvp_encode_mlp_fwd_supported": _i32, "nvp_encode_mlp_fwd_bwd_supported": _i32,
+}
+
+# include/nvp_hip_experiments.h: entry points only libnvp_hip_experiments.so exports (bound when present; the product path never needs them)
+EXPERIMENT_SIGNATURES = {
+    "nvp_encode_mlp_fwd_bwd_supported": [C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],
+    "nvp_encode_mlp_fwd_bwd": [_p, _p, _p, _p, _p, _p, _p, C.POINTER(MlpParams), _p, _p, _p, _p, _p, _p, _p, C.POINTER(ScatterLm), _i64,
+                               C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape), _vp],
 }
 
 _lib: Optional[C.CDLL] = None
@@ -136,8 +143,18 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    for name, argtypes in EXPERIMENT_SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
     return lib
+
+
+def has_entry(name: str) -> bool:
+    """True when the loaded library exports `name` (experiments-only entry points, include/nvp_hip_experiments.h)."""
+    return hasattr(load(), name)
 
 
 ERR_BADARG, ERR_UNSUPPORTED = -1, -2          # include/nvp_hip.h

@@ -29,7 +29,7 @@ build_lib() {
   for f in $SRCS; do
     [ -f "$f.hip" ] || continue
     local o="$objdir/$f.o"
-    if [ ! -f "$o" ] || [ "$f.hip" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o" 2>/dev/null)" ] || [ ../../include/nvp_hip.h -nt "$o" ] || [ -n "${NVP_REBUILD:-}" ]; then
+    if [ ! -f "$o" ] || [ "$f.hip" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o" 2>/dev/null)" ] || [ ../../include/nvp_hip.h -nt "$o" ] || [ ../../include/nvp_hip_experiments.h -nt "$o" ] || [ -n "${NVP_REBUILD:-}" ]; then
       local EXTRA=""
       case "$f" in encode|encode_fwd_lds|encode_bwd|harness|optim) EXTRA="-ffp-contract=off";; esac   # separately rounded mul/add (index parity)
       rm -f "$o"

@@ -9,6 +9,10 @@
 #define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
 #endif
 #include "mlp_b3_ring.h"
+#if NVP_EXPERIMENTS
+#include "mlp_fwd_b3_tile.h"      // the forward tile body, for the tile-fused forward + backward-chain kernel (experiments build)
+#include "../../include/nvp_hip_experiments.h"
+#endif
 
 #ifndef NVP_RING_MERGE_OPEN
 #define NVP_RING_MERGE_OPEN 0     // experiment: a layer's dx chain and its shared dz / dh pass are fed by ONE ring fill (48 half-steps)
@@ -25,19 +29,13 @@ __device__ __forceinline__ void load_act16(f32x16& v, const float* __restrict__ 
 // FUSE_DZ (latent <= 128 rows): the weights come from the consumption-ordered copy (z / mod-h streams interleaved per k-step);
 // otherwise every chain walks ONE stream, whose ordinary packed layout already is its consumption order (a k-step's four tiles =
 // two consecutive half-steps), so the ring reads the plain streams: half-step 16 s of stream s.
+// One 32-pixel tile of the backward chain.  (g0, g1, g2): the loss gradient of this lane's pixel (0 beyond the batch); xl_all: the
+// workgroup's LDS (four per-wave transpose / parking tiles, then the ring).  All four waves of the workgroup must call it (barriers).
 template <bool FUSE_DZ>
-__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
-                                                                    const float* __restrict__ saved, nvp_mlp_params p,
-                                                                    const unsigned* __restrict__ packed,
-                                                                    float* __restrict__ dy, float* __restrict__ dzr, NvpDzLm lm,
-                                                                    int64_t n, int64_t ntiles, int d) {
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int64_t tile = (int64_t)blockIdx.x * kWaves + wv;   // provably wave-uniform
-    // Every wave of the workgroup walks the ring (barriers).  A wave beyond the last tile recomputes the last tile and
-    // rewrites that tile's outputs with the very same values (benign: identical bits), so no store needs a predicate.
-    if (tile >= ntiles) tile = ntiles - 1;
-    nvp_stagger_start();
+__device__ __forceinline__ void bwd_b3r_tile(float g0, float g1, float g2, const float* __restrict__ steps,
+                                             const float* __restrict__ saved, const nvp_mlp_params& p, const unsigned* __restrict__ packed,
+                                             float* __restrict__ dy, float* __restrict__ dzr, const NvpDzLm& lm,
+                                             int64_t n, int64_t ntiles, int d, int64_t tile, int wv, int lane, float* __restrict__ xl_all) {
     const int j = lane & 31, h = lane >> 5;
     const int64_t px = tile * 32 + j;
     const bool valid = px < n;
@@ -50,8 +48,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
 
     // this wave's private LDS tile [128 features][32 px] (row stride 33): transposes x2 and dq0 so that a lane
     // can sum one feature row over the tile's pixels (the last layer's and SIREN layer 0's weight gradients)
-    extern __shared__ __attribute__((aligned(16))) float xl_all[];          // [4 waves][kRecTileFloats] | ring: 2 x kHalfQuads u32x4
-    float* xl = xl_all + wv * kRecTileFloats;
+    float* xl = xl_all + wv * kRecTileFloats;                               // xl_all: [4 waves][kRecTileFloats] | ring: 2 x kHalfQuads u32x4
     HRing R;
     R.lds = reinterpret_cast<u32x4*>(xl_all + kWaves * kRecTileFloats);
     R.g = reinterpret_cast<const u32x4*>(FUSE_DZ ? packed + nvp_bwd_b3_ring_off(4) : packed);
@@ -60,8 +57,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
     float* rec = dy + 3 * act + tile * (int64_t)NVP_H * 32;      // this tile's record (stream-3 slot)
 
     f32x16 dx[4], dh[4];
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (valid) { g0 = drgb[px * 3 + 0]; g1 = drgb[px * 3 + 1]; g2 = drgb[px * 3 + 2]; }
 
     // ---- last layer: dx2 = V3^T drgb (VALU, 3 terms)
     {
@@ -301,6 +296,27 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float
 }
 
 
+template <bool FUSE_DZ>
+__global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_b3r_kernel(const float* __restrict__ drgb, const float* __restrict__ steps,
+                                                                    const float* __restrict__ saved, nvp_mlp_params p,
+                                                                    const unsigned* __restrict__ packed,
+                                                                    float* __restrict__ dy, float* __restrict__ dzr, NvpDzLm lm,
+                                                                    int64_t n, int64_t ntiles, int d) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t tile = (int64_t)blockIdx.x * kWaves + wv;   // provably wave-uniform
+    // Every wave of the workgroup walks the ring (barriers).  A wave beyond the last tile recomputes the last tile and
+    // rewrites that tile's outputs with the very same values (benign: identical bits), so no store needs a predicate.
+    if (tile >= ntiles) tile = ntiles - 1;
+    nvp_stagger_start();
+    extern __shared__ __attribute__((aligned(16))) float xl_all[];          // [4 waves][kRecTileFloats] | ring: 2 x kHalfQuads u32x4
+    const int64_t px = tile * 32 + (lane & 31);
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (px < n) { g0 = drgb[px * 3 + 0]; g1 = drgb[px * 3 + 1]; g2 = drgb[px * 3 + 2]; }
+    bwd_b3r_tile<FUSE_DZ>(g0, g1, g2, steps, saved, p, packed, dy, dzr, lm, n, ntiles, d, tile, wv, lane, xl_all);
+}
+
+
 // ---- latent gradient of a wide latent through a full-step ring ---------------------------------------------------------
 // mlp_bwd_dz_b3_kernel<8> (mlp_bwd_b3.hip) pulls the three eight-tile z^T streams - 384 KiB per 32-pixel tile - through every
 // wave's own vector-memory path.  Here the four waves of a workgroup share them: a ring slot holds one whole k-step (ZT tiles x
@@ -424,6 +440,56 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3r_kernel(const fl
     nvp_dz_lm_finish(lm, mx, msx, tile, lane);
 }
 
+#if NVP_EXPERIMENTS
+// ---- tile-fused forward + backward chain (nvp_encode_mlp_fwd_bwd) -----------------------------------------------------------------------
+// The three-kernel step writes the five saved streams (2 560 B per pixel) in the forward kernel and reads them back in the backward
+// chain a full kernel later, from HBM.  image_mse's gradient is per pixel - d/d rgb = 2 (rgb - gt) / (3 N), loss_functions.py:1-3 - so
+// a wave can run the backward chain of its tile right after the forward of the SAME tile: the streams it reads are the ones it has just
+// written (memory-side-cache hits instead of HBM reads: the backward chain alone runs 16 % faster on cache-hot inputs,
+// profiles/r04_probe_hot_streams.txt).  Both bodies are the ones of the separate kernels (fwd_b3_tile, bwd_b3r_tile): same arithmetic,
+// same buffers, bit-identical outputs; only the order of the work changes.  The wave's LDS region serves first as the forward's latent
+// tile, then as the backward's transpose / parking tile.
+template <int GF>
+__global__ __launch_bounds__(kWaves * 64, 2) void step_b3_kernel(float* __restrict__ zt, const float* __restrict__ steps, const uint8_t* __restrict__ gt, float gscale,
+                                                                nvp_mlp_params p, const unsigned* __restrict__ packed_f, const unsigned* __restrict__ packed_b,
+                                                                float* __restrict__ rgb, float* __restrict__ saved, float* __restrict__ dy, float* __restrict__ dzr,
+                                                                NvpDzLm lm, int64_t n, int64_t ntiles, int d, NvpTileEnc enc) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t tile = (int64_t)blockIdx.x * kWaves + wv;
+    if (tile >= ntiles) tile = ntiles - 1;              // duplicate walk of the last tile (the ring's barriers need all four waves): identical stores
+    nvp_stagger_start();
+    extern __shared__ __attribute__((aligned(16))) float xl_all[];          // [4 waves][kRecTileFloats] | ring
+    float rgb_px[3];
+    fwd_b3_tile<true, GF>(zt, steps, p, packed_f, rgb, saved, n, ntiles, d, enc, tile, true, reinterpret_cast<float4*>(xl_all + wv * kRecTileFloats), lane, rgb_px);
+    // the loss gradient of this lane's pixel, exactly as mse_u8_kernel (harness.hip) computes it
+    const int64_t px = tile * 32 + (lane & 31);
+    float g[3] = {0.f, 0.f, 0.f};
+    if (px < n) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float q = __fdiv_rn(__fsub_rn((float)gt[px * 3 + c], 127.5f), 127.5f);
+            const float df = rgb_px[c] - q;
+            g[c] = df * gscale;
+        }
+    }
+    // The backward chain reads what THIS wave has just stored: the stores only have to have left the wave (vector L1 is write-through,
+    // the lines were never read before, so no stale copy exists).  An agent-scope release / acquire pair here costs an L2 write-back and
+    // an L1 invalidate per wave: the kernel took 6.35 ms with it (profiles/r04_ab_tile_fused.txt).
+#ifndef NVP_STEP_AGENT_FENCE
+#define NVP_STEP_AGENT_FENCE 0
+#endif
+#if NVP_STEP_AGENT_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    bwd_b3r_tile<true>(g[0], g[1], g[2], steps, saved, p, packed_b, dy, dzr, lm, n, ntiles, d, tile, wv, lane, xl_all);
+}
+
+#endif  // NVP_EXPERIMENTS
+
 }  // namespace
 
 // called by nvp_mlp_bwd_dx (mlp_bwd.hip) when NVP_BWD_B3 is on and NVP_MLP_RING_BWD != 0
@@ -443,3 +509,56 @@ int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* s
     NVP_LAUNCH_CHECK();
     return 0;
 }
+
+#if NVP_EXPERIMENTS
+// ---- C ABI of the tile-fused step -------------------------------------------------------------------------------------------------
+static bool step_fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, int* d_out) {
+    int d = 0;
+    if (!NVP_BWD_B3 || !fused_ok(lv_xy, lv_yt, lv_xt, sh, &d)) return false;
+    if (nvp_bwd_b3_zt(d) != 4 || !nvp_dz_lm_supported(d)) return false;                          // fused latent gradient, level-major hand-over
+    if (nvp_fwd_layout_b3(d).zs * 4 * 32 * 4 > kRecTileFloats) return false;                     // the latent tile must fit the backward's per-wave LDS tile
+    if (d_out) *d_out = d;
+    return true;
+}
+
+extern "C" int32_t nvp_encode_mlp_fwd_bwd_supported(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh) {
+    return step_fused_ok(lv_xy, lv_yt, lv_xt, sh, nullptr) ? 1 : 0;
+}
+
+extern "C" int nvp_encode_mlp_fwd_bwd(const float* coords, const float* steps, const uint8_t* gt_u8, const float* kf_xy, const float* kf_yt, const float* kf_xt,
+                                      const float* emb, const nvp_mlp_params* p, const float* packed_fwd, const float* packed_bwd, float* rgb, float* saved,
+                                      float* zt, float* dy, float* dz_rows, const nvp_scatter_lm* lm_host, int64_t n,
+                                      const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, void* stream) {
+    int d = 0;
+    if (!step_fused_ok(lv_xy, lv_yt, lv_xt, sh, &d)) return NVP_ERR_UNSUPPORTED;
+    if (!coords || !steps || !gt_u8 || !kf_xy || !kf_yt || !kf_xt || !emb || !p || !packed_fwd || !packed_bwd || !rgb || !saved || !zt || !dy || !dz_rows || n < 0)
+        return NVP_ERR_BADARG;
+    NvpDzLm lm = NVP_DZLM_OFF;
+    if (lm_host && lm_host->dzs[0]) {
+        if (!lm_host->dzs[1] || !lm_host->dzmax || !lm_host->sdzmax) return NVP_ERR_BADARG;
+        if ((lm_host->scol0 & 3) || lm_host->scol0 < 0 || lm_host->scols < 0 || lm_host->scol0 + lm_host->scols > nvp_dz_stride_dev(d)) return NVP_ERR_BADARG;
+        lm.dzs[0] = lm_host->dzs[0]; lm.dzs[1] = lm_host->dzs[1]; lm.dzmax = lm_host->dzmax;
+        lm.sdzmax = lm_host->sdzmax; lm.scol0 = lm_host->scol0; lm.scols = lm_host->scols;
+    }
+    if (n == 0) return 0;
+    NvpTileEnc e;
+    e.lv[0] = *lv_xy; e.lv[1] = *lv_yt; e.lv[2] = *lv_xt; e.sh = *sh;
+    e.kf[0] = kf_xy; e.kf[1] = kf_yt; e.kf[2] = kf_xt; e.emb = emb; e.coords = coords;
+    int col = 0;
+    for (int q = 0; q < 3; ++q) { e.col0[q] = col; col += e.lv[q].n_levels * e.lv[q].n_features; }
+    e.col0[3] = col;
+    e.rows = nvp_rows4(d);
+    const int64_t ntiles = nvp_ntiles(n);
+    dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
+    const size_t lds = kWaves * kRecTileFloats * sizeof(float) + 2 * kHalfQuads * sizeof(u32x4);
+    const float gscale = 2.0f / (float)(n * 3);                   // == nvp_mse_u8's
+    const unsigned* pf = reinterpret_cast<const unsigned*>(packed_fwd);
+    const unsigned* pb = reinterpret_cast<const unsigned*>(packed_bwd);
+    if (lv_xy->n_features == 2)
+        hipLaunchKernelGGL((step_b3_kernel<2>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, gt_u8, gscale, *p, pf, pb, rgb, saved, dy, dz_rows, lm, n, ntiles, d, e);
+    else
+        hipLaunchKernelGGL((step_b3_kernel<4>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, gt_u8, gscale, *p, pf, pb, rgb, saved, dy, dz_rows, lm, n, ntiles, d, e);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+#endif  // NVP_EXPERIMENTS

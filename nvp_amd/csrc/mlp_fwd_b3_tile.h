@@ -1,0 +1,327 @@
+// The forward MLP's per-tile body and its latent-chain helpers, shared by mlp_fwd_b3.hip (the forward kernels) and mlp_bwd_b3r.hip (the
+// tile-fused forward + backward-chain kernel, nvp_encode_mlp_fwd_bwd).  See mlp_fwd_b3.hip for the description.
+#pragma once
+#ifndef NVP_SPLIT_ASM
+#define NVP_SPLIT_ASM 2        // chain kernels: residuals of the fp16 x 2 split as v_fma_mix with op_sel (mlp_b3.h); -0.02 ms each, same bits
+#endif
+#include <cstring>
+#include "mlp_b3.h"
+#include "encode_tile.h"      // in-wave tile gather (FMA contraction off inside, restored after)
+
+#ifndef NVP_B3_ZUNROLL
+#define NVP_B3_ZUNROLL 1        // straight-line latent chain for the 8-step (nvp_s) case: 1.854 vs 1.879 ms
+#endif
+#ifndef NVP_FWD_LATE_STORES
+#define NVP_FWD_LATE_STORES 0  // 1: the h0 / h1 / h2 stream stores are issued inside the FOLLOWING chain, four per second k-step (bit-identical; not faster)
+#endif
+#ifndef NVP_FWD_SYNC
+#define NVP_FWD_SYNC 0          // experiment: s_barrier at every layer start keeps the workgroup's four waves in phase (their weight loads then hit in L1)
+#endif
+#if NVP_FWD_SYNC
+#define NVP_LAYER_SYNC() asm volatile("s_barrier" ::: "memory")
+#else
+#define NVP_LAYER_SYNC()
+#endif
+
+namespace {
+
+
+// `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
+// step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
+// zg / rg_end (optional, NVP_FWD_LATE_STORES): the latent tensor's tile - the two row-groups this lane reads anyway are written out from
+// here (every row-group of the tile is read by exactly one lane of one k-step), instead of a 15-KB store burst in front of the first layer
+__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane,
+                                                float4* __restrict__ zg = nullptr, int rg_end = 0) {
+    const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+    const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+    if (zg) {
+        if (4 * s + 2 * h < rg_end) zg[(4 * s + 2 * h) * 32 + j] = t0;
+        if (4 * s + 2 * h + 1 < rg_end) zg[(4 * s + 2 * h + 1) * 32 + j] = t1;
+    }
+    const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    BOp b;
+    split8(x, sc, b);
+    step_b3(acc, w + NVP_WSTRIDE(s * kB3StepQuads), b, lane);
+}
+
+// sc: the pixel's operand scale (mlp_b3.h; 1 for bf16 x 3)
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
+                                           float4* __restrict__ zg = nullptr, int rg_end = 0) {
+    const int j = lane & 31, h = lane >> 5;
+#if NVP_B3_ZUNROLL
+    if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
+#if NVP_CHAIN_PF_STEP == 3
+        constexpr int DPT = NVP_PF_DEPTH;
+        StepOps o[DPT + 1];
+#pragma unroll
+        for (int s = 0; s < DPT && s < 8; ++s) load_step(o[s], w + NVP_WSTRIDE(s * kB3StepQuads), lane);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + DPT < 8) load_step(o[(s + DPT) % (DPT + 1)], w + NVP_WSTRIDE((s + DPT) * kB3StepQuads), lane);
+            const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+            const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            BOp b;
+            split8(x, sc, b);
+            NVP_CHAIN_FENCE();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[s % (DPT + 1)].q[T], b);
+        }
+        return;
+#elif NVP_CHAIN_PF_STEP == 2
+        // tile pairs, one pair of operand quads in flight ahead of the pair being multiplied (see chain_h_b3)
+        const unsigned ul = (unsigned)lane;
+        u32x4 a[2][2][kP];
+        auto load_pair = [&](int p, int buf) {
+            const u32x4* wp = w + NVP_WSTRIDE((p >> 1) * kB3StepQuads) + (p & 1) * 2 * kP * 64;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int k = 0; k < kP; ++k) a[buf][t][k] = (wp + (t * kP + k) * 64)[ul];
+        };
+        load_pair(0, 0);
+        BOp b;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (p + 1 < 16) load_pair(p + 1, (p + 1) & 1);
+            if ((p & 1) == 0) {
+                const int s = p >> 1;
+                const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
+                const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
+                const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                split8(x, sc, b);
+            }
+            NVP_CHAIN_FENCE();
+            mac_parts(acc[2 * (p & 1)], a[p & 1][0], b);
+            mac_parts(acc[2 * (p & 1) + 1], a[p & 1][1], b);
+        }
+        return;
+#else
+#pragma unroll
+        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
+        return;
+#endif
+    }
+#endif
+#pragma unroll 1
+    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
+}
+
+// Stage this wave's latent tile into its LDS region (as stage_z, mlp_chain.h) and return the largest |z| this lane saw: every
+// float4 a lane moves belongs to pixel lane & 31 (the tile is [row-group][32 px] and 64 divides every chunk offset), so the
+// two lane halves' maxima combine to the pixel's.
+__device__ __forceinline__ float stage_z_absmax(float4* __restrict__ zl, const float4* __restrict__ z4, int n4, int lane) {
+    float m = 0.f;
+    for (int base = 0; base < n4; base += 16 * 64) {          // <= 2 passes (rows <= 256)
+        float4 tmp[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                        // 16 independent 1-KiB wave loads in flight
+            const int idx = base + k * 64 + lane;
+            tmp[k] = idx < n4 ? z4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = base + k * 64 + lane;
+            if (idx < n4) zl[idx] = tmp[k];
+            m = absmax_f4(m, tmp[k]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return m;
+}
+
+// k-steps [s0, s1) straight from the latent tensor (wide latents: rows the LDS tile does not hold); row-groups at or
+// beyond rg_end (the tensor's rows / 4) read as zero - the tile of the LAST pixels is followed by nothing
+__device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end, const float sc,
+                                            const u32x4* __restrict__ w, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int s = s0; s < s1; ++s) {
+        const int rg = 4 * s + 2 * h;
+        const float4 t0 = rg < rg_end ? zg[rg * 32 + j] : zero;
+        const float4 t1 = rg + 1 < rg_end ? zg[(rg + 1) * 32 + j] : zero;
+        const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        BOp b;
+        split8(x, sc, b);
+        step_b3(acc, w + s * kB3StepQuads, b, lane);
+    }
+}
+
+// GF = 0: the latent tile is staged from the tensor `zt` a gather kernel wrote.  GF = 2 / 4 (= features per level): the wave
+// GATHERS its tile itself (encode_tile.h) - `zt` is then an OUTPUT, written only when SAVE (the dW GEMMs of the backward pass
+// read it) and may be null otherwise.
+// One 32-pixel tile, all seven layers.  `z`: this wave's LDS latent region; `active` false: a duplicate walk whose results are not stored.
+// rgb_out: the tile pixel lane & 31's RGB (the tile-fused kernel derives the loss gradient from it).
+template <bool SAVE, int GF>
+__device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float* __restrict__ steps, const nvp_mlp_params& p, const unsigned* __restrict__ packed,
+                                            float* __restrict__ rgb, float* __restrict__ saved, int64_t n, int64_t ntiles, int d, const NvpTileEnc& enc,
+                                            int64_t tile, bool active, float4* __restrict__ z, int lane, float (&rgb_out)[3]) {
+    const int j = lane & 31, h = lane >> 5;
+    const NvpFwdLayoutB3 L = nvp_fwd_layout_b3(d);
+    // latent tile -> this wave's LDS region: the first zs_l k-steps' rows, zero-padded to whole k-steps (the packed
+    // weights are zero there, but 0 x garbage could be NaN); wide latents (nvp_l) read the remaining rows from the tensor
+    const int zs_l = min(L.zs, kB3ZLdsSteps);
+    const int zl4 = zs_l * 4 * 32;                           // float4 per wave in LDS (the caller's `z` region holds at least that)
+    const int z4 = (nvp_rows4(d) / 4) * 32;
+    const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
+    float mz;                                                 // per-pixel max |z|: the latent's share of the operand scale
+    if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
+    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active && !NVP_FWD_LATE_STORES) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
+    for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (NVP_SPLIT_H2) {
+        if (GF == 0) for (int idx = zl4 + lane; idx < z4; idx += 64) mz = absmax_f4(mz, zg[idx]);      // wide latents: the rows the LDS tile does not hold
+        mz = fmaxf(mz, __shfl_xor(mz, 32));
+    }
+    const int rg_end = nvp_rows4(d) / 4;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(packed);
+    const float* tab = reinterpret_cast<const float*>(packed + L.off[5]);      // sir_w0 / sir_b0 / last_w in D-register order
+    const float* winv = tab + kB3ScaleOff + 8;                                 // 2^-e of each weight stream (mlp_layout.h)
+    const int64_t px = tile * 32 + j;
+    const float s = px < n ? steps[px] : 0.f;
+    const int64_t act = ntiles * (int64_t)NVP_H * 32;
+    float* sv = (SAVE && active) ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
+
+    f32x16 hm[4], x[4], acc[4];
+
+    // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
+    {
+        const u32x4* w = wp + NVP_WSTRIDE(L.off[0] / 4);
+        NVP_LAYER_SYNC();
+#pragma unroll
+        for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
+        const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
+        bias_b3(hm, w, ps.s, lane);
+        // fused gather + NVP_FWD_LATE_STORES: the latent tile leaves for the tensor from inside this chain (the whole latent is in LDS: fused_ok)
+        chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,
+                   (GF != 0 && NVP_FWD_LATE_STORES && SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, rg_end);
+        if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
+        lrelu4_scaled(hm, ps.u * winv[0]);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
+#if !NVP_FWD_LATE_STORES
+        if (SAVE && active) store_ptm(sv + 0 * act, hm, lane);
+#endif
+    }
+    // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
+    {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            float w0v[16], c0v[16];
+            load_tab16(w0v, tab, 0, T, h);
+            load_tab16(c0v, tab, 1, T, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = 30.0f * __fmaf_rn(s, w0v[r], c0v[r]);
+                x[T][r] = nvp_sin(q) * hm[T][r];
+            }
+            nvp_pin(x[T]);
+            NVP_LOAD_FENCE();
+        }
+    }
+    // ---- layers 1 and 2
+#pragma unroll
+    for (int k = 1; k <= 2; ++k) {
+        {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
+            const u32x4* w = wp + NVP_WSTRIDE(L.off[k] / 4);
+            NVP_LAYER_SYNC();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            const PxScale ps = px_scale(fmaxf(fmaxf(px_absmax(hm), mz), 1.0f));
+            bias_b3(acc, w, ps.s, lane);
+#if NVP_FWD_LATE_STORES
+            // h_{k-1} (k = 1: h0) is this chain's input and stays untouched until the epilogue below: its stream stores ride along,
+            // one 32-row tile after every second k-step
+            if (k == 1) chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane, [&](int c) { if (SAVE && active && (c & 1)) store_ptm16(sv + 0 * act, hm[c >> 1], c >> 1, lane); });
+            else chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+#else
+            chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+#endif
+            chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
+            if (GF == 0) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
+            lrelu4_scaled(acc, ps.u * winv[k]);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
+#if !NVP_FWD_LATE_STORES
+            if (SAVE && active) store_ptm(sv + (int64_t)k * act, hm, lane);
+#endif
+        }
+        {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
+            const u32x4* w = wp + NVP_WSTRIDE(L.off[2 + k] / 4);
+            NVP_LAYER_SYNC();
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
+            const PxScale ps = px_scale(fmaxf(px_absmax(x), 1.0f));
+            bias_b3(acc, w, ps.s, lane);
+#if NVP_FWD_LATE_STORES
+            chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,             // h_k (hm) is only read again in the epilogue: its stores ride along here
+                       [&](int c) { if (SAVE && active && (c & 1)) store_ptm16(sv + (int64_t)k * act, hm[c >> 1], c >> 1, lane); });
+#else
+            chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
+#endif
+            scale4(acc, ps.u * winv[2 + k]);
+            if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[T][r] = nvp_sin(acc[T][r]) * hm[T][r];
+#pragma unroll
+            for (int T = 0; T < 4; ++T) nvp_pin(x[T]);
+        }
+    }
+    // ---- last layer (3 x 128, Identity): VALU dot products + cross-half add
+    {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            float v0[16], v1[16], v2[16];
+            load_tab16(v0, tab, 2, T, h);
+            load_tab16(v1, tab, 3, T, h);
+            load_tab16(v2, tab, 4, T, h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = x[T][r];
+                o0 = __fmaf_rn(v0[r], v, o0);
+                o1 = __fmaf_rn(v1[r], v, o1);
+                o2 = __fmaf_rn(v2[r], v, o2);
+            }
+            asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
+            NVP_LOAD_FENCE();
+        }
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o2 += __shfl_xor(o2, 32);
+        rgb_out[0] = o0 + p.last_b[0]; rgb_out[1] = o1 + p.last_b[1]; rgb_out[2] = o2 + p.last_b[2];      // (both lane halves hold the pixel's RGB)
+        if (active && h == 0 && px < n) {
+            rgb[px * 3 + 0] = rgb_out[0];
+            rgb[px * 3 + 1] = rgb_out[1];
+            rgb[px * 3 + 2] = rgb_out[2];
+        }
+    }
+}
+
+// ---- R11 fused: coordinates -> RGB in ONE kernel (the gather runs inside the forward MLP's waves) --------------------------------
+// Supported when the whole latent fits the wave's LDS tile (<= 144 rows: config_nvp_s) and the grids have 2 or 4 features per level,
+// every plane's rows start on a row-group boundary; nvp_encode_mlp_fwd_supported() tells a host.
+bool fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, int* d_out) {
+    if (!NVP_FWD_B3 || !lv_xy || !lv_yt || !lv_xt || !sh) return false;
+    const int F = lv_xy->n_features;
+    if (!(F == 2 || F == 4) || lv_yt->n_features != F || lv_xt->n_features != F || sh->n_features != F || sh->y_res < 3) return false;
+    const nvp_levels* lv[3] = {lv_xy, lv_yt, lv_xt};
+    int d = 0;
+    for (int q = 0; q < 3; ++q) {
+        if (lv[q]->flags != kTileFlags) return false;        // the in-wave gather is compiled for the default arithmetic variant
+        if (lv[q]->n_levels < 1 || lv[q]->n_levels > NVP_MAX_LEVELS || (lv[q]->n_levels * F) % 8) return false;     // an even number of row-groups per plane
+        d += lv[q]->n_levels * F;
+    }
+    d += 9 * F;
+    if (nvp_fwd_layout_b3(d).zs > kB3ZLdsSteps) return false;
+    if (d_out) *d_out = d;
+    return true;
+}
+
+
+}  // namespace

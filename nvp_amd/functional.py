@@ -82,16 +82,22 @@ class StepHooks:
                     grid's AdamW step is applied INSIDE the scatter's flush (nvp_encode_bwd_sparse_adamw) - its gradient is never
                     written to HBM, backward returns None for it.  Falls back to the gradient + early_grads route when the
                     optimizer declines (peek returns None) or the kernel does not support the layout;
+      loss_gt       uint8 ground truth [.., N, 3] of THIS batch, set BEFORE the forward call by a caller that promises the loss is
+                    image_mse(model_out, (gt - 127.5) / 127.5) seeded with gradient 1 (harness.train_step does): forward then runs the
+                    tile-fused step kernel (nvp_encode_mlp_fwd_bwd: forward, the loss gradient and the backward chain per 32-pixel tile
+                    in one launch; bit-identical streams and gradients) and backward starts at the scatter.  Ignored where the kernel
+                    does not apply (nvp_l, unsorted batches, data parallel sinks are fine);
       fused_dense   the same for the three dense planes (nvp_encode_bwd_dense_adamw: the update runs in band_kernel's /
                     slab_reduce_kernel's flushes).  With both set, no optimizer launch is left for the four grids."""
-    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse", "fused_dense")
+    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse", "fused_dense", "loss_gt")
 
-    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None, fused_sparse=None, fused_dense=None):
+    def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None, fused_sparse=None, fused_dense=None, loss_gt=None):
         self.grad_sink, self.sparse_ready, self.grids_ready, self.early_grads = grad_sink, sparse_ready, grids_ready, early_grads
         self.fused_sparse, self.fused_dense = fused_sparse, fused_dense
+        self.loss_gt = loss_gt
 
     def clear(self) -> None:
-        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = self.fused_sparse = self.fused_dense = None
+        self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = self.fused_sparse = self.fused_dense = self.loss_gt = None
 
 
 _NO_HOOKS = StepHooks()
@@ -112,6 +118,10 @@ CHECK_SORTED = os.environ.get("NVP_CHECK_SORTED", "0") == "1"
 # NVP.forward in ONE launch: the grid lookups run inside the forward MLP's waves (nvp_encode_mlp_fwd; config_nvp_s-sized latents).
 # NVP_FUSED_FWD=0 keeps the two-kernel path (gather kernel -> latent in HBM -> MLP kernel); RGB and gradients are bit-identical.
 FUSED_FWD = os.environ.get("NVP_FUSED_FWD", "1") != "0"
+# harness.train_step: forward, loss gradient and backward chain of a tile in ONE launch (nvp_encode_mlp_fwd_bwd; StepHooks.loss_gt).  EXPERIMENT:
+# bit-identical, measured 0.3 ms SLOWER than the two kernels; the entry point exists in libnvp_hip_experiments.so only
+# (NVP_HIP_LIB=.../libnvp_hip_experiments.so NVP_TILE_FUSED=1)
+TILE_FUSED = os.environ.get("NVP_TILE_FUSED", "0") == "1"
 
 # For y-sorted batches the backward chain hands the xy / yt planes' latent gradients to the scatter in its own level-major
 # layout (nvp_encode_bwd_prepare / NVP_DZ_PLANES_READY): 2/3 of the scatter's permute pass disappear.  NVP_DZ_LEVEL_MAJOR=0 keeps
@@ -250,7 +260,7 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
 
 
 def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, saved: torch.Tensor,
-                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None, packed=None, sink=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+                  mlp: Sequence[torch.Tensor], n: int, d: int, between=None, lm=None, packed=None, sink=None, chain=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
     """dX chain (+ latent gradient), then the dW GEMMs.  `between(dz_rows)`, if given, runs after the
     dX kernels are enqueued and before the dW kernels: the fused NVP path uses it to enqueue the grid
     scatter (which only needs dz) first, so its gradients can be all-reduced underneath the dW GEMMs."""
@@ -259,18 +269,21 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     stream = L.stream_ptr()
     nt = L.ntiles(n)
     pstruct = L.mlp_params_struct(mlp)
-    if packed is not None:          # (tensor, event): packed during forward on the side stream
-        packed, ev = packed
-        torch.cuda.current_stream(dev).wait_event(ev)
-    else:
-        packed = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32)
-        L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
-    dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
-    dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
     drgb = _f32c(drgb)
-    # lm (optional, fused NVP path with y-sorted batches): the scatter's level-major buffers for the xy / yt planes
-    L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
-                               L.ptr(dy), L.ptr(dz_rows), C.byref(lm) if lm is not None else None, n, d, stream), "nvp_mlp_bwd_dx")
+    if chain is not None:           # (dy, dz_rows) of the tile-fused step kernel (forward): the chain has run
+        dy, dz_rows = chain
+    else:
+        if packed is not None:          # (tensor, event): packed during forward on the side stream
+            packed, ev = packed
+            torch.cuda.current_stream(dev).wait_event(ev)
+        else:
+            packed = torch.empty(lib.nvp_packed_bwd_floats(d), device=dev, dtype=torch.float32)
+            L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_bwd")
+        dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
+        dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
+        # lm (optional, fused NVP path with y-sorted batches): the scatter's level-major buffers for the xy / yt planes
+        L.check(_call("nvp_mlp_bwd_dx", lib.nvp_mlp_bwd_dx, L.ptr(drgb), L.ptr(steps), L.ptr(saved), C.byref(pstruct), L.ptr(packed),
+                                   L.ptr(dy), L.ptr(dz_rows), C.byref(lm) if lm is not None else None, n, d, stream), "nvp_mlp_bwd_dx")
     grads = [_grad_buffer(t, sink) for t in mlp]
     gstruct = L.mlp_params_struct(grads)
     nch = dw_chunks(n)
@@ -406,9 +419,17 @@ class NVPFused(torch.autograd.Function):
         # back) is started NOW on a side stream, underneath the gather kernel, and the scatter later only waits for its event.
         # The side stream also packs the MLP weights (forward layout now, backward layout for later): ~0.1 ms of small kernels that
         # depend on the parameters only.
-        ctx.ws = ctx.presorted = ctx.packed_bwd = None
+        ctx.ws = ctx.presorted = ctx.packed_bwd = ctx.chain = None
         packed_fwd = None
         bwd_follows = need_grad and n and not temporal_interp
+        # the tile-fused training step (forward + loss gradient + backward chain in one launch): the caller handed the ground truth over
+        tile_fused = bool(TILE_FUSED and hooks is not None and hooks.loss_gt is not None and fused and bwd_follows and y_sorted and order is None
+                          and SIDE_WORK and DZ_LEVEL_MAJOR and lib.nvp_dz_lm_supported(d) and L.has_entry("nvp_encode_mlp_fwd_bwd")
+                          and lib.nvp_encode_mlp_fwd_bwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh)))
+        if tile_fused:
+            gt_u8 = hooks.loss_gt.reshape(-1, 3)
+            if gt_u8.dtype != torch.uint8 or gt_u8.shape[0] != n or not gt_u8.is_contiguous() or gt_u8.device != dev:
+                tile_fused = False
         # the side stream is only worth its hand-over (two event markers on the compute queue + one deferred-free event per buffer)
         # when something runs on it: the scatter's presort / backward pack (a backward pass follows) or the forward pack underneath
         # the gather kernel of the two-kernel path.  Fused inference (eval: 100 slices per frame) packs in line, below.
@@ -458,15 +479,41 @@ class NVPFused(torch.autograd.Function):
             if SIDE_WORK:                      # (bwd_follows: the hand-over above has run, `side` / `pstruct` / `pk_b` exist)
                 ctx.ws.record_stream(side)
                 with torch.cuda.stream(side):
+                    if tile_fused:             # the fused step kernel needs the backward pack up front: it goes first on the side stream
+                        L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(pk_b), d, L.stream_ptr()), "nvp_mlp_pack_bwd")
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        ctx.packed_bwd = (pk_b, ev)
                     L.check(lib.nvp_encode_bwd_presort(L.ptr(coords), n, C.byref(lvs[0]), C.byref(lvs[1]), C.byref(lvs[2]), C.byref(sh),
                                                        L.ptr(ctx.ws, torch.uint8), ws_bytes, bflags, L.stream_ptr()), "nvp_encode_bwd_presort")
                     ctx.presorted = torch.cuda.Event()
                     ctx.presorted.record()
-                    L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(pk_b), d, L.stream_ptr()), "nvp_mlp_pack_bwd")
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    ctx.packed_bwd = (pk_b, ev)
-        if fused:
+                    if not tile_fused:
+                        L.check(lib.nvp_mlp_pack_bwd(C.byref(pstruct), L.ptr(pk_b), d, L.stream_ptr()), "nvp_mlp_pack_bwd")
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        ctx.packed_bwd = (pk_b, ev)
+        if tile_fused:
+            # forward + image_mse gradient + backward chain, tile by tile, in one launch
+            pstruct = L.mlp_params_struct(mlp)
+            packed, _ = packed_fwd
+            pk_b, ev_b = ctx.packed_bwd
+            torch.cuda.current_stream(dev).wait_event(ev_b)
+            ws_bytes = ctx.ws.numel()
+            lm = L.ScatterLm()
+            L.check(lib.nvp_encode_bwd_prepare(n, C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
+                                               L.ptr(ctx.ws, torch.uint8), ws_bytes, C.byref(lm), L.stream_ptr()), "nvp_encode_bwd_prepare")
+            nt = L.ntiles(n)
+            rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
+            saved = torch.empty((5, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
+            dy = torch.empty((6, nt, L.HIDDEN, L.TILE), device=dev, dtype=torch.float32)
+            dz_rows = torch.empty((nt * L.TILE, lib.nvp_dz_stride(d)), device=dev, dtype=torch.float32)
+            L.check(_call("nvp_encode_mlp_fwd_bwd", lib.nvp_encode_mlp_fwd_bwd, L.ptr(coords), L.ptr(steps), L.ptr(gt_u8, torch.uint8), L.ptr(kf_xy), L.ptr(kf_yt),
+                          L.ptr(kf_xt), L.ptr(emb), C.byref(pstruct), L.ptr(packed), L.ptr(pk_b), L.ptr(rgb), L.ptr(saved), L.ptr(zt), L.ptr(dy), L.ptr(dz_rows),
+                          C.byref(lm), n, C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh), L.stream_ptr()), "nvp_encode_mlp_fwd_bwd")
+            ctx.chain = (dy, dz_rows, lm, gt_u8)
+            ctx.packed_bwd = None
+        elif fused:
             # one launch: every wave of the forward MLP gathers its own latent tile into LDS; the latent tensor is written only
             # when a backward pass will read it (dW GEMMs)
             pstruct = L.mlp_params_struct(mlp)
@@ -543,7 +590,10 @@ class NVPFused(torch.autograd.Function):
                 raise L.NvpHipError("nvp_encode_bwd_workspace_bytes failed")
             ws = torch.empty(ws_bytes, device=coords.device, dtype=torch.uint8)
         ws_bytes = ws.numel()
-        if flags & L.DZ_PLANES_READY:
+        chain, ctx.chain = ctx.chain, None          # the tile-fused step kernel already ran the backward chain in forward
+        if chain is not None:
+            lm = chain[2]
+        elif flags & L.DZ_PLANES_READY:
             lm = L.ScatterLm()
             L.check(lib.nvp_encode_bwd_prepare(n, C.byref(lv[0]), C.byref(lv[1]), C.byref(lv[2]), C.byref(ctx.sh),
                                                L.ptr(ws, torch.uint8), ws_bytes, C.byref(lm), L.stream_ptr()), "nvp_encode_bwd_prepare")
@@ -616,5 +666,6 @@ class NVPFused(torch.autograd.Function):
                 hk.grids_ready()            # e.g. start the (async) all-reduce of the grid gradients
 
         # order: dX chain -> grid scatter (needs only dz) -> dW GEMMs (independent of the scatter)
-        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm, packed=packed_bwd, sink=sink)
+        _, grads = _mlp_backward(drgb, steps, zt, saved, mlp, n, d, between=scatter, lm=lm, packed=packed_bwd, sink=sink,
+                                 chain=None if chain is None else chain[:2])
         return (None, None, d_xy, d_yt, d_xt, d_emb, None, None, None, None, None, None, None, *grads)

@@ -210,6 +210,8 @@ def train_step(model, opt, sched, model_input, gt, bucket=None) -> torch.Tensor:
     if sharded:
         bucket = opt.bucket
     hooks = functional.StepHooks()                  # this step's own hooks: read by this call's backward only (re-entrant)
+    if functional.TILE_FUSED and gt["img"].dtype == torch.uint8:
+        hooks.loss_gt = gt["img"]                   # the loss below IS image_mse on this ground truth, seeded with 1: forward may run the chain too
     out = model(dict(model_input, nvp_hooks=hooks))["model_out"]
     loss = image_mse_u8(out, gt["img"])
     if bucket is not None:
