@@ -28,6 +28,7 @@
 // Quantisation: contributions are scaled by 2^k with k chosen from max|dz| so that the sum of
 // N contributions cannot overflow 2^62; each contribution keeps >= 40 significant bits below
 // max|dz| (fp32 carries 24), so the scatter is more accurate than an fp32 atomic chain.
+#include <cstdlib>
 #include <cstring>
 #include "adamw.h"
 #include "grid_math.h"
@@ -69,8 +70,30 @@ struct Plan {
     int entries;             // int64 entries of the LDS table (>= the widest grid row)
 };
 
+// Target table size per feature width.  A band's visits scale with (rows + 2) / rows; with F = 4 the four finest levels (587 .. 1443 cells
+// x 4 floats per row) get ONE row per band from the F = 2 target - three visits per pixel and level.  NVP_BAND_ENTRIES_F4 (build) /
+// the experiments build's environment variable of the same name tune it.
+#ifndef NVP_BAND_ENTRIES_F4
+#define NVP_BAND_ENTRIES_F4 NVP_BAND_ENTRIES
+#endif
+#ifndef NVP_SPARSE_ENTRIES_F4
+#define NVP_SPARSE_ENTRIES_F4 NVP_SPARSE_ENTRIES
+#endif
+inline int env_int_or(const char* name, int dflt) {
+#if NVP_EXPERIMENTS
+    const char* e = getenv(name);
+    if (e && atoi(e) > 0) return atoi(e);
+#endif
+    (void)name;
+    return dflt;
+}
+inline int band_entries_target(int F) {
+    static const int f4 = env_int_or("NVP_BAND_ENTRIES_F4", NVP_BAND_ENTRIES_F4);
+    return F >= 4 ? f4 : kLdsEntries;
+}
+
 void make_plan(Plan& P, const nvp_levels* lv[3], int64_t n) {
-    P.entries = kLdsEntries;
+    P.entries = band_entries_target(lv[0]->n_features);
     for (int p = 0; p < 3; ++p)
         for (int l = 0; l < lv[p]->n_levels; ++l)
             if (lv[p]->res[l] * lv[p]->n_features > P.entries) P.entries = lv[p]->res[l] * lv[p]->n_features;
@@ -856,7 +879,9 @@ int sparse_geom(const nvp_sparse_shape* sh, const SparseAdam* adam, SparseGeom& 
     const int row_floats = sh->y_res * sh->n_features;
     if (row_floats < 1 || sh->x_res < 1 || sh->t_res < 1) return NVP_ERR_BADARG;
     if (sh->n_features != 1 && sh->n_features != 2 && sh->n_features != 4 && sh->n_features != 8) return NVP_ERR_UNSUPPORTED;
-    G.sentries = kSparseEntries > row_floats ? kSparseEntries : row_floats;
+    static const int s4 = env_int_or("NVP_SPARSE_ENTRIES_F4", NVP_SPARSE_ENTRIES_F4);
+    const int starget = sh->n_features >= 4 ? s4 : kSparseEntries;
+    G.sentries = starget > row_floats ? starget : row_floats;
     if (G.sentries > kMaxLdsEntries) return NVP_ERR_UNSUPPORTED;              // one x-row does not fit the LDS
     G.rows = G.sentries / row_floats;
     if (G.rows > sh->x_res) G.rows = sh->x_res;
