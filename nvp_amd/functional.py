@@ -89,12 +89,14 @@ class StepHooks:
                     does not apply (nvp_l, unsorted batches, data parallel sinks are fine);
       fused_dense   the same for the three dense planes (nvp_encode_bwd_dense_adamw: the update runs in band_kernel's /
                     slab_reduce_kernel's flushes).  With both set, no optimizer launch is left for the four grids."""
-    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse", "fused_dense", "loss_gt")
+    __slots__ = ("grad_sink", "sparse_ready", "grids_ready", "early_grads", "fused_sparse", "fused_dense", "loss_gt", "packed_cache")
 
     def __init__(self, grad_sink=None, sparse_ready=None, grids_ready=None, early_grads=None, fused_sparse=None, fused_dense=None, loss_gt=None):
         self.grad_sink, self.sparse_ready, self.grids_ready, self.early_grads = grad_sink, sparse_ready, grids_ready, early_grads
         self.fused_sparse, self.fused_dense = fused_sparse, fused_dense
         self.loss_gt = loss_gt
+        self.packed_cache = None      # inference only: a dict the caller keeps for as long as the parameters do not change (one frame / one
+                                      # evaluation under no_grad): the packed forward weights are built once and reused by every slice
 
     def clear(self) -> None:
         self.grad_sink = self.sparse_ready = self.grids_ready = self.early_grads = self.fused_sparse = self.fused_dense = self.loss_gt = None
@@ -248,7 +250,8 @@ def _mlp_forward(zt: torch.Tensor, steps: torch.Tensor, mlp: Sequence[torch.Tens
     pstruct = L.mlp_params_struct(mlp)
     if packed is not None:
         packed, ev = packed
-        torch.cuda.current_stream(dev).wait_event(ev)
+        if ev is not None:
+            torch.cuda.current_stream(dev).wait_event(ev)
     else:
         packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
         L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, stream), "nvp_mlp_pack_fwd")
@@ -304,6 +307,17 @@ def _mlp_backward(drgb: torch.Tensor, steps: torch.Tensor, zt: torch.Tensor, sav
     L.check(_call("nvp_mlp_bwd_dw", lib.nvp_mlp_bwd_dw, L.ptr(drgb), L.ptr(steps), L.ptr(zt), L.ptr(saved), L.ptr(dy), C.byref(pstruct),
                                L.ptr(partials), nch, C.byref(gstruct), n, d, stream), "nvp_mlp_bwd_dw")
     return dz_rows, grads
+
+
+def _packed_fwd_cached(lib, cache, pstruct, d: int, dev) -> torch.Tensor:
+    """The forward weight pack on the current stream; `cache` (StepHooks.packed_cache, inference only) keeps it for the caller's evaluation."""
+    packed = cache.get(("fwd", d, dev)) if cache is not None else None
+    if packed is None:
+        packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
+        L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
+        if cache is not None:
+            cache[("fwd", d, dev)] = packed
+    return packed
 
 
 def _check_mlp(mlp: Sequence[torch.Tensor], d: int) -> None:
@@ -433,7 +447,8 @@ class NVPFused(torch.autograd.Function):
         # the side stream is only worth its hand-over (two event markers on the compute queue + one deferred-free event per buffer)
         # when something runs on it: the scatter's presort / backward pack (a backward pass follows) or the forward pack underneath
         # the gather kernel of the two-kernel path.  Fused inference (eval: 100 slices per frame) packs in line, below.
-        if n and SIDE_WORK and (bwd_follows or not fused):
+        inf_cache = hooks.packed_cache if (hooks is not None and not need_grad) else None      # inference: one weight pack per evaluation
+        if n and SIDE_WORK and (bwd_follows or (not fused and inf_cache is None)):
             L.ptr(coords)                      # CPU tensors are refused here, before any stream is touched (no CPU path)
             side = _side_stream(dev)
             pstruct = L.mlp_params_struct(mlp)
@@ -522,8 +537,7 @@ class NVPFused(torch.autograd.Function):
                 if ev is not None:
                     torch.cuda.current_stream(dev).wait_event(ev)
             else:
-                packed = torch.empty(lib.nvp_packed_fwd_floats(d), device=dev, dtype=torch.float32)
-                L.check(lib.nvp_mlp_pack_fwd(C.byref(pstruct), L.ptr(packed), d, L.stream_ptr()), "nvp_mlp_pack_fwd")
+                packed = _packed_fwd_cached(lib, inf_cache, pstruct, d, dev)
             rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
             saved = torch.empty((5, L.ntiles(n), L.HIDDEN, L.TILE), device=dev, dtype=torch.float32) if need_grad else None
             L.check(_call("nvp_encode_mlp_fwd", lib.nvp_encode_mlp_fwd, L.ptr(coords), L.ptr(steps), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb),
@@ -534,6 +548,8 @@ class NVPFused(torch.autograd.Function):
                 L.check(_call("nvp_encode_fwd", lib.nvp_encode_fwd, L.ptr(coords), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb), L.ptr(zt), n,
                                            C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh),
                                            1 if temporal_interp else 0, L.COORDS_SORTED_BY_Y if y_sorted else 0, L.stream_ptr()), "nvp_encode_fwd")
+            if packed_fwd is None and inf_cache is not None and n:
+                packed_fwd = (_packed_fwd_cached(lib, inf_cache, L.mlp_params_struct(mlp), d, dev), None)
             rgb, saved = _mlp_forward(zt, steps, mlp, n, d, save=need_grad, packed=packed_fwd)
         if need_grad:
             if temporal_interp:

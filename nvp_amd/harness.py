@@ -274,9 +274,12 @@ def train_psnr(loss: torch.Tensor) -> float:
     return 10.0 * math.log10(4.0 / float(loss))
 
 
+_LATTICE = {}          # (device, H', W') -> [H'W', 3] float32 with columns 1, 2 = (row, col) lattice coordinates; column 0 is the frame's t
+
+
 @torch.no_grad()
 def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[int] = None, temporal_interp: bool = False,
-                 n_slice: int = 100) -> torch.Tensor:
+                 n_slice: int = 100, hooks=None) -> torch.Tensor:
     """One output frame of the reference's inference loop (eval.py:219-245): [H', W', 3] on the device, in [0, 1].
 
     resolution = (H', W') of the QUERY lattice (eval.py:201-204: the video's resolution times --s_interp);
@@ -290,21 +293,37 @@ def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[
     nframes = org_nframes if nframes is None else nframes
     Hq, Wq = int(resolution[0]), int(resolution[1])
     total = Hq * Wq
-    rows = torch.arange(Hq, device=dev, dtype=torch.float32) / max(Hq - 1, 1)
-    cols = torch.arange(Wq, device=dev, dtype=torch.float32) / max(Wq - 1, 1)      # dataio.get_mgrid: k / (side - 1)
+    # the (row, col) lattice of a resolution is the same for every frame and every slice: built once per (device, H', W') with the
+    # reference's arithmetic (dataio.get_mgrid: k / (side - 1)), then sliced - a slice costs the model call and one copy, not seven
+    # element-wise launches (the reference's 100-slice loop is launch-bound on a GPU this fast)
+    key = (dev, Hq, Wq)
+    lat = _LATTICE.get(key)
+    if lat is None:
+        rows = torch.arange(Hq, device=dev, dtype=torch.float32) / max(Hq - 1, 1)
+        cols = torch.arange(Wq, device=dev, dtype=torch.float32) / max(Wq - 1, 1)      # dataio.get_mgrid: k / (side - 1)
+        p = torch.arange(total, device=dev)
+        lat = torch.empty((total, 3), device=dev, dtype=torch.float32)
+        lat[:, 1] = rows[torch.div(p, Wq, rounding_mode="floor")]
+        lat[:, 2] = cols[p % Wq]
+        if len(_LATTICE) >= 4:
+            _LATTICE.clear()
+        _LATTICE[key] = lat
     half_dt = 0.5 / org_nframes
     tstep = torch.linspace(half_dt, 1 - half_dt, nframes)[f].item()
     tcoord = torch.linspace(0, 1, nframes)[f].item()
+    coords_all = lat.clone()
+    coords_all[:, 0] = tcoord
+    steps_all = torch.full((1, total), tstep, device=dev, dtype=torch.float32)
     out = torch.zeros((total, 3), device=dev, dtype=torch.float32)
     split = int(total / n_slice)
+    if hooks is None:                   # the parameters cannot change inside this call (no_grad): the slices share one weight pack
+        from . import functional
+        hooks = functional.StepHooks()
+        hooks.packed_cache = {}
     for i in range(n_slice if split > 0 else 0):
         lo, hi = i * split, (i + 1) * split
-        p = torch.arange(lo, hi, device=dev)
-        r = rows[torch.div(p, Wq, rounding_mode="floor")]
-        c = cols[p % Wq]
-        coords = torch.stack((torch.full_like(r, tcoord), r, c), dim=1).unsqueeze(0)
-        steps = torch.full((1, hi - lo), tstep, device=dev, dtype=torch.float32)
-        out[lo:hi] = model({"all_coords": coords, "temporal_steps": steps}, temporal_interp=temporal_interp)["model_out"].reshape(-1, 3)
+        out[lo:hi] = model({"all_coords": coords_all[lo:hi].unsqueeze(0), "temporal_steps": steps_all[:, lo:hi], "nvp_hooks": hooks},
+                           temporal_interp=temporal_interp)["model_out"].reshape(-1, 3)
     return torch.clamp((out.reshape(Hq, Wq, 3) + 1) / 2, 0, 1)
 
 
@@ -327,8 +346,11 @@ def eval_psnr(model, video: DeviceVideo, frames=None, n_slice: int = 100, s_inte
         nframes = video.T * t_interp
     plain = s_interp == -1 and t_interp == -1
     psnrs = []
+    from . import functional
+    hooks = functional.StepHooks()
+    hooks.packed_cache = {}                                 # one weight pack for the whole evaluation: nothing updates the model in here
     for f in (range(nframes) if frames is None else frames):
-        img = render_frame(model, f, video.T, res, nframes, temporal_interp, n_slice)
+        img = render_frame(model, f, video.T, res, nframes, temporal_interp, n_slice, hooks=hooks)
         if on_frame is not None:
             on_frame(f, img)
         if plain:
