@@ -379,3 +379,30 @@ def test_compat_optimizer_routing_is_opt_in_and_falls_back_to_the_stock_class():
     finally:
         compat.uninstall_optimizer()
     assert torch.optim.AdamW is stock
+
+
+def test_new_entry_points_refuse_bad_arguments_without_a_device():
+    """Round-4 entry points (nvp_order_by_rows, nvp_encode_bwd_dense_adamw): argument errors are decided on the host before anything is
+    enqueued, so they can be checked in this container: null pointers / missing flags -> NVP_ERR_BADARG, a key space beyond the counting
+    sort's LDS table -> NVP_ERR_UNSUPPORTED, and the workspace query is plain host arithmetic."""
+    lib = L.load()
+    lv = L.make_levels(small_cfg(F=2)["2d_encoding_xy"])
+    sh = L.SparseShape(8, 9, 7, 2)
+    n = 1000
+    wsb = lib.nvp_order_by_rows_workspace_bytes(n, ctypes.byref(lv), ctypes.byref(lv))
+    assert wsb > 0 and lib.nvp_order_by_rows_workspace_bytes(-1, ctypes.byref(lv), ctypes.byref(lv)) == L.ERR_BADARG
+    assert lib.nvp_order_by_rows(None, None, n, ctypes.byref(lv), ctypes.byref(lv), None, wsb, None) == L.ERR_BADARG
+    # two DIFFERENT level geometries for the xy / yt planes double the key space: 2 x 5 567 rows is still inside 12 288; a 3x finer one is not
+    big = L.make_levels(dict(small_cfg(F=2)["2d_encoding_xy"], base_resolution=64))
+    dummy = ctypes.c_void_p(64)             # never dereferenced: the support check comes first
+    assert lib.nvp_order_by_rows(dummy, dummy, n, ctypes.byref(big), ctypes.byref(lv), dummy, 1 << 40, None) == L.ERR_UNSUPPORTED
+    arr = (ctypes.c_void_p * 3)(64, 64, 64)
+    steps = (ctypes.c_int64 * 3)(1, 1, 1)
+    args = (dummy, dummy, 120, n, ctypes.byref(lv), ctypes.byref(lv), ctypes.byref(lv), ctypes.byref(sh), dummy, 1 << 30)
+    # needs NVP_COORDS_SORTED_BY_Y | NVP_DZ_PLANES_READY
+    assert lib.nvp_encode_bwd_dense_adamw(*args, 0, arr, arr, arr, 1e-2, 0.9, 0.999, 1e-8, 1e-3, steps, None) == L.ERR_BADARG
+    ok_flags = L.COORDS_SORTED_BY_Y | L.DZ_PLANES_READY
+    assert lib.nvp_encode_bwd_dense_adamw(*args, ok_flags, None, arr, arr, 1e-2, 0.9, 0.999, 1e-8, 1e-3, steps, None) == L.ERR_BADARG
+    zero = (ctypes.c_int64 * 3)(1, 0, 1)
+    assert lib.nvp_encode_bwd_dense_adamw(*args, ok_flags, arr, arr, arr, 1e-2, 0.9, 0.999, 1e-8, 1e-3, zero, None) == L.ERR_BADARG      # step counts are 1-based
+    assert lib.nvp_encode_bwd_dense_adamw(*args, ok_flags, arr, arr, arr, 1e-2, 1.0, 0.999, 1e-8, 1e-3, steps, None) == L.ERR_BADARG     # beta1 outside [0, 1)
