@@ -259,17 +259,20 @@ def eval_bench(args, dev):
     pk_mlp = PEAK_MFMA_16 / products if products > 1 else PEAK_MFMA_F32
     n_frames = max(args.steps, 1)
     runs = {}
-    for name, n_slice, t_interp in (("plain_1slice", 1, False), ("plain_100slices", 100, False), ("t_interp2_1slice", 1, True),
-                                    ("t_interp2_100slices", 100, True)):
+    # "*_100slices": the reference's slicing through harness.render_frame's default (the slices' pixels in one model call: bit-identical);
+    # "*_100slices_literal": the reference's loop slice by slice (100 model calls per frame: launch-bound)
+    for name, n_slice, t_interp, literal in (("plain_1slice", 1, False, False), ("plain_100slices", 100, False, False),
+                                             ("plain_100slices_literal", 100, False, True), ("t_interp2_1slice", 1, True, False),
+                                             ("t_interp2_100slices", 100, True, False), ("t_interp2_100slices_literal", 100, True, True)):
         nfr = T * 2 if t_interp else T
         frames = [int(round(i * (nfr - 2) / max(n_frames - 1, 1))) for i in range(n_frames)]       # (the last t_interp frame is the NaN frame)
         for f in frames[:max(args.warmup, 1)]:
-            harness.render_frame(model, f, T, (H, W), nfr, t_interp, n_slice)
+            harness.render_frame(model, f, T, (H, W), nfr, t_interp, n_slice, literal_slices=literal)
         functional.TIMER = functional.KernelTimer()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for f in frames:
-            harness.render_frame(model, f, T, (H, W), nfr, t_interp, n_slice)
+            harness.render_frame(model, f, T, (H, W), nfr, t_interp, n_slice, literal_slices=literal)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         k = functional.TIMER.summary()

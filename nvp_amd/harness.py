@@ -279,7 +279,7 @@ _LATTICE = {}          # (device, H', W') -> [H'W', 3] float32 with columns 1, 2
 
 @torch.no_grad()
 def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[int] = None, temporal_interp: bool = False,
-                 n_slice: int = 100, hooks=None) -> torch.Tensor:
+                 n_slice: int = 100, hooks=None, literal_slices: bool = False) -> torch.Tensor:
     """One output frame of the reference's inference loop (eval.py:219-245): [H', W', 3] on the device, in [0, 1].
 
     resolution = (H', W') of the QUERY lattice (eval.py:201-204: the video's resolution times --s_interp);
@@ -288,7 +288,12 @@ def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[
     Frame f: temporal coordinate linspace(0,1,nframes)[f], modulation input linspace(half_dt, 1-half_dt, nframes)[f];
     pixels are evaluated in n_slice slices of int(H'W'/n_slice) (eval.py:233-239: a remainder beyond the last slice stays
     0, i.e. 0.5 after the (img+1)/2 map - reference behaviour); temporal_interp routes the sparse grid through
-    forward_inter (modules.py:72-73), whose t == 1 rows are NaN (the last frame of a --t_interp run; clamp keeps NaN)."""
+    forward_inter (modules.py:72-73), whose t == 1 rows are NaN (the last frame of a --t_interp run; clamp keeps NaN).
+
+    The reference slices a frame to bound the memory of its materialised activations; this path materialises none under no_grad, and
+    every pixel is computed independently of its neighbours, so the n_slice * int(H'W'/n_slice) pixels the slices cover are evaluated in
+    ONE model call - bit-identical to the sliced loop (tests/test_gpu_parity.py::test_eval_drivers...), pixels beyond the last slice
+    still stay 0.  literal_slices=True runs the reference's loop slice by slice (bench.py --mode eval reports both)."""
     dev = next(model.parameters()).device
     nframes = org_nframes if nframes is None else nframes
     Hq, Wq = int(resolution[0]), int(resolution[1])
@@ -320,15 +325,18 @@ def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[
         from . import functional
         hooks = functional.StepHooks()
         hooks.packed_cache = {}
-    for i in range(n_slice if split > 0 else 0):
-        lo, hi = i * split, (i + 1) * split
+    spans = [(i * split, (i + 1) * split) for i in range(n_slice if split > 0 else 0)]
+    if not literal_slices and spans:
+        spans = [(0, split * n_slice)]          # the same pixels, one call
+    for lo, hi in spans:
         out[lo:hi] = model({"all_coords": coords_all[lo:hi].unsqueeze(0), "temporal_steps": steps_all[:, lo:hi], "nvp_hooks": hooks},
                            temporal_interp=temporal_interp)["model_out"].reshape(-1, 3)
     return torch.clamp((out.reshape(Hq, Wq, 3) + 1) / 2, 0, 1)
 
 
 @torch.no_grad()
-def eval_psnr(model, video: DeviceVideo, frames=None, n_slice: int = 100, s_interp: int = -1, t_interp: int = -1, on_frame=None):
+def eval_psnr(model, video: DeviceVideo, frames=None, n_slice: int = 100, s_interp: int = -1, t_interp: int = -1, on_frame=None,
+              literal_slices: bool = False):
     """The reference's evaluation driver (eval.py:201-263) on a device-resident video.
 
     Plain run (s_interp == t_interp == -1): per-frame PSNR on [0,1] - (img+1)/2, clamp, vs u8/255 - averaged over
@@ -350,7 +358,7 @@ def eval_psnr(model, video: DeviceVideo, frames=None, n_slice: int = 100, s_inte
     hooks = functional.StepHooks()
     hooks.packed_cache = {}                                 # one weight pack for the whole evaluation: nothing updates the model in here
     for f in (range(nframes) if frames is None else frames):
-        img = render_frame(model, f, video.T, res, nframes, temporal_interp, n_slice, hooks=hooks)
+        img = render_frame(model, f, video.T, res, nframes, temporal_interp, n_slice, hooks=hooks, literal_slices=literal_slices)
         if on_frame is not None:
             on_frame(f, img)
         if plain:

@@ -1266,6 +1266,12 @@ def test_eval_drivers_t_interp_and_s_interp_vs_oracle():
         want = _oracle_frame(sd, cfg, f, T, (2 * H, 2 * W), T, False, n_slice)
         assert frames[f].shape == (2 * H, 2 * W, 3)
         assert float((frames[f] - want).abs().max()) <= RGB_TOL / 2 + 1e-7
+    # render_frame evaluates the slices' pixels in one model call by default; the reference's literal loop - slice by slice - must give
+    # the same bits (every pixel is independent of its neighbours), the unrendered remainder included, plain and with forward_inter
+    for ti, nfr in ((False, T), (True, 2 * T)):
+        a = harness.render_frame(model, 2, T, (H, W), nfr, ti, n_slice)
+        b = harness.render_frame(model, 2, T, (H, W), nfr, ti, n_slice, literal_slices=True)
+        assert torch.equal(a.isnan(), b.isnan()) and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
 
 
 # ----------------------------------------------------------------------------------------
