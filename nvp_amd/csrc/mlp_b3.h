@@ -260,6 +260,21 @@ __device__ __forceinline__ void load_step(StepOps& o, const u32x4* __restrict__ 
 #pragma unroll
         for (int k = 0; k < kP; ++k) o.q[T][k] = (w + (T * kP + k) * 64)[ul];
 }
+// experiment: wave priority around the MFMA chains (two waves share a SIMD; whose instructions win when both are ready?)
+//   1: a wave inside a chain outranks its partner (keeps the matrix pipe fed), 2: the opposite (element-wise stages outrank chains)
+#ifndef NVP_MFMA_PRIO
+#define NVP_MFMA_PRIO 1          // measured (profiles/r04_ab_wave_priority.txt): backward chain 1.65 -> 1.60 ms, forward unchanged; bit-identical
+#endif
+#if NVP_MFMA_PRIO == 1
+#define NVP_CHAIN_ENTER() __builtin_amdgcn_s_setprio(2)
+#define NVP_CHAIN_LEAVE() __builtin_amdgcn_s_setprio(0)
+#elif NVP_MFMA_PRIO == 2
+#define NVP_CHAIN_ENTER() __builtin_amdgcn_s_setprio(0)
+#define NVP_CHAIN_LEAVE() __builtin_amdgcn_s_setprio(2)
+#else
+#define NVP_CHAIN_ENTER()
+#define NVP_CHAIN_LEAVE()
+#endif
 #ifndef NVP_PF_DEPTH
 #define NVP_PF_DEPTH 2           // NVP_CHAIN_PF_STEP == 3: k-steps of weights in flight
 #endif
@@ -340,6 +355,7 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
         return;
     }
 #endif
+    NVP_CHAIN_ENTER();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
@@ -349,6 +365,7 @@ __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)
         step_b3<PF>(acc, w + NVP_WSTRIDE(c * kB3StepQuads), b, lane);
         post(c);
     }
+    NVP_CHAIN_LEAVE();
 }
 template <bool PF = true>
 __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane) {

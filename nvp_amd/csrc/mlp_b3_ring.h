@@ -304,6 +304,7 @@ __device__ __forceinline__ void step_b3_hring(f32x16 (&acc)[4], HRing& R, int& h
 // 0 = a previous chain already opened the ring for this one: one exposed L2 round trip less)
 __device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane, int open_nh = 16) {
     if (open_nh) R.open(hs, open_nh);
+    NVP_CHAIN_ENTER();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
@@ -312,12 +313,14 @@ __device__ __forceinline__ void chain_h_b3_hring(f32x16 (&acc)[4], const f32x16 
         split8(x, sc, b);
         step_b3_hring(acc, R, hs, b, lane);
     }
+    NVP_CHAIN_LEAVE();
 }
 
 // two transposed GEMMs over the SAME input registers, one operand split per k-step; the packed stream interleaves the two
 // weight streams k-step by k-step (a's step c, then b's step c)
 __device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&acc_b)[4], const f32x16 (&hin)[4], const float sc, HRing& R, int& hs, int lane, int open_nh = 32) {
     if (open_nh) R.open(hs, open_nh);
+    NVP_CHAIN_ENTER();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float x[8];
@@ -327,4 +330,5 @@ __device__ __forceinline__ void chain_h2_b3_hring(f32x16 (&acc_a)[4], f32x16 (&a
         step_b3_hring(acc_a, R, hs, b, lane);
         step_b3_hring(acc_b, R, hs, b, lane);
     }
+    NVP_CHAIN_LEAVE();
 }

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3r_kernel(const fl
 #pragma unroll
             for (int T = 0; T < ZT; ++T) dz[T] *= f;
         }
+        NVP_CHAIN_ENTER();
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const u32x4* w = R.begin(s);
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_bwd_dz_b3r_kernel(const fl
             R.end();
             ++s;
         }
+        NVP_CHAIN_LEAVE();
 #ifndef NVP_ABL_DZ_NOLOAD        // ablation builds only (wrong results): what the exposed dp loads of layers 1 and 0 cost
         if (k > 0) {
 #pragma unroll

@@ -32,6 +32,21 @@
 #define NVP_DW_B3 1           // dW GEMMs on bf16 x 3 split MFMA (fragments split after the LDS read): 2.72 -> 2.21 ms
 #endif
 
+// experiment: wave priority of the compute phase (LDS fragment reads, operand splits, MFMAs) against the staging phase of the other
+// workgroups' waves on the SIMD (1: compute outranks staging, 2: staging outranks compute)
+#ifndef NVP_DW_PRIO
+#define NVP_DW_PRIO 2            // measured (profiles/r04_ab_wave_priority.txt): 1.66 -> 1.57 ms (1: 1.59); bit-identical
+#endif
+#if NVP_DW_PRIO == 1
+#define NVP_DW_COMPUTE_ENTER() __builtin_amdgcn_s_setprio(2)
+#define NVP_DW_COMPUTE_LEAVE() __builtin_amdgcn_s_setprio(0)
+#elif NVP_DW_PRIO == 2
+#define NVP_DW_COMPUTE_ENTER() __builtin_amdgcn_s_setprio(0)
+#define NVP_DW_COMPUTE_LEAVE() __builtin_amdgcn_s_setprio(2)
+#else
+#define NVP_DW_COMPUTE_ENTER()
+#define NVP_DW_COMPUTE_LEAVE()
+#endif
 #ifndef NVP_DW_PAIR_DEFAULT
 #define NVP_DW_PAIR_DEFAULT 0
 #endif
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
         const float* la = lds + (BUFS == 2 ? cur : 0) * kBufFloats;
         const float* lb = la + (1 + wb) * kTileFloats;
 #if NVP_DW_B3
+        NVP_DW_COMPUTE_ENTER();
         {
             // split-operand MFMA (mlp_b3.h): a lane's 16 pixels of a row are two k-steps of 8 (the SAME pixels on both
             // operands); fragments are split after the LDS read, the part products per (row tile, column tile, k-step)
@@ -357,6 +373,7 @@ __global__ __launch_bounds__(256 * NB, (KIND == 0 && NVP_DW_BUFS == 1 && NB == 1
                 }
             }
         }
+        NVP_DW_COMPUTE_LEAVE();
 #else
         {
             float fa[16], fb[2][16];

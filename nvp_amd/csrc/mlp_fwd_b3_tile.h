@@ -97,14 +97,18 @@ __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __res
         }
         return;
 #else
+        NVP_CHAIN_ENTER();
 #pragma unroll
         for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
+        NVP_CHAIN_LEAVE();
         return;
 #endif
     }
 #endif
+    NVP_CHAIN_ENTER();
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
+    NVP_CHAIN_LEAVE();
 }
 
 // Stage this wave's latent tile into its LDS region (as stage_z, mlp_chain.h) and return the largest |z| this lane saw: every
@@ -137,6 +141,7 @@ __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __re
                                             const u32x4* __restrict__ w, int lane) {
     const int j = lane & 31, h = lane >> 5;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    NVP_CHAIN_ENTER();
 #pragma unroll 1
     for (int s = s0; s < s1; ++s) {
         const int rg = 4 * s + 2 * h;
@@ -147,6 +152,7 @@ __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __re
         split8(x, sc, b);
         step_b3(acc, w + s * kB3StepQuads, b, lane);
     }
+    NVP_CHAIN_LEAVE();
 }
 
 // GF = 0: the latent tile is staged from the tensor `zt` a gather kernel wrote.  GF = 2 / 4 (= features per level): the wave
@@ -167,8 +173,13 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
     const int z4 = (nvp_rows4(d) / 4) * 32;
     const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
     float mz;                                                 // per-pixel max |z|: the latent's share of the operand scale
+#ifndef NVP_GATHER_PRIO
+#define NVP_GATHER_PRIO 0       // experiment: the tile gather (address arithmetic + fetch issue) outranks the partner wave's MLP
+#endif
+    if (NVP_GATHER_PRIO && GF != 0) __builtin_amdgcn_s_setprio(3);
     if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
     else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active && !NVP_FWD_LATE_STORES) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
+    if (NVP_GATHER_PRIO && GF != 0) __builtin_amdgcn_s_setprio(0);
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
