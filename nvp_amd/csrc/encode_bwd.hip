@@ -546,6 +546,10 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
 #pragma unroll
         for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)p * F + f];
     }
+#ifndef NVP_BAND_PRIO
+#define NVP_BAND_PRIO 0          // experiment: wave priority of the visit loop (1) or of the flush (2) against the other workgroups of the CU
+#endif
+    if (NVP_BAND_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     for (int kk = kb + threadIdx.x; kk < ke; kk += kBandThreads) {
         const bool extra = kk < lenX;
         const int p = visit_index(kk);
@@ -593,6 +597,8 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
             }
         }
     }
+    if (NVP_BAND_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (NVP_BAND_PRIO == 2) __builtin_amdgcn_s_setprio(2);
     __syncthreads();
 
     // ---- flush: exclusive bands go straight to the gradient; split bands keep their exact int64 sums in a slab (the order of
@@ -781,6 +787,11 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
                 }
             }
         }
+#ifndef NVP_SBAND_PRIO
+#define NVP_SBAND_PRIO 0         // experiment: wave priority of the accumulate phase (1) or of the flush (2) of the sparse band kernel
+#endif
+        if (NVP_SBAND_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+        if (NVP_SBAND_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         unit_apply(un[0]);
         unit_apply(un[1]);
         for (int u = threadIdx.x + 2 * kSparseThreads; u < units; u += kSparseThreads) {      // rare: more than 512 units
@@ -789,6 +800,8 @@ __global__ __launch_bounds__(kSparseThreads) void sparse_band_kernel(const float
             unit_load(x, lo + q, u - q * 3, r0, r1);
             unit_apply(x);
         }
+        if (NVP_SBAND_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (NVP_SBAND_PRIO == 2) __builtin_amdgcn_s_setprio(2);
         __syncthreads();
         if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);          // in flight during the flush
         if (ADAM) {
