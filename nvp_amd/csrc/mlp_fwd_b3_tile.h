@@ -44,9 +44,11 @@ __device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* 
     step_b3(acc, w + NVP_WSTRIDE(s * kB3StepQuads), b, lane);
 }
 
-// sc: the pixel's operand scale (mlp_b3.h; 1 for bf16 x 3)
-__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
-                                           float4* __restrict__ zg = nullptr, int rg_end = 0) {
+// sc: the pixel's operand scale (mlp_b3.h; 1 for bf16 x 3).  post(s) (optional) runs after k-step s of the straight-line 8-step path only -
+// independent VALU work the caller wants issued in the shadow of that step's MFMAs; returns true when post ran for every step.
+template <typename Post>
+__device__ __forceinline__ bool chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
+                                           float4* __restrict__ zg, int rg_end, Post post) {
     const int j = lane & 31, h = lane >> 5;
 #if NVP_B3_ZUNROLL
     if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
@@ -67,7 +69,7 @@ __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __res
 #pragma unroll
             for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[s % (DPT + 1)].q[T], b);
         }
-        return;
+        return false;
 #elif NVP_CHAIN_PF_STEP == 2
         // tile pairs, one pair of operand quads in flight ahead of the pair being multiplied (see chain_h_b3)
         const unsigned ul = (unsigned)lane;
@@ -95,13 +97,13 @@ __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __res
             mac_parts(acc[2 * (p & 1)], a[p & 1][0], b);
             mac_parts(acc[2 * (p & 1) + 1], a[p & 1][1], b);
         }
-        return;
+        return false;
 #else
         NVP_CHAIN_ENTER();
 #pragma unroll
-        for (int s = 0; s < 8; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
+        for (int s = 0; s < 8; ++s) { chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end); post(s); }
         NVP_CHAIN_LEAVE();
-        return;
+        return true;
 #endif
     }
 #endif
@@ -109,6 +111,11 @@ __device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __res
 #pragma unroll 1
     for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
     NVP_CHAIN_LEAVE();
+    return false;
+}
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
+                                           float4* __restrict__ zg = nullptr, int rg_end = 0) {
+    chain_z_b3(acc, zl, ns, sc, w, lane, zg, rg_end, [](int) {});
 }
 
 // Stage this wave's latent tile into its LDS region (as stage_z, mlp_chain.h) and return the largest |z| this lane saw: every
@@ -197,6 +204,7 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
     float* sv = (SAVE && active) ? saved + tile * (int64_t)NVP_H * 32 : nullptr;
 
     f32x16 hm[4], x[4], acc[4];
+    bool sir0_early = false;        // x already holds sin(30 (w s + c)) when the first chain could carry it (wave-uniform)
 
     // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
     {
@@ -207,8 +215,22 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
         const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
         bias_b3(hm, w, ps.s, lane);
         // fused gather + NVP_FWD_LATE_STORES: the latent tile leaves for the tensor from inside this chain (the whole latent is in LDS: fused_ok)
-        chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,
-                   (GF != 0 && NVP_FWD_LATE_STORES && SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, rg_end);
+#ifndef NVP_FWD_SIR0_EARLY
+#define NVP_FWD_SIR0_EARLY 1     // SIREN layer 0's sines - sin(30 (w s + c)), independent of everything the MLP has computed so far - are issued eight per
+#endif                           // k-step in the shadow of this chain's MFMAs instead of as a serial 900-instruction VALU stage behind it (same bits)
+        sir0_early = chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,
+                   (GF != 0 && NVP_FWD_LATE_STORES && SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, rg_end,
+                   [&](int ks) {
+                       if (!NVP_FWD_SIR0_EARLY) return;
+                       const int T = ks >> 1, r0 = 8 * (ks & 1);
+                       const float4* pw = reinterpret_cast<const float4*>(tab + ((0 * 2 + h) * 4 + T) * 16 + r0);
+                       const float4* pc = reinterpret_cast<const float4*>(tab + ((1 * 2 + h) * 4 + T) * 16 + r0);
+                       const float4 wa = pw[0], wb = pw[1], ca = pc[0], cb = pc[1];
+                       const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+                       const float cv[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+                       for (int q = 0; q < 8; ++q) x[T][r0 + q] = nvp_sin(30.0f * __fmaf_rn(s, wv[q], cv[q]));
+                   }) && NVP_FWD_SIR0_EARLY;
         if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
         lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
@@ -219,18 +241,27 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
     }
     // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
     {
+        if (sir0_early) {
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            float w0v[16], c0v[16];
-            load_tab16(w0v, tab, 0, T, h);
-            load_tab16(c0v, tab, 1, T, h);
+            for (int T = 0; T < 4; ++T) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float q = 30.0f * __fmaf_rn(s, w0v[r], c0v[r]);
-                x[T][r] = nvp_sin(q) * hm[T][r];
+                for (int r = 0; r < 16; ++r) x[T][r] = x[T][r] * hm[T][r];
+                nvp_pin(x[T]);
             }
-            nvp_pin(x[T]);
-            NVP_LOAD_FENCE();
+        } else {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                float w0v[16], c0v[16];
+                load_tab16(w0v, tab, 0, T, h);
+                load_tab16(c0v, tab, 1, T, h);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float q = 30.0f * __fmaf_rn(s, w0v[r], c0v[r]);
+                    x[T][r] = nvp_sin(q) * hm[T][r];
+                }
+                nvp_pin(x[T]);
+                NVP_LOAD_FENCE();
+            }
         }
     }
     // ---- layers 1 and 2
