@@ -144,20 +144,34 @@ __device__ __forceinline__ float stage_z_absmax(float4* __restrict__ zl, const f
 
 // k-steps [s0, s1) straight from the latent tensor (wide latents: rows the LDS tile does not hold); row-groups at or
 // beyond rg_end (the tensor's rows / 4) read as zero - the tile of the LAST pixels is followed by nothing
-__device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end, const float sc,
-                                            const u32x4* __restrict__ w, int lane) {
-    const int j = lane & 31, h = lane >> 5;
+#ifndef NVP_ZG_PREFETCH
+#define NVP_ZG_PREFETCH 0        // experiment (wide latents): the tensor rows of k-step s + 1 requested before k-step s is multiplied, the first step's before the LDS part: measured neutral (profiles/r04_ab_nvpl_zg_prefetch.txt)
+#endif
+struct ZgRows { float4 t0, t1; };
+__device__ __forceinline__ ZgRows zg_rows(const float4* __restrict__ zg, int s, int rg_end, int j, int h) {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int rg = 4 * s + 2 * h;
+    ZgRows r;
+    r.t0 = rg < rg_end ? zg[rg * 32 + j] : zero;
+    r.t1 = rg + 1 < rg_end ? zg[(rg + 1) * 32 + j] : zero;
+    return r;
+}
+// `first`: the rows of k-step s0, requested by the caller ahead of the LDS part (only read when NVP_ZG_PREFETCH and s0 < s1)
+__device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end, const float sc,
+                                            const u32x4* __restrict__ w, int lane, ZgRows first) {
+    const int j = lane & 31, h = lane >> 5;
     NVP_CHAIN_ENTER();
+    ZgRows cur = first;
 #pragma unroll 1
     for (int s = s0; s < s1; ++s) {
-        const int rg = 4 * s + 2 * h;
-        const float4 t0 = rg < rg_end ? zg[rg * 32 + j] : zero;
-        const float4 t1 = rg + 1 < rg_end ? zg[(rg + 1) * 32 + j] : zero;
-        const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        ZgRows nxt = cur;
+        if (NVP_ZG_PREFETCH) { if (s + 1 < s1) nxt = zg_rows(zg, s + 1, rg_end, j, h); }
+        else cur = zg_rows(zg, s, rg_end, j, h);
+        const float x[8] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w, cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w};
         BOp b;
         split8(x, sc, b);
         step_b3(acc, w + s * kB3StepQuads, b, lane);
+        cur = nxt;
     }
     NVP_CHAIN_LEAVE();
 }
@@ -213,6 +227,8 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
+        ZgRows zg_first = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (GF == 0 && NVP_ZG_PREFETCH && zs_l < L.zs) zg_first = zg_rows(zg, zs_l, rg_end, j, h);        // wide latents: first tensor-resident k-step, requested now
         bias_b3(hm, w, ps.s, lane);
         // fused gather + NVP_FWD_LATE_STORES: the latent tile leaves for the tensor from inside this chain (the whole latent is in LDS: fused_ok)
 #ifndef NVP_FWD_SIR0_EARLY
@@ -231,7 +247,7 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 #pragma unroll
                        for (int q = 0; q < 8; ++q) x[T][r0 + q] = nvp_sin(30.0f * __fmaf_rn(s, wv[q], cv[q]));
                    }) && NVP_FWD_SIR0_EARLY;
-        if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
+        if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane, zg_first);
         lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
@@ -273,6 +289,8 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             const PxScale ps = px_scale(fmaxf(fmaxf(px_absmax(hm), mz), 1.0f));
+            ZgRows zg_first = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            if (GF == 0 && NVP_ZG_PREFETCH && zs_l < L.zs) zg_first = zg_rows(zg, zs_l, rg_end, j, h);
             bias_b3(acc, w, ps.s, lane);
 #if NVP_FWD_LATE_STORES
             // h_{k-1} (k = 1: h0) is this chain's input and stays untouched until the epilogue below: its stream stores ride along,
@@ -283,7 +301,7 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
             chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
 #endif
             chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
-            if (GF == 0) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
+            if (GF == 0) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane, zg_first);
             lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
