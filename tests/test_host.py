@@ -406,3 +406,26 @@ def test_new_entry_points_refuse_bad_arguments_without_a_device():
     zero = (ctypes.c_int64 * 3)(1, 0, 1)
     assert lib.nvp_encode_bwd_dense_adamw(*args, ok_flags, arr, arr, arr, 1e-2, 0.9, 0.999, 1e-8, 1e-3, zero, None) == L.ERR_BADARG      # step counts are 1-based
     assert lib.nvp_encode_bwd_dense_adamw(*args, ok_flags, arr, arr, arr, 1e-2, 1.0, 0.999, 1e-8, 1e-3, steps, None) == L.ERR_BADARG     # beta1 outside [0, 1)
+
+
+def test_product_library_has_no_environment_switches_and_no_experiment_entry_points():
+    """the measured-slower kernel variants and the NVP_* switches that selected them live in
+    libnvp_hip_experiments.so only.  The product library imports no getenv, carries no NVP_* switch name, and exports none of the entry
+    points of include/nvp_hip_experiments.h; the experiments library (when built) exports everything the product does."""
+    import subprocess
+    prod = os.path.join(ROOT, "nvp_amd", "csrc", "libnvp_hip.so")
+    dyn = subprocess.run(["nm", "-D", prod], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in dyn
+    raw = open(prod, "rb").read()
+    assert not re.findall(rb"NVP_[A-Z][A-Z0-9_]{3,}\x00", raw), "an environment switch name is compiled into the product library"
+    exp_hdr = open(os.path.join(ROOT, "include", "nvp_hip_experiments.h")).read()
+    exp_names = set(re.findall(r"^(?:int|int32_t|int64_t)\s+(nvp_[a-z0-9_]+)\s*\(", exp_hdr, re.M))      # declarations only
+    assert exp_names == set(L.EXPERIMENT_SIGNATURES) and exp_names
+    exported = set(re.findall(r" T (nvp_[a-z0-9_]+)", dyn))
+    assert not (exp_names & exported)
+    assert exported == set(L.SIGNATURES)
+    exp = os.path.join(ROOT, "nvp_amd", "csrc", "libnvp_hip_experiments.so")
+    if os.path.exists(exp):
+        dyn_e = subprocess.run(["nm", "-D", exp], capture_output=True, text=True, check=True).stdout
+        exported_e = set(re.findall(r" T (nvp_[a-z0-9_]+)", dyn_e))
+        assert exported_e == exported | exp_names
