@@ -4,6 +4,9 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            (no launcher: bench.py starts the N ranks itself, same single line)
+
+A world size that differs from --gpus exits 2 WITHOUT a line (a mislabelled point of the scaling curve is worse than none).
 
 A "step" is one full optimisation iteration of the reference's loop (training.py:42-76) over
 one batch of N = 1 245 184 synthetic (t, x, y) samples of a 1920x1080x600 video
@@ -21,6 +24,9 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   "cpu_baseline": the oracle (pure-PyTorch CPU port of the reference path) timed on this
                   host's cores on a bounded sample of the same workload (N=1 run only);
   "kernels_ms":   mean ms of every hot-path kernel stage, "fwd_bwd_mpx_s": hot path only;
+  "isolated":     (N=1) the same steps with every side stream off: each stage's span alone;
+  "reference_surface": (N=1) the same model driven through the reference's own loop shape (training.py:42-76: raw-order
+                  batches, torch-expression MSE, torch.optim.AdamW - stock, and routed by compat.install(optimizer=True));
   "dp" (N>1):     the exchange scheme, the autotune timings and, per rank, the HIP-event time between
                   the end of backward and the end of the optimizer (exposed exchange + AdamW share).
 """
