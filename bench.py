@@ -243,6 +243,28 @@ def cpu_baseline_worker(n_sample: int, reps: int = 3):
                       f"N = {N_PX}: {med * N_PX / n_sample:.1f} s/step"}
 
 
+def other_configs(args) -> dict:
+    """`bench.py --config l` and `--config 4k` (headline pass only: no cpu_baseline, isolated or reference-surface pass) as child processes;
+    returns {config: {workload, ms_per_step, value, kernels_ms, roofline}} - or {"error": ...} per config that failed."""
+    import subprocess
+    out = {}
+    for c in ("l", "4k"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", c, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--prewarm", str(args.prewarm), "--no-cpu-baseline", "--no-isolate", "--no-reference-surface", "--no-other-configs"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[c] = {"error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+                continue
+            d = json.loads(lines[-1])
+            out[c] = {"workload": d["config"]["workload"], "metric": d["metric"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "value": d["value"],
+                      "steps": d["steps"], "warmup": d["warmup"], "kernels_ms": d["kernels_ms"], "roofline": d["roofline"]}
+        except Exception as e:                                   # noqa: BLE001 - the headline line must come out whatever a side run does
+            out[c] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def eval_bench(args, dev):
     """Inference throughput of the reference's evaluation loop (eval.py:219-259) on the HIP path: whole 1080p frames of
     BASELINE.json configs[1] through harness.render_frame - the reference's slicing (100 slices of 20 736 pixels per frame,
@@ -358,6 +380,8 @@ def main():
     ap.add_argument("--no-reference-surface", action="store_true",
                     help="N = 1: skip the third timed pass that drives the model the way the reference's training.py:42-76 does (raw-order "
                          "batches, torch-expression MSE, torch.optim.AdamW), recorded as 'reference_surface'")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, --config s: skip the short child runs of --config l and --config 4k whose results are recorded as 'other_configs'")
     ap.add_argument("--dp", choices=["auto", "sharded", "a2a", "replicated"], default=os.environ.get("NVP_DP_MODE", "auto"),
                     help="N > 1 gradient exchange: sharded = reduce-scatter + sharded AdamW + all-gather (ZeRO-1), a2a = the same with the "
                          "one-hop all_to_all exchange, replicated = chunked all-reduce + full AdamW; auto = time 3 untimed steps of each "
@@ -752,6 +776,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         else:
             line["cpu_baseline"] = None
+        # BASELINE.json's other single-GPU configs (configs[2], configs[3]: config_nvp_l) in the same record: a short run of this same
+        # script per config, each in a process of its own (the driver only runs the default invocation)
+        if world == 1 and not multi and args.config == "s" and not args.no_other_configs:
+            line["other_configs"] = other_configs(args)
         print(json.dumps(line))
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

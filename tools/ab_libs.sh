@@ -21,7 +21,7 @@ else:
 PY
   fi
   for rep in 1 2; do
-  timeout 400 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-reference-surface ${BENCH_ARGS:-} 2>/dev/null | grep '^{' | python -c "
+  timeout 400 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-reference-surface --no-other-configs ${BENCH_ARGS:-} 2>/dev/null | grep '^{' | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms']; i=d['isolated']['kernels_ms'] if d.get('isolated') else {}
 print('%-14s step %.3f iso %.3f |' % ('$name', d['ms_per_step'], d['isolated']['ms_per_step'] if d.get('isolated') else 0), ' '.join('%s %.3f/%.3f' % (n.replace('nvp_',''), v, i.get(n, 0)) for n, v in k.items()))" | tee -a $OUT
