@@ -169,6 +169,19 @@ def work_per_pixel(F: int):
     return flop, byts
 
 
+def ideal_bytes_per_pixel(F: int):
+    """SURVEY.md 8(d)'s FUSED-IDEAL bytes, split over the launches that exist today (no saved activation, latent or dY stream counted:
+    in the fused ideal none of them reaches HBM).  Whole step: coords 12 + step 4 + gt 12 + rgb 12 + gather 804 F + scatter 804 F =
+    40 + 1608 F (3 256 B/px nvp_s, 6 472 nvp_l).  A stage that only moves what the design chose to move has an ideal of ~0."""
+    cells = (192 + 9) * 4 * F
+    return {"nvp_encode_mlp_fwd": 12 + 4 + cells + 12,          # coords + step in, the gathered cells, RGB out  (1 636 B/px for F = 2)
+            "nvp_encode_fwd": 12 + cells, "nvp_mlp_fwd": 4 + 12,
+            "nvp_mlp_bwd_dx": 12,                               # the ground truth / RGB gradient; everything else it moves is saved state
+            "nvp_encode_bwd": cells,                            # the same cells read-modify-written once
+            "nvp_mlp_bwd_dw": 0,
+            "step": 40 + 2 * cells}
+
+
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_16 = 2516.6e12        # bf16 / fp16 dense peak (32x32x16 forms)
 # stages that run on split-operand 16-bit MFMA (DESIGN.md 4.1a): forward, backward chain and dW GEMMs (latents <= 256 rows); their
@@ -243,6 +256,60 @@ def cpu_baseline_worker(n_sample: int, reps: int = 3):
                       f"N = {N_PX}: {med * N_PX / n_sample:.1f} s/step"}
 
 
+def arithmetic_check(dev, n: int = 4096) -> dict:
+    """Untimed CHECKER leg (like cpu_baseline the only other place where bench.py touches oracle/): one forward + backward of the hot path
+    on `n` pixels (config_nvp_s values, a small sparse grid so the float64 side stays cheap) against the oracle evaluated in FLOAT64, with
+    the oracle's fp32 evaluation (= the reference's arithmetic) measured against the same yardstick.  Puts "the split-operand MFMA
+    arithmetic stays below an fp32 fma chain's error" into the driver's line next to nvp_mlp_mfma_products()."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import copy
+    import numpy as np
+    import nvp_oracle as O
+    from nvp_amd import _lib
+    from nvp_amd.modules import NVP
+    cfg = copy.deepcopy(CONFIG_NVP_S)
+    cfg["3d_encoding"].update(x_resolution=20, y_resolution=20, t_resolution=16)
+    gen = torch.Generator().manual_seed(11)
+    sd = O.init_state(cfg, seed=11)
+    for k in list(sd):
+        if k.endswith(".params") or k.endswith("embeddings"):
+            sd[k] = (torch.rand(sd[k].shape, generator=gen) - 0.5) * 0.6          # every cell carries signal
+    cand = torch.rand((2 * n, 3), generator=gen)
+    cand_s = torch.rand((2 * n,), generator=gen)
+    with torch.no_grad():                                                          # away from the LeakyReLU kinks (a 1-ulp flip there says nothing)
+        pre = O.modulator_preacts(O.nvp_latent(cand, sd, cfg), [sd[f"wrapper.modulator.layers.{k}.0.weight"] for k in range(3)],
+                                  [sd[f"wrapper.modulator.layers.{k}.0.bias"] for k in range(3)])
+        keep = torch.nonzero(torch.stack([p_.abs().min(dim=1).values for p_ in pre]).min(dim=0).values > 1e-4).flatten()[:n]
+    coords, steps = cand[keep].unsqueeze(0), cand_s[keep].unsqueeze(0)
+    gt = torch.rand((1, keep.numel(), 3), generator=gen) * 2 - 1
+    grads = {}
+    for name, cast in (("f32", lambda v: v.clone()), ("f64", lambda v: v.double())):
+        ref = {k: cast(v).requires_grad_(True) for k, v in sd.items()}
+        out = O.nvp_forward(coords, steps, ref, cfg)
+        O.image_mse(out, cast(gt)).backward()
+        grads[name] = ({k: v.grad.numpy().astype(np.float64) for k, v in ref.items()}, out.detach().double().numpy())
+    model = NVP(out_features=3, encoding_config=cfg, verbose=False)
+    model.load_state_dict({**sd, **{"wrapper." + k: v for k, v in sd.items() if k.startswith("net.")}})
+    model = model.to(dev)
+    out = model({"all_coords": coords.to(dev), "temporal_steps": steps.to(dev)})["model_out"]
+    ((out - gt.to(dev)) ** 2).mean().backward()
+    torch.cuda.synchronize()
+    got = dict(model.named_parameters())
+    l2 = lambda a, b: float(np.sqrt(((a - b) ** 2).sum()) / (np.sqrt((b ** 2).sum()) + 1e-300))      # noqa: E731
+    worst_hip, worst_ref = (0.0, ""), (0.0, "")
+    for k, g64 in grads["f64"][0].items():
+        worst_hip = max(worst_hip, (l2(got[k].grad.cpu().numpy().astype(np.float64), g64), k))
+        worst_ref = max(worst_ref, (l2(grads["f32"][0][k], g64), k))
+    o = out.detach().cpu().double().numpy()
+    return {"pixels": int(keep.numel()), "mfma_products_per_fp32_product": int(_lib.load().nvp_mlp_mfma_products()),
+            "grad_rel_l2_vs_float64": {"hip_worst": worst_hip[0], "hip_worst_tensor": worst_hip[1],
+                                       "fp32_oracle_worst": worst_ref[0], "fp32_oracle_worst_tensor": worst_ref[1]},
+            "rgb_max_abs": {"hip_vs_fp32_oracle": float(np.abs(o - grads["f32"][1]).max()), "hip_vs_float64": float(np.abs(o - grads["f64"][1]).max()),
+                            "fp32_oracle_vs_float64": float(np.abs(grads["f32"][1] - grads["f64"][1]).max())},
+            "what": "one fwd+bwd of the hot path on random pixels (config_nvp_s values, 16x20x20 sparse grid, grids at +-0.3) against the oracle in "
+                    "float64; the fp32 oracle (the reference's arithmetic) against the same yardstick; untimed, after the timed region"}
+
+
 def other_configs(args) -> dict:
     """`bench.py --config l` and `--config 4k` (headline pass only: no cpu_baseline, isolated or reference-surface pass) as child processes;
     returns {config: {workload, ms_per_step, value, kernels_ms, roofline}} - or {"error": ...} per config that failed."""
@@ -280,8 +347,24 @@ def eval_bench(args, dev):
     model = NVP(out_features=3, encoding_config=make_cfg(F, T), verbose=False).to(dev)
     FLOP_PX, BYTES_PX = work_per_pixel(F)
     D, R = 57 * F, (57 * F + 3) // 4 * 4
-    bytes_fwd = {"nvp_encode_fwd": BYTES_PX["nvp_encode_fwd"], "nvp_mlp_fwd": 4 * R + 4 + 12,       # inference: latent + step in, RGB out
-                 "nvp_encode_mlp_fwd": 12 + 4 + (192 + 9) * 4 * F + 12}                               # fused: coords + step + cells in, RGB out
+    # Byte model of a whole-FRAME lattice (fixed t, every pixel of the frame once): the cells are counted as DISTINCT cells per frame, not
+    # as per-pixel random accesses - 2 M pixels of one frame share the xy plane's 4.6 M cells, read two rows of every xt / yt level and one
+    # (two with --t_interp) t-slice of the sparse grid; the per-pixel figure of the training batches would put the gather above 1.0 of HBM.
+    from nvp_amd import _lib as _L
+    lv = _L.make_levels(make_cfg(F, T)["2d_encoding_xy"])
+    res = [int(lv.res[i]) for i in range(int(lv.n_levels))]
+
+    def frame_cell_bytes(px, t_interp):
+        xy = sum(min(r * r, 4 * px) for r in res)                      # every cell of a level at most once
+        xt_yt = 2 * sum(2 * r for r in res)                            # two t-rows of every level, both planes
+        sparse = 300 * 300 * (2 if t_interp else 1)
+        return 4 * F * (xy + xt_yt + sparse)
+
+    def bytes_fwd(kk, px, t_interp):
+        io = {"nvp_encode_fwd": 12 * px + 4 * R * px, "nvp_mlp_fwd": (4 * R + 4 + 12) * px, "nvp_encode_mlp_fwd": (12 + 4 + 12) * px}.get(kk)
+        if io is None:
+            return None
+        return io + (frame_cell_bytes(px, t_interp) if kk != "nvp_mlp_fwd" else 0)
     FLOP_PX = dict(FLOP_PX)
     products = int(_lib.load().nvp_mlp_mfma_products())
     pk_mlp = PEAK_MFMA_16 / products if products > 1 else PEAK_MFMA_F32
@@ -310,10 +393,13 @@ def eval_bench(args, dev):
         st = {}
         for kk, ms in per_frame.items():
             e = {"ms_per_frame": ms}
-            if kk in bytes_fwd:
-                e["hbm_frac"] = round(bytes_fwd[kk] * px / (ms * 1e-3) / PEAK_HBM, 4)
+            b = bytes_fwd(kk, px, t_interp)
+            if b is not None:
+                e["hbm_frac"] = round(b / (ms * 1e-3) / PEAK_HBM, 4)
+                e["bytes_per_frame"] = b
             if kk in ("nvp_mlp_fwd", "nvp_encode_mlp_fwd"):
                 e["mfma_frac"] = round(FLOP_PX[kk] * px / (ms * 1e-3) / pk_mlp, 4)
+                e["frac_fp32_roof"] = round(FLOP_PX[kk] * px / (ms * 1e-3) / PEAK_MFMA_F32, 4)
             st[kk] = e
         runs[name] = {"frames_per_s": round(n_frames / dt, 2), "mpx_per_s": round(n_frames * px / dt / 1e6, 1), "ms_per_frame": round(dt / n_frames * 1e3, 3),
                       "kernel_ms_per_frame": round(sum(per_frame.values()), 3), "stages": st}
@@ -325,7 +411,7 @@ def eval_bench(args, dev):
             "ms_per_step": head["ms_per_frame"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["label"] + f", {H * W} pixels per frame, random-init parameters, forward only", "mode": "eval"},
             "roofline": {"kernel": dom, "bound": "hbm" if hb >= mf else "mfma", "frac": max(hb, mf), "ms_per_launch": head["stages"][dom]["ms_per_frame"],
-                         "achieved": round((bytes_fwd[dom] if hb >= mf else FLOP_PX[dom]) * H * W / (head["stages"][dom]["ms_per_frame"] * 1e-3) / (1e9 if hb >= mf else 1e12), 1),
+                         "achieved": round((head["stages"][dom]["bytes_per_frame"] if hb >= mf else FLOP_PX[dom] * H * W) / (head["stages"][dom]["ms_per_frame"] * 1e-3) / (1e9 if hb >= mf else 1e12), 1),
                          "peak": PEAK_HBM / 1e9 if hb >= mf else round(pk_mlp / 1e12, 1), "unit": "GB/s" if hb >= mf else "TFLOP/s", "traffic": None},
             "runs": runs, "cpu_baseline": None}
     print(json.dumps(line))
@@ -364,6 +450,7 @@ def main():
                          "per step after 0 / 1 / 2 / 3 / 5 untimed ones); many more do not help - 100 made the timed steps 0.05 ms SLOWER "
                          "(the board runs at its power limit and warms up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-arithmetic-check", action="store_true", help="skip the untimed HIP-vs-float64-oracle gradient check (arithmetic_check)")
     ap.add_argument("--cpu-sample", type=int, default=N_PX // 8)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--cpu-baseline-only", action="store_true",
@@ -427,6 +514,7 @@ def main():
     T, H, W = wl["video"]
     cfg = make_cfg(F, T)
     FLOP_PX, BYTES_PX = work_per_pixel(F)
+    STEP_FLOP_PX = FLOP_PX["nvp_encode_mlp_fwd"] + FLOP_PX["nvp_mlp_bwd_dx"] + FLOP_PX["nvp_mlp_bwd_dw"]     # 658 688 (nvp_s) / 921 344 (nvp_l)
     # one GPU, default path: the scatter's flush also applies the sparse grid's AdamW step (nvp_encode_bwd_sparse_adamw): p, m, v read
     # and written once per element, per step - that is optimizer work (K13) done inside the scatter stage, so it is added to the
     # stage's algorithmic bytes (the separate AdamW launch for the sparse grid and its gradient tensor are gone)
@@ -686,39 +774,50 @@ def main():
         # every hot-path stage against its rooflines (SURVEY 8d asks for the isolated gather/scatter fractions too).  The MLP
         # stages are priced against BOTH the matrix peak of their arithmetic and HBM (their algorithmic stream bytes); the
         # roof a stage sits closer to is reported as its bound.
+        # Units: an MLP stage is MATRIX-bound in SURVEY 8(d)'s accounting - `frac` = 8(d)'s FLOP/px x N / span
+        # against the pipe the kernel issues on / products (`frac_fp32_roof`: against the 157.3 TF fp32-MFMA roof 8(d) names).  Its bytes
+        # are reported twice and never as `frac`: `ideal_bytes_frac` = 8(d)'s fused-ideal bytes of the launch against 8 TB/s (removing a
+        # saved stream RAISES it: the span shrinks, the numerator stays) and `stream_bytes_frac` = the bytes THIS design moves (saved
+        # activations, latent, dY streams included) - a utilisation figure, not a roofline fraction.
+        IDEAL_PX = ideal_bytes_per_pixel(F)
+
         def price(k, ms, alone=False):
             out = {"ms": ms}
             if k in BYTES_PX:
                 # (the side-streams-off pass also runs the optimizer after backward: its scatter stage carries no AdamW bytes)
                 a = (BYTES_PX[k] - (fused_sparse_bytes_per_px if alone and k == "nvp_encode_bwd" else 0.0)) * N_PX / (ms * 1e-3)
-                out.update({"achieved_gbs": round(a / 1e9, 1), "hbm_frac": round(a / PEAK_HBM, 4),
+                out.update({"stream_gbs": round(a / 1e9, 1), "stream_bytes_frac": round(a / PEAK_HBM, 4),
                             "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None})
+                if IDEAL_PX.get(k):
+                    out["ideal_bytes_frac"] = round(IDEAL_PX[k] * N_PX / (ms * 1e-3) / PEAK_HBM, 4)
+                    if traffic.get(k):
+                        out["pmc_over_ideal"] = round(traffic[k] / (IDEAL_PX[k] * N_PX), 2)
             if k in FLOP_PX:
                 a = FLOP_PX[k] * N_PX / (ms * 1e-3)
                 out.update({"mfma": split_name, "achieved_tflops": round(a / 1e12, 2), "peak_tflops": round(pk_mlp / 1e12, 1),
-                            "mfma_frac": round(a / pk_mlp, 4)})
-            hb, mf = out.get("hbm_frac", 0.0), out.get("mfma_frac", 0.0)
-            out["bound"] = "hbm" if hb >= mf else "mfma"
-            out["frac"] = max(hb, mf)
+                            "mfma_frac": round(a / pk_mlp, 4), "frac_fp32_roof": round(a / PEAK_MFMA_F32, 4)})
+                out["bound"], out["frac"] = "mfma", out["mfma_frac"]
+            else:
+                out["bound"], out["frac"] = "hbm", out.get("stream_bytes_frac", 0.0)       # gather / scatter stages: their bytes ARE 8(d)'s
             return out
         stages = {k: price(k, ms) for k, ms in kms.items() if k in FLOP_PX or k in BYTES_PX}
-        roof = None
-        if dom in stages:
-            st = stages[dom]
+
+        def roof_of(k, st, ms):
             if st["bound"] == "mfma":
-                roof = {"kernel": dom, "bound": "mfma", "achieved": st["achieved_tflops"], "peak": st["peak_tflops"], "unit": "TFLOP/s",
-                        "frac": st["mfma_frac"], "traffic": traffic.get(dom), "ms_per_launch": kms[dom],
-                        "algorithmic_flop_per_launch": FLOP_PX[dom] * N_PX}
+                r = {"kernel": k, "bound": "mfma", "achieved": st["achieved_tflops"], "peak": st["peak_tflops"], "unit": "TFLOP/s",
+                     "frac": st["mfma_frac"], "frac_fp32_roof": st["frac_fp32_roof"], "traffic": traffic.get(k), "ms_per_launch": ms,
+                     "algorithmic_flop_per_launch": FLOP_PX[k] * N_PX, "peak_is": "16-bit dense MFMA peak / products issued per fp32 product" if products > 1 else "fp32 MFMA dense peak",
+                     "stream_bytes_frac": st.get("stream_bytes_frac"), "ideal_bytes_frac": st.get("ideal_bytes_frac"),
+                     "ideal_bytes_per_launch": IDEAL_PX.get(k, 0) * N_PX, "pmc_over_ideal": st.get("pmc_over_ideal")}
             else:
-                roof = {"kernel": dom, "bound": "hbm", "achieved": st["achieved_gbs"], "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                        "frac": st["hbm_frac"], "traffic": traffic.get(dom), "ms_per_launch": kms[dom],
-                        "algorithmic_bytes_per_launch": BYTES_PX[dom] * N_PX}
-                if dom in FLOP_PX:
-                    roof["mfma_frac"] = st["mfma_frac"]
-                if traffic.get(dom):
-                    # what the kernel actually moved through HBM per second (PMC bytes / this run's launch time): the gap between
-                    # `frac` and this is re-fetched or sector-padded traffic, the gap between this and 1 is what the kernel leaves idle
-                    roof["traffic_frac"] = round(traffic[dom] / (kms[dom] * 1e-3) / PEAK_HBM, 4)
+                r = {"kernel": k, "bound": "hbm", "achieved": st["stream_gbs"], "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                     "frac": st["stream_bytes_frac"], "traffic": traffic.get(k), "ms_per_launch": ms,
+                     "algorithmic_bytes_per_launch": BYTES_PX[k] * N_PX, "ideal_bytes_frac": st.get("ideal_bytes_frac"), "pmc_over_ideal": st.get("pmc_over_ideal")}
+            if traffic.get(k):
+                # what the kernel actually moved through HBM per second (PMC bytes / this run's launch time)
+                r["traffic_frac"] = round(traffic[k] / (ms * 1e-3) / PEAK_HBM, 4)
+            return r
+        roof = roof_of(dom, stages[dom], kms[dom]) if dom in stages else None
         iso_line = None
         if isolated is not None:
             ikms = {k: round(v[0] * v[1] / isolated["n_inst"], 4) for k, v in isolated["kernels"].items()}
@@ -727,10 +826,7 @@ def main():
                         "ms_per_step": isolated["ms_per_step"], "kernels_ms": ikms,
                         "stages": {k: price(k, ms, alone=True) for k, ms in ikms.items() if k in FLOP_PX or k in BYTES_PX}}
             if roof is not None and roof["kernel"] in iso_line["stages"]:
-                st = iso_line["stages"][roof["kernel"]]
-                iso_line["roofline"] = {"kernel": roof["kernel"], "bound": roof["bound"], "unit": roof["unit"], "peak": roof["peak"],
-                                        "achieved": st["achieved_gbs"] if roof["bound"] == "hbm" else st["achieved_tflops"],
-                                        "frac": st["hbm_frac"] if roof["bound"] == "hbm" else st["mfma_frac"], "ms_per_launch": ikms[roof["kernel"]]}
+                iso_line["roofline"] = roof_of(roof["kernel"], iso_line["stages"][roof["kernel"]], ikms[roof["kernel"]])
         hot_ms = sum(kms.values())
         n_params = sum(p.numel() for p in parallel.unique_parameters(model))
         exchange = {"replicated": "chunked all-reduce (grid grads async under the dW GEMMs) + AdamW on every rank",
@@ -752,6 +848,16 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "step_contents": "device sampler + fwd + mse + bwd + " + ((exchange[mode] + " + ") if multi else "AdamW + ") + "cosine"},
             "roofline": roof,
+            # the whole step in 8(d)'s units: its GEMM FLOP against the fp32-MFMA roof 8(d) names and against the pipe the kernels issue on;
+            # the HBM bytes the step moved (PMC, committed measurement) over 8(d)'s fused-ideal bytes
+            "step_roofline": {"flop_per_px": STEP_FLOP_PX, "achieved_tflops": round(value * 1e6 / world * STEP_FLOP_PX / 1e12, 2),
+                              "step_frac_fp32_roof": round(value * 1e6 / world * STEP_FLOP_PX / PEAK_MFMA_F32, 4),
+                              "step_frac_issued_pipe": round(value * 1e6 / world * STEP_FLOP_PX / pk_mlp, 4),
+                              "ideal_bytes_per_px": IDEAL_PX["step"],
+                              "step_ideal_bytes_frac": round(value * 1e6 / world * IDEAL_PX["step"] / PEAK_HBM, 4),
+                              "pmc_bytes_per_step": (sum(traffic[k] for k in kms if traffic.get(k)) or None),
+                              "pmc_over_ideal": (round(sum(traffic[k] for k in kms if traffic.get(k)) / (IDEAL_PX["step"] * N_PX), 2)
+                                                 if any(traffic.get(k) for k in kms) else None)},
             "kernels_ms": kms,
             "stages": stages,
             "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
@@ -772,6 +878,11 @@ def main():
             line["dp"] = {"mode": mode, "autotune_ms_per_step": tune, "gradient_bytes": 4 * n_params,
                           "post_backward_ms_per_rank": post_all, "adamw_share_ms_est": round(adam_ms, 3),
                           "exposed_exchange_ms_per_rank_est": [round(max(v - adam_ms, 0.0), 3) for v in post_all]}
+        if world == 1 and args.config == "s" and not args.no_arithmetic_check:
+            try:
+                line["arithmetic_check"] = arithmetic_check(dev)
+            except Exception as e:      # the checker must not cost the line
+                line["arithmetic_check"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline and args.config == "s":
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         else:

@@ -275,7 +275,8 @@ int nvp_sample_order_by_column(const int64_t* pi, int64_t* order, int64_t n, int
  * ascending key(y) = sum over the levels of the xy / yt planes' grid row index of coords[:,2] (both planes are indexed by y,
  * modules.py:61,63), ties in input order (stable, hence deterministic).  A batch gathered in this order has non-decreasing grid rows
  * at every level, which is all NVP_COORDS_SORTED_BY_Y promises the scatter.  One counting sort; NVP_ERR_UNSUPPORTED when the key
- * space exceeds 12 288 (level geometries far beyond the reference's configs): use a library sort of coords[:,2] then. */
+ * space exceeds 12 288 (level geometries far beyond the reference's configs): use a library sort of coords[:,2] then.  The workspace
+ * query returns the same NVP_ERR_UNSUPPORTED (negative) for such geometries, so a caller never sizes a buffer for a call that would refuse. */
 int64_t nvp_order_by_rows_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt);
 int nvp_order_by_rows(const float* coords, int64_t* order, int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt,
                       void* workspace, int64_t workspace_bytes, void* stream);

@@ -28,17 +28,36 @@ def install_optimizer() -> None:
     if _STOCK_ADAMW is not None:
         return
     stock = _STOCK_ADAMW = torch.optim.AdamW
+    from .optim import AdamW as NvpAdamW
 
-    def AdamW(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
-        from .optim import AdamW as NvpAdamW
-        plist = list(params)
-        plain = all(torch.is_tensor(p) for p in plist)              # (param groups given as dicts keep the stock class)
-        ok = plain and plist and all(p.is_cuda and p.dtype == torch.float32 for p in plist) and not any(kw.get(k) for k in ("amsgrad", "maximize", "capturable", "differentiable"))
-        if ok and isinstance(lr, float):
-            return NvpAdamW(plist, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        return stock(plist, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+    class _Routing(type(stock)):
+        # isinstance(opt, torch.optim.AdamW) stays true for the routed optimizer (LR-scheduler wrappers, checkpoint loaders, Lightning)
+        def __instancecheck__(cls, obj):
+            return isinstance(obj, NvpAdamW) or type.__instancecheck__(cls, obj)
 
-    AdamW.__doc__ = "torch.optim.AdamW, routed to nvp_amd.optim.AdamW for fp32 HIP parameters (nvp_amd.compat.install_optimizer)"
+    class AdamW(stock, metaclass=_Routing):
+        """torch.optim.AdamW, routed to nvp_amd.optim.AdamW for fp32 HIP parameters (nvp_amd.compat.install_optimizer).  A SUBCLASS of the
+        stock class - subclassing it, isinstance checks, __name__ / pickle lookups keep working; `foreach` / `fused` are accepted and
+        ignored on the routed path (the routed step is one launch over all tensors already)."""
+
+        def __new__(cls, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
+            if cls is AdamW:                                            # (subclasses of this class keep the stock behaviour)
+                plist = list(params)
+                plain = all(torch.is_tensor(p) for p in plist)          # (param groups given as dicts keep the stock class)
+                ok = (plain and plist and all(p.is_cuda and p.dtype == torch.float32 for p in plist)
+                      and not any(kw.get(k) for k in ("amsgrad", "maximize", "capturable", "differentiable")) and isinstance(lr, float))
+                if ok:
+                    return NvpAdamW(plist, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)      # not an instance of cls: __init__ is not re-run
+                self = object.__new__(cls)
+                self._nvp_params = plist                                # a generator was consumed above: hand the list to __init__
+                return self
+            return object.__new__(cls)
+
+        def __init__(self, params, *a, **kw):
+            super().__init__(self.__dict__.pop("_nvp_params", params), *a, **kw)
+
+    AdamW.__name__ = AdamW.__qualname__ = "AdamW"
+    AdamW.__module__ = stock.__module__
     torch.optim.AdamW = AdamW
 
 

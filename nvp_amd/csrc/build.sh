@@ -8,7 +8,7 @@
 #                              NVP_SKIP_EXPERIMENTS=1 skips it.
 # and its all-fp32-MFMA twin
 # libnvp_hip_fp32mfma.so (same sources, -DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0: every MLP GEMM on v_mfma_f32_32x32x2_f32).
-# The twin is TEST INFRASTRUCTURE: tests/test_gpu_long_horizon.py trains both builds on identical batches to bound what the
+# The twin is TEST INFRASTRUCTURE: tests/test_gpu_zz_trajectories.py trains both builds on identical batches to bound what the
 # split-operand 16-bit MFMA arithmetic of the default build does to the PSNR trajectory.  NVP_SKIP_TWIN=1 skips it.
 # A failed compile aborts the build: its old object is removed first and every job's exit status is
 # checked, so the link can never pick up a stale object (bare `wait` returns 0 whatever the jobs did).

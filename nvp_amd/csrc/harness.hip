@@ -252,6 +252,7 @@ static int row_key_count(const nvp_levels* lv_xy, const nvp_levels* lv_yt) {
 int64_t nvp_order_by_rows_workspace_bytes(int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt) {
     if (n < 0 || !lv_xy || !lv_yt) return NVP_ERR_BADARG;
     const int nk = row_key_count(lv_xy, lv_yt);
+    if (nk > 12288 || n >= ((int64_t)1 << 31)) return NVP_ERR_UNSUPPORTED;             // what nvp_order_by_rows refuses: say so BEFORE the caller allocates nchunks * nk * 4 bytes
     return nvp_sample_order_workspace_bytes(n, nk) + ((n + 63) / 64) * 256;             // counting-sort tables + the keys
 }
 

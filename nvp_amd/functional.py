@@ -396,6 +396,19 @@ def _scatter_ws_bytes(lib, n, lv_xy, lv_yt, lv_xt, sh) -> int:
     return b
 
 
+def materialises_nothing(model, temporal_interp: bool) -> bool:
+    """True when a no-grad forward of `model` writes no per-pixel tensor besides the RGB (the fused forward takes the call): then a whole
+    frame can go through one call whatever its size (harness.render_frame); otherwise the call writes the latent [n, D] and callers bound n."""
+    if temporal_interp or not FUSED_FWD:
+        return False
+    try:
+        sh = _sparse_shape(model.sparse_grid._grid())
+        return bool(L.load().nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
+                                                           C.byref(model.keyframes_xt.levels), C.byref(sh)))
+    except Exception:
+        return False
+
+
 class NVPFused(torch.autograd.Function):
     """NVP.forward hot path (R11): coords [N,3], steps [N] -> rgb [N,3] in four kernels
     (encode -> pack -> MLP), the latent only ever exists in the MFMA-friendly PTM layout."""

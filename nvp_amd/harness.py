@@ -20,12 +20,15 @@ N_SAMPLES = 1245184          # reference dataio.py:91
 # nothing of the gradient exchange / optimizer yet): bench.py records a HIP event there to time the exposed exchange.
 AFTER_BACKWARD_HOOK = None
 # one GPU, nvp_amd.optim.AdamW: update the grids on a side stream as soon as the scatter has produced their gradients (0: after backward)
-EARLY_ADAMW = os.environ.get("NVP_EARLY_ADAMW", "1") != "0"
+# NVP_FUSED_ADAMW=0: ONE kill switch for every update that happens before step() (early side-stream update, sparse and dense flushes) -
+# for loops that clip / accumulate gradients, read the grids' .grad, skip steps or recover from failed ones (nvp_amd/optim.py)
+_ALL_FUSED = os.environ.get("NVP_FUSED_ADAMW", "1") != "0"
+EARLY_ADAMW = _ALL_FUSED and os.environ.get("NVP_EARLY_ADAMW", "1") != "0"
 # one GPU, nvp_amd.optim.AdamW, y-sorted batches: the sparse grid's AdamW step is applied by the scatter kernel's flush
 # (nvp_encode_bwd_sparse_adamw; bit-identical parameters; 0: gradient tensor + early_update)
-FUSED_SPARSE_ADAMW = os.environ.get("NVP_FUSED_SPARSE_ADAMW", "1") != "0"
+FUSED_SPARSE_ADAMW = _ALL_FUSED and os.environ.get("NVP_FUSED_SPARSE_ADAMW", "1") != "0"
 # ... and the three dense planes' by band_kernel / slab_reduce_kernel (nvp_encode_bwd_dense_adamw; bit-identical; 0: gradient tensors + early_update)
-FUSED_DENSE_ADAMW = os.environ.get("NVP_FUSED_DENSE_ADAMW", "1") != "0"
+FUSED_DENSE_ADAMW = _ALL_FUSED and os.environ.get("NVP_FUSED_DENSE_ADAMW", "1") != "0"
 SAMPLER_SORT = os.environ.get("NVP_SAMPLER_SORT", "nvp")        # "torch": torch.argsort for the sampler's column order
 RECORD_STREAM = os.environ.get("NVP_SAMPLER_RECORD_STREAM", "0") == "1"     # DeviceVideo(prefetch=True): record_stream on every batch tensor
 
@@ -275,6 +278,11 @@ def train_psnr(loss: torch.Tensor) -> float:
 
 
 _LATTICE = {}          # (device, H', W') -> [H'W', 3] float32 with columns 1, 2 = (row, col) lattice coordinates; column 0 is the frame's t
+_LATTICE_MAX_BYTES = 1 << 30       # cached lattices are evicted (oldest first) beyond this: a 4K x --s_interp 2 lattice alone is 400 MB
+# pixels per model call when a call MATERIALISES per-pixel state (the two-kernel forward of nvp_l-sized latents and forward_inter write the
+# latent [n, D] and the MLP's buffers): what the reference's 100-slice loop (eval.py:233-239) exists to bound.  The fused no-grad forward
+# (functional.fused_forward_supported) materialises nothing and takes the frame in one call.
+MAX_PIXELS_PER_CALL = int(os.environ.get("NVP_EVAL_MAX_PIXELS", str(1 << 22)))
 
 
 @torch.no_grad()
@@ -310,9 +318,9 @@ def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[
         lat = torch.empty((total, 3), device=dev, dtype=torch.float32)
         lat[:, 1] = rows[torch.div(p, Wq, rounding_mode="floor")]
         lat[:, 2] = cols[p % Wq]
-        if len(_LATTICE) >= 4:
-            _LATTICE.clear()
         _LATTICE[key] = lat
+        while len(_LATTICE) > 1 and sum(t.numel() * 4 for t in _LATTICE.values()) > _LATTICE_MAX_BYTES:
+            _LATTICE.pop(next(iter(_LATTICE)))               # oldest first; the newest always stays
     half_dt = 0.5 / org_nframes
     tstep = torch.linspace(half_dt, 1 - half_dt, nframes)[f].item()
     tcoord = torch.linspace(0, 1, nframes)[f].item()
@@ -321,13 +329,18 @@ def render_frame(model, f: int, org_nframes: int, resolution, nframes: Optional[
     steps_all = torch.full((1, total), tstep, device=dev, dtype=torch.float32)
     out = torch.zeros((total, 3), device=dev, dtype=torch.float32)
     split = int(total / n_slice)
+    from . import functional
     if hooks is None:                   # the parameters cannot change inside this call (no_grad): the slices share one weight pack
-        from . import functional
         hooks = functional.StepHooks()
         hooks.packed_cache = {}
     spans = [(i * split, (i + 1) * split) for i in range(n_slice if split > 0 else 0)]
     if not literal_slices and spans:
-        spans = [(0, split * n_slice)]          # the same pixels, one call
+        # the same pixels in one call - or, where a call materialises per-pixel state, in chunks of <= MAX_PIXELS_PER_CALL (bit-identical:
+        # every pixel is independent), so a 4K or --s_interp lattice cannot ask for tens of GB of latent
+        covered = split * n_slice
+        one_call = functional.materialises_nothing(model, temporal_interp)
+        step = covered if one_call else max(min(covered, MAX_PIXELS_PER_CALL), 1)
+        spans = [(lo, min(lo + step, covered)) for lo in range(0, covered, step)]
     for lo, hi in spans:
         out[lo:hi] = model({"all_coords": coords_all[lo:hi].unsqueeze(0), "temporal_steps": steps_all[:, lo:hi], "nvp_hooks": hooks},
                            temporal_interp=temporal_interp)["model_out"].reshape(-1, 3)

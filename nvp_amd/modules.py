@@ -8,6 +8,8 @@ pixel-tile-major layout the MFMA MLP consumes; backward is the mirrored chain.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -39,8 +41,8 @@ class NVP(nn.Module):
         latent_dim += c3["n_features_per_level"] * 9
         self.latent_dim = latent_dim
         self.wrapper = modulation.SirenWrapper(self.net, latent_dim=latent_dim)
-        if kwargs.get("verbose", True):
-            print(self)          # as the reference does (modules.py:49); verbose=False (not a reference argument) silences it
+        if kwargs.get("verbose", os.environ.get("NVP_QUIET", "0") != "1"):
+            print(self)          # as the reference does (modules.py:49); verbose=False (not a reference argument) or NVP_QUIET=1 silences it
 
     def forward(self, model_input, temporal_interp=False, params=None):
         timesteps = model_input['temporal_steps']

@@ -7,11 +7,15 @@ It is a regular `torch.optim.Optimizer`: `param_groups[i]['lr']` is what `Cosine
 Same update rule as torch.optim.AdamW (decoupled weight decay, bias-corrected, no amsgrad/maximize).
 There is no CPU path: parameters must live on a HIP device.
 
-Early / fused updates (harness.train_step on one GPU: `early_update`, `fused_peek` / `fused_commit`) step the grids DURING backward.
+Early / fused updates (harness.train_step on one GPU: `early_update`, `fused_peek` / `fused_commit`) step the grids DURING backward:
+the sparse grid (NVP_FUSED_SPARSE_ADAMW, default on) AND the three keyframe planes (NVP_FUSED_DENSE_ADAMW, default on) are updated
+inside the scatter's flushes - after backward their `.grad` is None and their parameters are already stepped (a grad-norm log or a
+clipping hook on AFTER_BACKWARD sees no gradient for them); the remaining grids, if any, follow on a side stream (NVP_EARLY_ADAMW).
 That is only equivalent to the reference's loop when every backward is followed by exactly one `step()` on unmodified gradients:
-loops that clip or accumulate gradients, inspect `.grad` of the grids (the sparse grid has none on the fused route), skip steps or
-recover from exceptions must run with NVP_EARLY_ADAMW=0 NVP_FUSED_SPARSE_ADAMW=0 (then this class is a plain fused AdamW).  An
-iteration whose step() never ran is reported by `begin_step()` (RuntimeWarning, `unfinished_iterations`).
+loops that clip or accumulate gradients, inspect `.grad` of the grids, skip steps or recover from exceptions must run with
+NVP_FUSED_ADAMW=0 (one switch for all of the above; = NVP_EARLY_ADAMW=0 NVP_FUSED_SPARSE_ADAMW=0 NVP_FUSED_DENSE_ADAMW=0) - then this
+class is a plain one-launch AdamW.  An iteration whose step() never ran is reported by `begin_step()` (RuntimeWarning,
+`unfinished_iterations`).
 """
 from __future__ import annotations
 
@@ -49,8 +53,8 @@ class AdamW(torch.optim.Optimizer):
             import warnings
             self.unfinished_iterations = getattr(self, "unfinished_iterations", 0) + 1
             warnings.warn(f"nvp_amd.optim.AdamW: {len(self._early_done)} parameter tensor(s) were updated early in an iteration whose step() never "
-                          "ran; they are one optimizer step ahead of the rest (set NVP_EARLY_ADAMW=0 NVP_FUSED_SPARSE_ADAMW=0 for loops that skip or "
-                          "recover from failed steps, clip or accumulate gradients)", RuntimeWarning, stacklevel=2)
+                          "ran (the sparse grid and the keyframe planes are stepped inside the scatter's flushes); they are one optimizer step ahead of the "
+                          "rest (set NVP_FUSED_ADAMW=0 for loops that skip or recover from failed steps, clip or accumulate gradients or read the grids' .grad)", RuntimeWarning, stacklevel=2)
         self._early_done.clear()
 
     @torch.no_grad()

@@ -9,18 +9,45 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_THREADS = 16
+
+
+class oracle_determinism:
+    """Context for the oracle's TRAININGS (chaotic comparisons): fixed intra-op thread count and torch's deterministic algorithms,
+    so the checker's trajectory is reproducible run to run and box to box.  Scoped, because deterministic mode makes some ATen
+    device kernels used elsewhere in the suite raise."""
+
+    def __enter__(self):
+        import torch
+        self._n, self._det = torch.get_num_threads(), torch.are_deterministic_algorithms_enabled()
+        torch.set_num_threads(ORACLE_THREADS)
+        torch.use_deterministic_algorithms(True)
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.use_deterministic_algorithms(self._det)
+        torch.set_num_threads(self._n)
+        return False
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The CPU oracle runs many small / medium ATen ops; on the GPU box's 2 x 64-core host the default 128 intra-op threads
-    # make them SLOWER (fork-join over two NUMA nodes per op).  Cap the pool for the checker.
+    # The CPU oracle is the CHECKER: its results must not depend on the host it runs on.  ATen's CPU kernels partition their
+    # reductions by the intra-op thread count, so the count is FIXED (not "whatever the box has, capped"): the builder's box and the
+    # driver's box then walk the same oracle trajectory.  (16 is also faster than the GPU hosts' default 128: fork-join over two NUMA
+    # nodes per small op.)
     import torch
-    if torch.get_num_threads() > 32:
-        torch.set_num_threads(32)
+    torch.set_num_threads(ORACLE_THREADS)
+    os.environ.setdefault("NVP_QUIET", "1")        # NVP.__init__ prints the module tree like the reference (modules.py:49): keep the driver's tail for numbers
 
 
 def pytest_collection_modifyitems(config, items):
+    # Deterministic parity first: every multi-hundred-step TRAJECTORY test (statistical margins on a chaotic comparison) is collected
+    # after everything else, whatever its file is called - a margin can then never hide a deterministic test behind `-x`.
+    # Before them: golden-vector and oracle parity (test_gpu_parity), the real configuration sizes, the twin, then the multi-process tests.
+    order = ("test_gpu_parity", "test_gpu_real_configs", "test_gpu_twin", "test_gpu_dp2")
+    items.sort(key=lambda it: next((i for i, n in enumerate(order) if n in it.nodeid), len(order) + (1 if "zz_trajectories" in it.nodeid else 0)))
     import torch
     if torch.cuda.is_available():
         return

@@ -1,6 +1,6 @@
 """The yardstick is checked too (-m gpu).
 
-tests/test_gpu_long_horizon.py bounds the default build's split-operand arithmetic against libnvp_hip_fp32mfma.so (the same
+tests/test_gpu_zz_trajectories.py (full-size test) bounds the default build's split-operand arithmetic against libnvp_hip_fp32mfma.so (the same
 sources with every MLP GEMM on v_mfma_f32_32x32x2_f32).  That twin is only a yardstick if it passes the ORACLE tests itself:
 here the golden-vector MLP test, the whole-path forward/backward test and the real-config test of configs[1] run again in a
 subprocess whose NVP_HIP_LIB points at the twin (the library is chosen at load time, once per process)."""
@@ -42,7 +42,8 @@ def test_twin_is_the_fp32_mfma_build():
 
 def test_fp32_mfma_twin_passes_the_oracle_tests():
     assert os.path.exists(TWIN), f"{TWIN} missing: run nvp_amd/csrc/build.sh"
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "900"] + ORACLE_TESTS,
+    # (no --timeout flag: it belongs to the pytest-timeout plugin, which a GPU image need not carry; subprocess.run bounds the run)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + ORACLE_TESTS,
                        cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     tail = r.stdout.strip().splitlines()[-1]

@@ -1,0 +1,294 @@
+"""Trajectory tests (-m gpu): PSNR at equal step count over hundreds of optimisation steps, the HIP path against the ORACLE.
+
+Collected LAST (tests/conftest.py sorts `zz_trajectories` behind everything else): these compare two trainings of a chaotic
+problem, their margins are statistical, and a margin must never stand in front of the deterministic parity tests
+(test_gpu_parity.py, test_gpu_real_configs.py, test_gpu_twin.py, test_gpu_dp2.py) under `-x`.
+
+The checker is made reproducible: the oracle's trainings run with a FIXED intra-op thread count and torch's deterministic
+algorithms (conftest.oracle_determinism); the 1 000-step oracle walks in a process of its own with MKL's conditional numerical
+reproducibility switched on (util_windows.oracle_env).  The HIP side is bit-reproducible by construction (fixed-point scatter,
+ordered dW reduction).  Every test prints ONE summary line (`PSNR-PARITY ...`) so the numbers reach the driver's tail."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import nvp_oracle as O
+from conftest import ROOT, oracle_determinism, report, small_cfg
+from util_parity import _load_state_into
+from util_windows import oracle_env, ulp_perturbed, window_verdicts
+
+pytestmark = pytest.mark.gpu
+
+TWIN = os.path.join(ROOT, "nvp_amd", "csrc", "libnvp_hip_fp32mfma.so")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _say(line: str) -> None:
+    """one summary line past pytest's capture (the driver keeps the tail of the run's output)"""
+    sys.__stdout__.write("\nPSNR-PARITY " + line + "\n")
+    sys.__stdout__.flush()
+
+
+# ----------------------------------------------------------------------------------------
+# PSNR at equal step count: the HIP path and the oracle trained on IDENTICAL batches
+# (BASELINE.json configs[0]: 64x64x16 synthetic RGB, config_nvp_s values; north_star: +-0.02 dB)
+# ----------------------------------------------------------------------------------------
+def _psnr_trajectories(seed, steps_total, n_levels=16, log=None, ulp_twin=True, clip="procedural"):
+    """Train (a) the oracle, (b) the oracle started <= 1 ulp away, (c) the HIP path with the product's own AdamW kernel on
+    IDENTICAL batches drawn with the reference's sampler; returns per-step train PSNRs (training.py:58) and the three
+    final parameter sets' full-frame eval PSNRs (eval.py:243-256)."""
+    import math
+    from nvp_amd import harness
+    from nvp_amd.modules import NVP
+    from nvp_amd.optim import AdamW as _NvpAdamW
+    T, H, W, n = 16, 64, 64, 8192
+    cfg = small_cfg(F=2, T=T, X=20, Y=20, n_levels=n_levels)
+    sd = O.init_state(cfg, seed=seed)                       # reference init distributions
+    model = NVP(out_features=3, encoding_config=cfg)
+    _load_state_into(model, sd)
+    model = model.to(dev())
+    if clip == "natural":          # 1/f texture + edges + motion + sensor grain (harness.natural_video): the PSNR saturates at the grain floor
+        video = harness.natural_video(T, H, W, torch.device("cpu"), seed=seed, grain=4.0)
+    else:
+        video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=seed)       # u8 [T,H,W,3]
+    flat = video.reshape(T, H * W, 3)
+
+    def make_ref(state):
+        ref = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+        opt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)
+        return ref, opt, torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps_total, eta_min=1e-5)
+
+    ref_a, opt_a, sch_a = make_ref(sd)
+    ref_b, opt_b, sch_b = make_ref(ulp_perturbed(sd, seed + 1000))
+    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)      # the product's optimiser: nvp_adamw_step + cosine
+    assert isinstance(opt_g, _NvpAdamW)
+    gen = torch.Generator().manual_seed(seed)
+    pa, pb, pg = [], [], []
+    for it in range(steps_total):
+        ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)          # the reference's sampler order
+        gt_u8 = flat[ti, pi].unsqueeze(0)
+        with oracle_determinism():                                                          # the checker: same trajectory on every box
+            for ref, opt, sch, acc in ((ref_a, opt_a, sch_a, pa), (ref_b, opt_b, sch_b, pb))[:2 if ulp_twin else 1]:
+                out_r = O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg)        # training.py:50-76 order
+                loss_r = O.image_mse(out_r, O.normalise_gt(gt_u8))
+                opt.zero_grad(); loss_r.backward(); opt.step(); sch.step()
+                acc.append(10 * math.log10(4 / float(loss_r.detach())))                         # training.py:58
+        mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
+        out_g = model(mi)["model_out"]
+        loss_g = harness.image_mse_u8(out_g, gt_u8.to(dev()))
+        opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
+        pg.append(10 * math.log10(4 / float(loss_g)))
+        if log:
+            with open(log, "a") as f:
+                f.write(f'{{"seed": {seed}, "step": {it + 1}, "psnr_oracle": {pa[-1]:.4f}, "psnr_oracle_1ulp": {(pb[-1] if pb else float("nan")):.4f}, "psnr_hip": {pg[-1]:.4f}}}\n')
+    # evaluation PSNR on full frames (eval.py:243-256) with the final parameter sets
+    frames = (0, 7, 15)
+    data = harness.DeviceVideo(video.to(dev()), n_samples=n, seed=0)
+    ev_g = harness.eval_psnr(model, data, frames=list(frames), n_slice=4)
+
+    def eval_ref(ref):
+        with torch.no_grad():
+            mg, ps = O.get_mgrid_2d(H, W), []
+            for f in frames:
+                c = torch.cat((torch.linspace(0, 1, T)[f].expand(H * W, 1), mg), dim=1).unsqueeze(0)
+                s_ = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[f].expand(1, H * W)
+                img = torch.clamp((O.nvp_forward(c, s_, {k: v.detach() for k, v in ref.items()}, cfg) + 1) / 2, 0, 1)
+                ps.append(10 * math.log10(1 / float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())))
+            return sum(ps) / len(ps)
+
+    return pa, pb, pg, eval_ref(ref_a), (eval_ref(ref_b) if ulp_twin else float("nan")), ev_g
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_psnr_at_equal_steps_matches_oracle(seed):
+    """north_star: PSNR within +-0.02 dB at equal step count - 100 steps (NVP_PSNR_STEPS), three seeds, identical batches, the
+    product's own AdamW kernel, plus the full-frame evaluation PSNR of the final parameters.
+
+    Each run also trains the oracle started <= 1 ulp away from itself: two fp32 trainings of this model drift apart whatever
+    computes them (sine layers with w0 = 30 amplify rounding differences); that envelope is REPORTED next to the gap
+    (measured on MI355X: gap 0.008-0.013 dB, envelope 0.006-0.011 dB, signed final differences -0.008 ... +0.011 dB: no
+    systematic sign - profiles/r02_parity_report.jsonl; against a float64 training the HIP path is closer than the fp32 oracle,
+    profiles/r02_psnr_bisect_f64_f32_hip.txt).  12 of the 16 keyframe levels (0.36 M cells per
+    plane instead of 4.6 M) keep the three CPU trainings of the checker affordable; the 16-level model is covered by
+    test_psnr_at_equal_steps_full_levels."""
+    steps_total = int(os.environ.get("NVP_PSNR_STEPS", "100"))
+    pa, pb, pg, ev_a, ev_b, ev_g = _psnr_trajectories(seed, steps_total, 12, log=os.environ.get("NVP_PSNR_LOG"))
+    import math
+    assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
+    gap = [abs(a - g) for a, g in zip(pa, pg)]
+    env = [abs(a - b) for a, b in zip(pa, pb)]
+    report("psnr_equal_steps", seed=seed, n_levels=12, steps=steps_total, gap30=max(gap[:30]), gap=max(gap), envelope=max(env),
+           final_hip_minus_oracle=pg[-1] - pa[-1], final_1ulp_minus_oracle=pb[-1] - pa[-1],
+           eval_hip_minus_oracle=ev_g - ev_a, eval_1ulp_minus_oracle=ev_b - ev_a, final_psnr=pa[-1])
+    # north_star: +-0.02 dB, UNCONDITIONAL (measured 0.007-0.011 dB train, 0.001-0.004 dB eval).  The oracle's drift against its
+    # own 1-ulp twin on the same batches is reported next to it (envelope), it does not widen the bound.
+    _say(f"100-step seed={seed} train_gap_max={max(gap):.4f} envelope_max={max(env):.4f} final_hip-oracle={pg[-1] - pa[-1]:+.4f} "
+         f"final_1ulp-oracle={pb[-1] - pa[-1]:+.4f} eval_hip-oracle={ev_g - ev_a:+.4f} eval_1ulp-oracle={ev_b - ev_a:+.4f} dB")
+    assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB over {steps_total} steps (1-ulp envelope {max(env):.4f} dB)"
+    assert abs(ev_g - ev_a) <= 0.02, f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
+
+
+def _walk_windows(tmp_path, seed, steps_total, window, n_controls):
+    """oracle (own process, reproducible) -> product (this process) -> fp32-MFMA twin (own process); returns the three results"""
+    from util_windows import hip_walk
+    d = str(tmp_path / f"windows_seed{seed}")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "util_windows.py"), "--oracle", "1", "--dir", d, "--out", os.path.join(d, "oracle.json"),
+           "--seed", str(seed), "--steps", str(steps_total), "--window", str(window), "--controls", str(n_controls)]
+    os.makedirs(d, exist_ok=True)
+    r = subprocess.run(cmd, cwd=ROOT, env=oracle_env(), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, f"oracle walk: {r.stderr[-2000:]}"
+    orc = json.load(open(os.path.join(d, "oracle.json")))
+    prod = hip_walk(d, free=True)
+    env = dict(os.environ)
+    env["NVP_HIP_LIB"] = TWIN
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "util_windows.py"), "--dir", d, "--out", os.path.join(d, "twin.json")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, f"twin walk: {r.stderr[-2000:]}"
+    twin = json.load(open(os.path.join(d, "twin.json")))
+    for f in os.listdir(d):
+        if f.endswith(".pt"):
+            os.remove(os.path.join(d, f))
+    return orc, prod, twin
+
+
+def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(tmp_path):
+    """The HIP path against the ORACLE over a whole cosine schedule of 1 000 steps (NVP_PSNR_STEPS_LONG) at the small size, walked in
+    50-step windows (NVP_PSNR_WINDOW) from the oracle's state, WITH THE CONTROLS IN THE RUN (tests/util_windows.py): at every window
+    start the product build, the fp32-MFMA twin build (subprocess) and two 1-ulp copies of the oracle are set to the oracle's
+    parameters, Adam moments and step count; all take the oracle's batches and learning rates; train PSNR (training.py:58) is
+    compared at every window end.  north_star's +-0.02 dB is asserted unconditionally wherever the oracle reproduces itself to
+    0.01 dB (window_verdicts); where it does not, the product must stay with the fp32-MFMA twin and inside twice the envelope.
+    The final full-frame evaluation PSNR (eval.py:243-256) of the synced model is held to +-0.02 dB as well.  A free-running
+    product model is reported and bounded loosely (a real divergence still fails).  A failure names its cause."""
+    import math
+    steps_total = int(os.environ.get("NVP_PSNR_STEPS_LONG", "1000"))
+    window = int(os.environ.get("NVP_PSNR_WINDOW", "50"))
+    seed = int(os.environ.get("NVP_PSNR_SEED", "7"))
+    assert os.path.exists(TWIN), f"{TWIN} missing: run nvp_amd/csrc/build.sh"
+    orc, prod, twin = _walk_windows(tmp_path, seed, steps_total, window, n_controls=2)
+    assert prod["mfma_products"] == 3 and twin["mfma_products"] == 1, (prod["lib"], twin["lib"])
+    pa = orc["psnr"]
+    ends = [min(s + window, steps_total) - 1 for s in range(0, steps_total, window)]
+    gp = [abs(pa[e] - prod["psnr"][e]) for e in ends]
+    gt = [abs(pa[e] - twin["psnr"][e]) for e in ends]
+    env = [max(abs(pa[e] - c[e]) for c in orc["controls"]) for e in ends]
+    gap_free = [abs(a - b) for a, b in zip(pa, prod["free"])]
+    ev_gap, ev_gap_twin = abs(prod["eval"] - orc["eval"]), abs(twin["eval"] - orc["eval"])
+    fmt = lambda xs: "[" + " ".join(f"{x:.4f}" for x in xs) + "]"          # noqa: E731
+    series = f"product={fmt(gp)} twin={fmt(gt)} envelope={fmt(env)}"
+    report("psnr_equal_steps_windows", seed=seed, steps=steps_total, window=window, product=gp, twin=gt, envelope=env, eval_product_gap=ev_gap,
+           eval_twin_gap=ev_gap_twin, free_final_gap=gap_free[-1], free_max_gap=max(gap_free), free_argmax=gap_free.index(max(gap_free)) + 1,
+           final_psnr_oracle=pa[-1], oracle_threads=orc["threads"])
+    bad = window_verdicts(gp, gt, env)
+    _say(f"windows seed={seed} steps={steps_total} window={window} max_product={max(gp):.4f} max_twin={max(gt):.4f} max_envelope={max(env):.4f} "
+         f"hot_windows={sum(e > 0.01 for e in env)} violations={len(bad)} eval_gap={ev_gap:.5f} free_max={max(gap_free):.3f} free_final={gap_free[-1]:.3f} dB | {series}")
+    assert pa[-1] > 10 * math.log10(4 / 0.34) + 6, "training did not make progress"
+    assert not bad, "; ".join(f"window {w} (steps {w * window}-{ends[w] + 1}): {why}" for w, why in bad) + " | " + series
+    assert ev_gap <= 0.02, f"final eval-PSNR gap {ev_gap:.4f} dB (twin: {ev_gap_twin:.4f})"
+    assert max(gap_free) <= 1.0 and gap_free[-1] <= 0.3, (f"free-running HIP trajectory left the oracle's: {max(gap_free):.3f} dB at step "
+                                                         f"{gap_free.index(max(gap_free)) + 1}, {gap_free[-1]:.3f} dB at the end")
+
+
+def test_psnr_at_equal_steps_full_levels():
+    """The same check on the full 16-level keyframes (config_nvp_s values, BASELINE.json configs[0]) over 50 steps, without the
+    1-ulp twin (each CPU step of the checker updates 27.8 M parameters)."""
+    import math
+    from nvp_amd import harness
+    from nvp_amd.modules import NVP
+    T, H, W, n, steps_total, seed = 16, 64, 64, 8192, int(os.environ.get("NVP_PSNR_STEPS_FULL", "50")), 3
+    cfg = small_cfg(F=2, T=T, X=20, Y=20)
+    sd = O.init_state(cfg, seed=seed)
+    model = NVP(out_features=3, encoding_config=cfg)
+    _load_state_into(model, sd)
+    model = model.to(dev())
+    video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=1)
+    flat = video.reshape(T, H * W, 3)
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt_r = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)
+    sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=steps_total, eta_min=1e-5)
+    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)
+    gen = torch.Generator().manual_seed(0)
+    gap = []
+    for it in range(steps_total):
+        ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)
+        gt_u8 = flat[ti, pi].unsqueeze(0)
+        with oracle_determinism():
+            loss_r = O.image_mse(O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg), O.normalise_gt(gt_u8))
+            opt_r.zero_grad(); loss_r.backward(); opt_r.step(); sch_r.step()
+            loss_r = loss_r.detach()
+        mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
+        loss_g = harness.image_mse_u8(model(mi)["model_out"], gt_u8.to(dev()))
+        opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
+        gap.append(abs(10 * math.log10(4 / float(loss_r)) - 10 * math.log10(4 / float(loss_g))))
+    report("psnr_equal_steps_full", steps=steps_total, gap=max(gap), final_gap=gap[-1], final_psnr=10 * math.log10(4 / float(loss_r)))
+    assert 10 * math.log10(4 / float(loss_g)) > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
+    _say(f"50-step 16-level train_gap_max={max(gap):.4f} final_gap={gap[-1]:.4f} dB")
+    assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"
+
+
+
+# ----------------------------------------------------------------------------------------
+# FULL SIZE (configs[1]): the fp16x2 build against the fp32-MFMA twin over a 1 000-step schedule
+# ----------------------------------------------------------------------------------------
+def _run(tag, lib, steps, every, out, ulp=0):
+    env = dict(os.environ)
+    env.pop("NVP_HIP_LIB", None)
+    if lib:
+        env["NVP_HIP_LIB"] = lib
+    if os.path.exists(out):
+        os.remove(out)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "long_horizon.py"), "--steps", str(steps), "--every", str(every),
+           "--video", "natural", "--tag", tag, "--out", out, "--ulp", str(ulp)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, f"{tag}: {r.stderr[-2000:]}"
+    recs = [json.loads(line) for line in open(out) if line.startswith("{")]
+    return {x["step"]: x for x in recs if "step" in x}, [x for x in recs if x.get("summary")][0]
+
+
+def test_fp16x2_split_tracks_the_fp32_mfma_twin_at_full_size(tmp_path):
+    """Long-horizon, FULL-SIZE parity of the split-operand 16-bit MFMA arithmetic (-m gpu).
+
+    The default build issues every fp32 MLP product as three fp16 MFMA products of a scaled hi+lo operand split
+    (nvp_amd/csrc/mlp_b3.h); its twin libnvp_hip_fp32mfma.so (same sources, -DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0, built
+    next to it by nvp_amd/csrc/build.sh) runs the same GEMMs on v_mfma_f32_32x32x2_f32, which is bit-equal to an ordered fmaf
+    chain.  Both are trained here on BASELINE.json configs[1] - config_nvp_s, 1920x1080x600, N = 1 245 184 samples per step, the
+    reference's sampler / loss / AdamW + cosine (dataio.py:104-120, training.py:13-14,47-76) - from the same init on the same
+    batches for NVP_LH_STEPS (default 1000) steps, in one process each (tools/long_horizon.py; the library is chosen at load
+    time), together with the twin started <= 1 fp32 ulp away (the envelope).
+
+    What is asserted.  At the END of the schedule (the cosine has annealed the step size) train PSNR (training.py:58) and
+    full-frame evaluation PSNR (eval.py:243-256) of the two builds agree to the north-star bound of +-0.02 dB, unconditionally.
+    At the intermediate checkpoints the optimiser runs at lr ~ 1e-2 and the instantaneous PSNR of ANY trajectory of this model
+    jitters by ~0.1 dB from step to step (profiles/r03_long_horizon_5000_compare.txt: the fp32-MFMA build against its own 1-ulp
+    twin differs by up to 0.10 dB train / 0.19 dB eval during the first 2000 of 5000 steps, and by <= 0.006 dB from step 2250 on;
+    the fp16x2 build sits inside that envelope: 0.15 / 0.19 early, <= 0.005 dB from step 2250 on) - there the gap must stay within
+    max(0.02 dB, 3 x the envelope measured in the same test), and the numbers are reported."""
+    assert os.path.exists(TWIN), f"{TWIN} missing: run nvp_amd/csrc/build.sh (it builds the fp32-MFMA twin next to libnvp_hip.so)"
+    steps = int(os.environ.get("NVP_LH_STEPS", "1000"))
+    every = int(os.environ.get("NVP_LH_EVERY", "250"))
+    a, sa = _run("f16x2", None, steps, every, str(tmp_path / "a.jsonl"))
+    b, sb = _run("fp32mfma", TWIN, steps, every, str(tmp_path / "b.jsonl"))
+    c, sc = _run("fp32mfma_1ulp", TWIN, steps, every, str(tmp_path / "c.jsonl"), ulp=1)
+    # the processes really ran different arithmetic on the same problem
+    assert sa["mfma_products"] == 3 and sb["mfma_products"] == 1 and sc["mfma_products"] == 1, (sa["mfma_products"], sb["mfma_products"])
+    assert sa["samples"] == sb["samples"] == 1245184 and sa["geometry"] == sb["geometry"] == [600, 1080, 1920]
+    assert sorted(a) == sorted(b) == sorted(c) and max(a) == steps
+    gap = {k: [abs(a[s_][k] - b[s_][k]) for s_ in sorted(a)] for k in ("train_psnr", "eval_psnr")}
+    env = {k: [abs(c[s_][k] - b[s_][k]) for s_ in sorted(a)] for k in ("train_psnr", "eval_psnr")}
+    report("long_horizon", steps=steps, checkpoints=sorted(a), train_gap=gap["train_psnr"], eval_gap=gap["eval_psnr"],
+           train_envelope=env["train_psnr"], eval_envelope=env["eval_psnr"], final_train=a[steps]["train_psnr"], final_eval=a[steps]["eval_psnr"],
+           wall_f16x2=sa["wall_s"], wall_fp32mfma=sb["wall_s"])
+    _say(f"full-size {steps} steps fp16x2-vs-fp32mfma train_gap={gap['train_psnr']} eval_gap={gap['eval_psnr']} envelope_train={env['train_psnr']} envelope_eval={env['eval_psnr']}")
+    assert a[steps]["eval_psnr"] > a[min(a)]["eval_psnr"] and a[steps]["eval_psnr"] > 20.0, "training did not make progress"
+    for k in ("train_psnr", "eval_psnr"):
+        assert gap[k][-1] <= 0.02, f"final {k} gap {gap[k][-1]:.4f} dB between the fp16x2 build and the fp32-MFMA twin after {steps} steps"
+        bound = max(0.02, 3.0 * max(env[k]))
+        assert max(gap[k]) <= bound, (f"{k} gap {max(gap[k]):.4f} dB at an intermediate checkpoint exceeds max(0.02, 3 x the 1-ulp envelope "
+                                      f"{max(env[k]):.4f}) dB; gaps {gap[k]}, envelope {env[k]}")

@@ -376,6 +376,16 @@ def test_compat_optimizer_routing_is_opt_in_and_falls_back_to_the_stock_class():
         assert isinstance(opt, stock) and opt.defaults["weight_decay"] == 0.001 and opt.defaults["lr"] == 1e-2
         opt2 = torch.optim.AdamW(lin.parameters(), lr=1e-3, amsgrad=True)
         assert isinstance(opt2, stock) and opt2.defaults["amsgrad"]
+        # the routed name is still a CLASS derived from the stock one: isinstance / issubclass / subclassing / name lookups keep working
+        assert isinstance(torch.optim.AdamW, type) and issubclass(torch.optim.AdamW, stock) and torch.optim.AdamW.__name__ == "AdamW"
+        assert isinstance(opt, torch.optim.AdamW) and isinstance(opt2, torch.optim.AdamW)
+        opt.zero_grad(); lin(torch.ones(2, 4)).sum().backward(); opt.step()                  # a working optimizer, generator argument and all
+
+        class Mine(torch.optim.AdamW):
+            pass
+        assert isinstance(Mine(lin.parameters(), lr=1e-3), stock)
+        from nvp_amd.optim import AdamW as NvpAdamW
+        assert isinstance(NvpAdamW.__new__(NvpAdamW), torch.optim.AdamW)                     # what a routed call returns passes the same check
     finally:
         compat.uninstall_optimizer()
     assert torch.optim.AdamW is stock

@@ -1,0 +1,35 @@
+"""CPU tests of the trajectory checker itself (tests/util_windows.py): the verdict rule, and that the oracle walk is reproducible
+run to run under the environment the graded test gives it."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+from util_windows import oracle_env, window_verdicts
+
+
+def test_window_rule():
+    calm, hot = 0.004, 0.03
+    assert window_verdicts([0.019], [0.001], [calm]) == []                       # north_star's bound where the oracle reproduces itself
+    bad = window_verdicts([0.021], [0.001], [calm])
+    assert len(bad) == 1 and "fp16x2 split-operand arithmetic is the cause" in bad[0][1]
+    bad = window_verdicts([0.021], [0.025], [calm])
+    assert len(bad) == 1 and "the twin leaves too" in bad[0][1]
+    assert window_verdicts([0.034], [0.03], [hot]) == []                         # hot window: with the twin (+0.005) and inside 2 x envelope
+    assert len(window_verdicts([0.036], [0.03], [hot])) == 1                     # leaves the twin
+    assert len(window_verdicts([0.07], [0.07], [hot])) == 1                      # with the twin but outside 2 x envelope
+    assert [w for w, _ in window_verdicts([0.0, 0.5, 0.0], [0.0] * 3, [0.0, 0.1, 0.0])] == [1]
+
+
+def test_oracle_walk_is_reproducible(tmp_path):
+    outs = []
+    for k in range(2):
+        d = str(tmp_path / f"w{k}")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "util_windows.py"), "--oracle", "1", "--dir", d, "--out", os.path.join(d, "o.json"),
+                            "--seed", "7", "--steps", "4", "--window", "2", "--controls", "1"], cwd=ROOT, env=oracle_env(), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.load(open(os.path.join(d, "o.json"))))
+        assert sorted(f for f in os.listdir(d) if f.startswith("win_")) == ["win_000.pt", "win_001.pt"]
+    assert outs[0]["psnr"] == outs[1]["psnr"] and outs[0]["controls"] == outs[1]["controls"] and outs[0]["eval"] == outs[1]["eval"]
+    assert outs[0]["threads"] == 16 and len(outs[0]["lr"]) == 4

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dump RGB + every gradient of one fixed fwd/bwd of the fused path to an .npz (A/B runs of kernel variants selected by
-environment variables that libnvp_hip.so reads once per process: NVP_MLP_RING_FWD, NVP_MLP_RING_BWD, NVP_ENCODE_LDS).  tools/ab_ring.sh compares
+environment variables that libnvp_hip.so reads once per process: NVP_MLP_RING_FWD, NVP_MLP_RING_BWD, NVP_ENCODE_LDS).  tools/ab_libs.sh compares
 the dumps bit for bit."""
 import os
 import sys
