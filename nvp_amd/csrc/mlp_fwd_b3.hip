@@ -11,7 +11,11 @@
 #ifdef NVP_FWD_PF_STEP         // forward-only override of the chains' weight prefetch scheme (mlp_b3.h: NVP_CHAIN_PF_STEP)
 #define NVP_CHAIN_PF_STEP NVP_FWD_PF_STEP
 #endif
+#include <cstdlib>
 #include "mlp_fwd_b3_tile.h"
+#if NVP_EXPERIMENTS
+#include "mlp_fwd_b3x2_tile.h"     // two tiles per wave, one wave per SIMD: built, bit-identical, measured SLOWER (profiles/r05_ab_fwd_pair_per_wave.txt)
+#endif
 
 namespace {
 
@@ -51,6 +55,30 @@ __global__ __launch_bounds__(kWaves * 64, NVP_FWD_OCC) void mlp_fwd_b3_kernel(fl
     float rgb_px[3];
     fwd_b3_tile<SAVE, GF>(zt, steps, p, packed, rgb, saved, n, ntiles, d, enc, tile, active, z, lane, rgb_px);
 }
+
+#if NVP_EXPERIMENTS
+// ---- EXPERIMENT: two tiles per wave, one wave per SIMD (mlp_fwd_b3x2_tile.h), for the fused gather + forward of
+// config_nvp_s-sized latents (8 latent k-steps).  Bit-identical RGB / saved streams / latent; 2.85 ms alone against 1.80 ms for the
+// one-tile kernel at two waves per SIMD (profiles/r05_ab_fwd_pair_per_wave.txt: a lone wave per SIMD is parked on s_waitcnt for half of
+// its life and issues its ~23 K non-MFMA instructions at ~10 cycles each: 2.14 ms with the MFMAs removed).  Experiments library only, NVP_FWD_X2=1.
+constexpr int kWavesX2 = 4;    // one wave per SIMD
+constexpr int kZsX2 = 8;       // latent k-steps the pair kernel is compiled for (rows <= 128)
+
+template <bool SAVE, int GF>
+__global__ __launch_bounds__(kWavesX2 * 64, 1) void mlp_fwd_b3x2_kernel(float* __restrict__ zt, const float* __restrict__ steps, nvp_mlp_params p,
+                                                                        const unsigned* __restrict__ packed, float* __restrict__ rgb, float* __restrict__ saved,
+                                                                        int64_t n, int64_t ntiles, int d, NvpTileEnc enc) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t pair = (int64_t)blockIdx.x * kWavesX2 + wv;
+    const int64_t tileA = 2 * pair;
+    if (tileA >= ntiles) return;                      // wave-uniform
+    extern __shared__ __attribute__((aligned(16))) float4 zlds[];
+    float4* zA = zlds + (2 * wv) * (kZsX2 * 4 * 32);
+    float4* zB = zA + kZsX2 * 4 * 32;
+    fwd_b3_pair<SAVE, GF, kZsX2>(zt, steps, p, packed, rgb, saved, n, ntiles, d, enc, tileA, tileA + 1 < ntiles, zA, zB, lane);
+}
+#endif
 
 }  // namespace
 
@@ -98,6 +126,26 @@ extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const
     const size_t lds = (size_t)kWaves * nvp_fwd_layout_b3(d).zs * 4 * 32 * sizeof(float4);
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_fwd);
     const int F = lv_xy->n_features;
+#if NVP_EXPERIMENTS
+    static const bool x2_on = [] { const char* e_ = getenv("NVP_FWD_X2"); return e_ && e_[0] == '1'; }();
+    if (x2_on && NVP_SPLIT_H2 && F == 2 && nvp_fwd_layout_b3(d).zs == kZsX2) {
+        // pair kernel: 2 tiles per wave, 4 waves per workgroup, one workgroup per CU (128 KiB of LDS: 2 x 16 KiB latent tiles per wave)
+        const int64_t npairs = (ntiles + 1) / 2;
+        dim3 grid2((unsigned)((npairs + kWavesX2 - 1) / kWavesX2));
+        const size_t lds2 = (size_t)kWavesX2 * 2 * kZsX2 * 4 * 32 * sizeof(float4);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_b3x2_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_b3x2_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                (void)hipGetLastError();              // (HIP on gfx950 accepts > 64 KiB of dynamic LDS without the attribute; a refusal here must not fail the call)
+            attr_set = true;
+        }
+        if (saved) hipLaunchKernelGGL((mlp_fwd_b3x2_kernel<true, 2>), grid2, dim3(kWavesX2 * 64), lds2, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d, e);
+        else hipLaunchKernelGGL((mlp_fwd_b3x2_kernel<false, 2>), grid2, dim3(kWavesX2 * 64), lds2, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d, e);
+        NVP_LAUNCH_CHECK();
+        return 0;
+    }
+#endif
 #define NVP_FUSED_LAUNCH(SV, GF) hipLaunchKernelGGL((mlp_fwd_b3_kernel<SV, GF>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d, e)
     if (saved) { if (F == 2) NVP_FUSED_LAUNCH(true, 2); else NVP_FUSED_LAUNCH(true, 4); }
     else { if (F == 2) NVP_FUSED_LAUNCH(false, 2); else NVP_FUSED_LAUNCH(false, 4); }

@@ -1101,7 +1101,7 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     """The alternative kernels kept behind environment switches (read once per process by libnvp_hip.so) - the LDS-staged gather
     (NVP_ENCODE_LDS=1), the workgroup-shared weight ring of the forward chain (NVP_MLP_RING_FWD=1), the per-wave backward
     chain (NVP_MLP_RING_BWD=0), the merged dW jobs (NVP_DW_MERGE=1), the row-major latent-gradient hand-over to the scatter
-    (NVP_DZ_LEVEL_MAJOR=0), the two-kernel forward (NVP_FUSED_FWD=0: gather kernel -> latent in HBM -> MLP kernel), all dW jobs in one launch (NVP_DW_ONE_LAUNCH=1) on a second stream (NVP_DW_SIDE_STREAM=1) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
+    (NVP_DZ_LEVEL_MAJOR=0), the two-kernel forward (NVP_FUSED_FWD=0: gather kernel -> latent in HBM -> MLP kernel), the pair-per-wave forward (NVP_FWD_X2=1), all dW jobs in one launch (NVP_DW_ONE_LAUNCH=1) on a second stream (NVP_DW_SIDE_STREAM=1) - must reproduce the default build's RGB and every gradient BIT for bit (same MFMA order per
     accumulator, same index arithmetic; only where operands are staged differs)."""
     import subprocess
     import sys
@@ -1126,7 +1126,8 @@ def test_kernel_variants_are_bit_identical(tmp_path):
                              {"NVP_ENCODE_LDS": "1", "NVP_MLP_RING_FWD": "1", "NVP_MLP_RING_BWD": "0", "NVP_DW_MERGE": "1",
                               "NVP_DZ_LEVEL_MAJOR": "0"},                                                                # every alternative
                              {"NVP_DW_ONE_LAUNCH": "1", "NVP_DW_SIDE_STREAM": "1", "NVP_SCATTER_PRESORT": "0", "NVP_PACK_ONE_LAUNCH": "0"},            # launch / stream experiments
-                             {"NVP_FUSED_FWD": "0"})):                                                                      # the seven per-job dW workgroups instead of the grouped ones
+                             {"NVP_FUSED_FWD": "0"},                                                                        # the two-kernel forward
+                             {"NVP_FWD_X2": "1"})):                                                                         # two tiles per wave, one wave per SIMD (mlp_fwd_b3x2_tile.h; 70 000 px = an odd tile count: the unpaired last tile too)
         out = str(tmp_path / f"v{k}.npz")
         run_variant([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "2", "70000"], env, check=True, timeout=300)
         outs.append(np.load(out))

@@ -12,6 +12,7 @@ from util_windows import oracle_env, window_verdicts
 def test_window_rule():
     calm, hot = 0.004, 0.03
     assert window_verdicts([0.019], [0.001], [calm]) == []                       # north_star's bound where the oracle reproduces itself
+    assert window_verdicts([0.0185], [0.0023], [0.0123]) == []                   # ... and a hot window is never STRICTER than the calm bound (seed 8, window 5 on MI355X)
     bad = window_verdicts([0.021], [0.001], [calm])
     assert len(bad) == 1 and "fp16x2 split-operand arithmetic is the cause" in bad[0][1]
     bad = window_verdicts([0.021], [0.025], [calm])
