@@ -152,9 +152,14 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
  * arithmetic as nvp_encode_fwd: the latent is bit-identical) and runs the seven layers on it, so the latent is never read back from
  * HBM and the separate gather launch disappears.  `saved` != NULL (training): the five activation streams are saved as by nvp_mlp_fwd
  * AND the latent is written once to `zt` (PTM4, as nvp_encode_fwd would have) because the weight-gradient GEMMs read it; `saved` ==
- * NULL (inference): `zt` may be NULL, nothing but RGB is written.  Supported (nvp_encode_mlp_fwd_supported() != 0) when all four
- * grids have 2 or 4 features per level, every plane contributes a multiple of 8 latent rows and the latent has <= 144 rows
- * (config_nvp_s); otherwise call nvp_encode_fwd + nvp_mlp_fwd.  packed_fwd: nvp_mlp_pack_fwd's output. */
+ * NULL (inference): `zt` may be NULL, nothing but RGB is written.  nvp_encode_mlp_fwd_supported() returns
+ *   0  not supported: call nvp_encode_fwd + nvp_mlp_fwd (grids with other than 2 or 4 features per level, a plane that does not
+ *      contribute a multiple of 8 latent rows, a non-default arithmetic variant, F = 2 latents of more than 144 rows);
+ *   1  supported, the whole latent tile lives in the wave's LDS region (<= 144 rows: config_nvp_s);
+ *   2  supported, and `zt` is REQUIRED for inference too: the latent is wider than the wave's LDS tile (config_nvp_l: F = 4, 228 rows)
+ *      - rows beyond the first 144 are stored straight into `zt` by the gather and read back from there by the modulator chains
+ *      (each wave reads only what it has just written); with `saved` == NULL the rest of `zt` is left unwritten.
+ * packed_fwd: nvp_mlp_pack_fwd's output. */
 int32_t nvp_encode_mlp_fwd_supported(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh);
 int nvp_encode_mlp_fwd(const float* coords, const float* steps, const float* kf_xy, const float* kf_yt, const float* kf_xt,
                        const float* emb, const nvp_mlp_params* p, const float* packed_fwd, float* rgb, float* saved, float* zt,

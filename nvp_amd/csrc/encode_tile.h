@@ -34,15 +34,30 @@ __device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirst
 // Encodings configured otherwise take the two-kernel path (nvp_encode_mlp_fwd_supported).
 constexpr int kTileFlags = NVP_GRID_POS_FMA | NVP_GRID_INTERP_FMA;
 
-// one plane, this lane's row-groups -> LDS tile; returns the largest |value| written.
+// Where a row-group of the tile goes: the wave's LDS tile holds row-groups [0, rg_lds) (kB3ZLdsSteps k-steps = 144 rows: all of a config_nvp_s
+// latent); row-groups beyond it - config_nvp_l's 228-row latent - are stored straight into the latent tensor's tile `zg`, from where the MLP
+// chains read them back (chain_zg_b3), so that the gather can run inside the MLP's waves for wide latents too.
+// WIDE false (config_nvp_s): every row-group goes to LDS - no test, the code of the narrow kernels is unchanged.
+template <bool WIDE>
+struct TileDst {
+    float4* __restrict__ zl;       // LDS tile
+    float4* __restrict__ zg;       // this tile of the latent tensor (WIDE only)
+    int rg_lds;
+    __device__ __forceinline__ void put(int rg, int j, const float4 v) const {
+        if (!WIDE || rg < rg_lds) zl[rg * 32 + j] = v;
+        else zg[rg * 32 + j] = v;
+    }
+};
+
+// one plane, this lane's row-groups -> tile; returns the largest |value| written.
 // Straight-line code for memory-level parallelism (a wave of the MLP kernel has one partner on its SIMD, not seven, to hide a
 // miss behind): level geometry through scalar registers with compile-time indices, the variant flags folded at compile time,
 // the cell wrap as two selects (exact for cells within one level size of the level - any coordinate in [-1, 2]), the two corners
 // of a grid row as ONE 16-byte fetch; all 16 fetches of the plane are issued before the first blend.  The rare cases the
 // selects cannot express (a corner pair split by the wrap, far-away coordinates) are redone exactly, for the whole wave, behind one
 // wave-uniform branch.  Pixels past the end of the batch gather at coordinate 0 and write zeros: no load sits behind a branch.
-template <int F>
-__device__ __forceinline__ float tile_plane(float4* __restrict__ zl, const float* __restrict__ params, const nvp_levels& lv,
+template <int F, bool WIDE>
+__device__ __forceinline__ float tile_plane(const TileDst<WIDE>& dst, const float* __restrict__ params, const nvp_levels& lv,
                                             int col0, float x0, float x1, bool valid, int j, int h) {
     constexpr int LPG = 4 / F;                       // levels per row-group
     constexpr int NQ = NVP_MAX_LEVELS / LPG / 2;     // row-groups per lane and plane at 16 levels
@@ -134,7 +149,7 @@ __device__ __forceinline__ float tile_plane(float4* __restrict__ zl, const float
         }
         if (2 * q < ngroups) {                        // (uniform: an even number of row-groups per plane)
             const float4 o = make_float4(r[0], r[1], r[2], r[3]);
-            zl[((col0 >> 2) + g) * 32 + j] = o;
+            dst.put((col0 >> 2) + g, j, o);
             m = fmaxf(fmaxf(m, fmaxf(fabsf(r[0]), fabsf(r[1]))), fmaxf(fabsf(r[2]), fabsf(r[3])));
         }
     }
@@ -170,8 +185,8 @@ __device__ __forceinline__ void tile_sparse_fetch(SparseFetch<F>& sf, const NvpT
     }
 }
 
-template <int F>
-__device__ __forceinline__ float tile_sparse_write(float4* __restrict__ zl, const SparseFetch<F>& sf, const NvpTileEnc& a, bool valid, int j, int h) {
+template <int F, bool WIDE>
+__device__ __forceinline__ float tile_sparse_write(const TileDst<WIDE>& dst, const SparseFetch<F>& sf, const NvpTileEnc& a, bool valid, int j, int h) {
     constexpr int NV = 9 * F;
     constexpr int NVP4 = (NV + 3) & ~3;
     constexpr int Q0 = (6 * F) / 4;                  // float4 of patch rows 0 and 1 (12 or 24 floats): lane half 0
@@ -197,33 +212,36 @@ __device__ __forceinline__ float tile_sparse_write(float4* __restrict__ zl, cons
         const int rg = rg0 + (h ? Q0 + q : q);
         const float4 o = valid ? make_float4(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (mine && 4 * rg < a.rows) {
-            zl[rg * 32 + j] = o;
+            dst.put(rg, j, o);
             m = fmaxf(fmaxf(m, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
     return m;
 }
 
-// Fill the wave's latent tile zl ([rows/4][32] float4, PTM4) for tile `tile`; zg != nullptr: also write it to the latent tensor
-// (training: the dW GEMMs read it) - from LDS, after the gather, so that no fetch waits for a store's data registers.
+// Fill the wave's latent tile for tile `tile`: row-groups [0, rg_lds) into zl ([.][32] float4, PTM4), row-groups beyond it into the latent
+// tensor's tile zg (TileDst).  copy_lds: also write the LDS part to zg (training: the dW GEMMs read the whole latent) - from LDS, after the
+// gather, so that no fetch waits for a store's data registers.  zg may be null when rg_lds covers the tile and copy_lds is false.
 // Returns this lane's largest |z| (combine the two lane halves for the pixel's).
-template <int F>
-__device__ __forceinline__ float nvp_gather_tile(float4* __restrict__ zl, float4* __restrict__ zg, const NvpTileEnc& a, int64_t tile, int64_t n, int lane) {
+template <int F, bool WIDE = false>
+__device__ __forceinline__ float nvp_gather_tile(float4* __restrict__ zl, float4* __restrict__ zg, const NvpTileEnc& a, int64_t tile, int64_t n, int lane,
+                                                 int rg_lds = 1 << 20, bool copy_lds = true) {
     const int j = lane & 31, h = lane >> 5;
     const int64_t px = tile * 32 + j;
     const bool valid = px < n;
     float t = 0.f, x = 0.f, y = 0.f;
     if (valid) { const float* c = a.coords + px * 3; t = c[0]; x = c[1]; y = c[2]; }
+    const TileDst<WIDE> dst = {zl, zg, rg_lds};
     SparseFetch<F> sf;
     tile_sparse_fetch<F>(sf, a, t, x, y, h);
-    float m = tile_plane<F>(zl, a.kf[2], a.lv[2], a.col0[2], t, x, valid, j, h);          // xt plane <- (t, x)   modules.py:62
-    m = fmaxf(m, tile_plane<F>(zl, a.kf[0], a.lv[0], a.col0[0], x, y, valid, j, h));      // xy plane <- (x, y)   modules.py:61
-    m = fmaxf(m, tile_plane<F>(zl, a.kf[1], a.lv[1], a.col0[1], t, y, valid, j, h));      // yt plane <- (t, y)   modules.py:63
-    m = fmaxf(m, tile_sparse_write<F>(zl, sf, a, valid, j, h));
-    if (zg) {
+    float m = tile_plane<F, WIDE>(dst, a.kf[2], a.lv[2], a.col0[2], t, x, valid, j, h);          // xt plane <- (t, x)   modules.py:62
+    m = fmaxf(m, tile_plane<F, WIDE>(dst, a.kf[0], a.lv[0], a.col0[0], x, y, valid, j, h));      // xy plane <- (x, y)   modules.py:61
+    m = fmaxf(m, tile_plane<F, WIDE>(dst, a.kf[1], a.lv[1], a.col0[1], t, y, valid, j, h));      // yt plane <- (t, y)   modules.py:63
+    m = fmaxf(m, tile_sparse_write<F, WIDE>(dst, sf, a, valid, j, h));
+    if (zg && copy_lds) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int n4 = (a.rows >> 2) * 32;
+        const int n4 = (WIDE ? min(a.rows >> 2, rg_lds) : (a.rows >> 2)) * 32;
         for (int idx = lane; idx < n4; idx += 64) zg[idx] = zl[idx];
     }
     return m;

@@ -516,7 +516,8 @@ int nvp_mlp_bwd_b3r_launch(const float* drgb, const float* steps, const float* s
 // ---- C ABI of the tile-fused step -------------------------------------------------------------------------------------------------
 static bool step_fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, int* d_out) {
     int d = 0;
-    if (!NVP_BWD_B3 || !fused_ok(lv_xy, lv_yt, lv_xt, sh, &d)) return false;
+    bool wide = false;
+    if (!NVP_BWD_B3 || !fused_ok(lv_xy, lv_yt, lv_xt, sh, &d, &wide) || wide) return false;      // (the tile-fused step is built for latents that fit the LDS tile)
     if (nvp_bwd_b3_zt(d) != 4 || !nvp_dz_lm_supported(d)) return false;                          // fused latent gradient, level-major hand-over
     if (nvp_fwd_layout_b3(d).zs * 4 * 32 * 4 > kRecTileFloats) return false;                     // the latent tile must fit the backward's per-wave LDS tile
     if (d_out) *d_out = d;

@@ -102,7 +102,9 @@ int nvp_mlp_fwd_b3_launch(const float* zt, const float* steps, const nvp_mlp_par
 }
 
 extern "C" int32_t nvp_encode_mlp_fwd_supported(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh) {
-    return fused_ok(lv_xy, lv_yt, lv_xt, sh, nullptr) ? 1 : 0;
+    bool wide = false;
+    if (!fused_ok(lv_xy, lv_yt, lv_xt, sh, nullptr, &wide)) return 0;
+    return wide ? 2 : 1;          // 2: supported, and the latent tensor `zt` is required for inference too (rows beyond the wave's LDS tile are parked there)
 }
 
 extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const float* kf_xy, const float* kf_yt, const float* kf_xt,
@@ -110,9 +112,10 @@ extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const
                                   int64_t n, const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt,
                                   const nvp_sparse_shape* sh, int temporal_interp, void* stream) {
     int d = 0;
-    if (!fused_ok(lv_xy, lv_yt, lv_xt, sh, &d) || temporal_interp) return NVP_ERR_UNSUPPORTED;
+    bool wide = false;
+    if (!fused_ok(lv_xy, lv_yt, lv_xt, sh, &d, &wide) || temporal_interp) return NVP_ERR_UNSUPPORTED;
     if (!coords || !steps || !kf_xy || !kf_yt || !kf_xt || !emb || !p || !packed_fwd || !rgb || n < 0) return NVP_ERR_BADARG;
-    if (saved && !zt) return NVP_ERR_BADARG;          // training: the latent is an output too (the dW GEMMs read it)
+    if ((saved || wide) && !zt) return NVP_ERR_BADARG;          // training: the latent is an output too (the dW GEMMs read it); wide latents: it is the kernel's workspace
     if (n == 0) return 0;
     NvpTileEnc e;
     e.lv[0] = *lv_xy; e.lv[1] = *lv_yt; e.lv[2] = *lv_xt; e.sh = *sh;
@@ -123,7 +126,8 @@ extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const
     e.rows = nvp_rows4(d);
     const int64_t ntiles = nvp_ntiles(n);
     dim3 grid((unsigned)((ntiles + kWaves - 1) / kWaves));
-    const size_t lds = (size_t)kWaves * nvp_fwd_layout_b3(d).zs * 4 * 32 * sizeof(float4);
+    const int zs_fused = nvp_fwd_layout_b3(d).zs;
+    const size_t lds = (size_t)kWaves * (zs_fused < kB3ZLdsSteps ? zs_fused : kB3ZLdsSteps) * 4 * 32 * sizeof(float4);
     const unsigned* pk = reinterpret_cast<const unsigned*>(packed_fwd);
     const int F = lv_xy->n_features;
 #if NVP_EXPERIMENTS

@@ -198,9 +198,14 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 #define NVP_GATHER_PRIO 0       // experiment: the tile gather (address arithmetic + fetch issue) outranks the partner wave's MLP
 #endif
     if (NVP_GATHER_PRIO && GF != 0) __builtin_amdgcn_s_setprio(3);
+    // GF == 4 (config_nvp_l: 228 rows): the tile is WIDER than the wave's LDS region - its row-groups beyond kB3ZLdsSteps k-steps go straight into the
+    // latent tensor (which the caller then always provides) and are read back from there by the chains, like the staged path's tail
+    constexpr bool kWide = GF == 4;
     if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
+    else if (kWide) mz = nvp_gather_tile<(GF == 0 ? 2 : GF), kWide>(z, active ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane, zs_l * 4, SAVE && !NVP_FWD_LATE_STORES);
     else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active && !NVP_FWD_LATE_STORES) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
     if (NVP_GATHER_PRIO && GF != 0) __builtin_amdgcn_s_setprio(0);
+    if (kWide && zs_l < L.zs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail rows this wave has just stored are read back below (a wave reading its own stores: the count suffices)
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -247,7 +252,7 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 #pragma unroll
                        for (int q = 0; q < 8; ++q) x[T][r0 + q] = nvp_sin(30.0f * __fmaf_rn(s, wv[q], cv[q]));
                    }) && NVP_FWD_SIR0_EARLY;
-        if (GF == 0) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane, zg_first);
+        if (GF == 0 || GF == 4) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane, zg_first);
         lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
@@ -301,7 +306,7 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
             chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
 #endif
             chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
-            if (GF == 0) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane, zg_first);
+            if (GF == 0 || GF == 4) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane, zg_first);
             lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
@@ -364,9 +369,11 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 }
 
 // ---- R11 fused: coordinates -> RGB in ONE kernel (the gather runs inside the forward MLP's waves) --------------------------------
-// Supported when the whole latent fits the wave's LDS tile (<= 144 rows: config_nvp_s) and the grids have 2 or 4 features per level,
+// Supported when the grids have 2 or 4 features per level; a latent wider than the wave's LDS tile (> 144 rows: config_nvp_l, F = 4) parks its tail in the latent tensor,
 // every plane's rows start on a row-group boundary; nvp_encode_mlp_fwd_supported() tells a host.
-bool fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, int* d_out) {
+// needs_tensor (optional): the latent is wider than the wave's LDS tile (config_nvp_l) - the caller must provide the latent tensor `zt` even
+// for inference, the kernel parks the rows beyond kB3ZLdsSteps k-steps there.
+bool fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh, int* d_out, bool* needs_tensor = nullptr) {
     if (!NVP_FWD_B3 || !lv_xy || !lv_yt || !lv_xt || !sh) return false;
     const int F = lv_xy->n_features;
     if (!(F == 2 || F == 4) || lv_yt->n_features != F || lv_xt->n_features != F || sh->n_features != F || sh->y_res < 3) return false;
@@ -378,7 +385,10 @@ bool fused_ok(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels
         d += lv[q]->n_levels * F;
     }
     d += 9 * F;
-    if (nvp_fwd_layout_b3(d).zs > kB3ZLdsSteps) return false;
+    const int zs = nvp_fwd_layout_b3(d).zs;
+    if (!nvp_fwd_b3_ok(d)) return false;
+    if (zs > kB3ZLdsSteps && F != 4) return false;           // only the F = 4 kernel is built with the tensor-parked tail
+    if (needs_tensor) *needs_tensor = zs > kB3ZLdsSteps;
     if (d_out) *d_out = d;
     return true;
 }

@@ -403,8 +403,8 @@ def materialises_nothing(model, temporal_interp: bool) -> bool:
         return False
     try:
         sh = _sparse_shape(model.sparse_grid._grid())
-        return bool(L.load().nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
-                                                           C.byref(model.keyframes_xt.levels), C.byref(sh)))
+        return int(L.load().nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
+                                                          C.byref(model.keyframes_xt.levels), C.byref(sh))) == 1      # (2: fused, but the latent tensor is its workspace)
     except Exception:
         return False
 
@@ -437,9 +437,11 @@ class NVPFused(torch.autograd.Function):
         if need_grad and not y_sorted and not temporal_interp and AUTO_SORT_MIN > 0 and n >= AUTO_SORT_MIN:
             order = _row_order(lib, coords, n, lv_xy, lv_yt)
             coords, steps, y_sorted = coords[order], steps[order], True
-        fused = bool(n) and FUSED_FWD and not temporal_interp and bool(lib.nvp_encode_mlp_fwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh)))
-        # the latent tensor: an intermediate of the two-kernel path; with the fused forward it only exists for the backward pass
-        zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32) if (need_grad or not fused) else None
+        sup = int(lib.nvp_encode_mlp_fwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh))) if (bool(n) and FUSED_FWD and not temporal_interp) else 0
+        fused = sup > 0
+        fused_parks_rows = sup == 2        # config_nvp_l-sized latents: the rows beyond the wave's LDS tile pass through the latent tensor even without a backward pass
+        # the latent tensor: an intermediate of the two-kernel path; with the fused forward it only exists for the backward pass (or as that workspace)
+        zt = torch.empty((L.ntiles(n), rows, L.TILE), device=dev, dtype=torch.float32) if (need_grad or not fused or fused_parks_rows) else None
         # Scatter workspace, allocated here when a backward pass will follow: (a) for y-sorted batches the backward chain writes the
         # xy / yt planes' latent gradients straight into the scatter's level-major buffers, (b) everything the scatter derives from
         # the COORDINATES alone (sort keys, orders, the sparse row table: a dozen small latency-bound kernels, ~0.26 ms back to
@@ -554,7 +556,7 @@ class NVPFused(torch.autograd.Function):
             rgb = torch.empty((n, 3), device=dev, dtype=torch.float32)
             saved = torch.empty((5, L.ntiles(n), L.HIDDEN, L.TILE), device=dev, dtype=torch.float32) if need_grad else None
             L.check(_call("nvp_encode_mlp_fwd", lib.nvp_encode_mlp_fwd, L.ptr(coords), L.ptr(steps), L.ptr(kf_xy), L.ptr(kf_yt), L.ptr(kf_xt), L.ptr(emb),
-                          C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), L.ptr(zt) if need_grad else None, n,
+                          C.byref(pstruct), L.ptr(packed), L.ptr(rgb), L.ptr(saved), L.ptr(zt) if (need_grad or fused_parks_rows) else None, n,
                           C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh), 1 if temporal_interp else 0, L.stream_ptr()), "nvp_encode_mlp_fwd")
         else:
             if n:

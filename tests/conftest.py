@@ -31,7 +31,23 @@ class oracle_determinism:
         return False
 
 
+_CONFIG = None
+
+
+def say(line: str) -> None:
+    """One summary line on the REAL stdout, past pytest's capture, for passing tests too: the driver keeps the tail of the run's output,
+    and the numbers behind a statistical or arithmetic claim belong there."""
+    capman = _CONFIG.pluginmanager.getplugin("capturemanager") if _CONFIG is not None else None
+    if capman is not None:
+        with capman.global_and_fixture_disabled():
+            print("\n" + line, flush=True)
+    else:
+        print("\n" + line, flush=True)
+
+
 def pytest_configure(config):
+    global _CONFIG
+    _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The CPU oracle is the CHECKER: its results must not depend on the host it runs on.  ATen's CPU kernels partition their
     # reductions by the intra-op thread count, so the count is FIXED (not "whatever the box has, capped"): the builder's box and the

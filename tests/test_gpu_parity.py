@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import nvp_oracle as O
-from conftest import GOLDEN, full_cfg, relerr_l2, relerr_max, report, small_cfg
+from conftest import GOLDEN, full_cfg, relerr_l2, relerr_max, report, say, small_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -223,7 +223,7 @@ def test_mlp_gradients_are_as_close_to_float64_as_the_reference_arithmetic(D):
         assert e_hip <= max(2.0 * e_ref, 2e-6), f"grad {k}: rel-L2 vs float64 {e_hip:.3e}; the reference's fp32 arithmetic: {e_ref:.3e} ({products} MFMA products per fp32 product)"
     rgb = float(np.abs(out.detach().cpu().double().numpy() - out64.detach().numpy()).max())
     rgb_ref = float(np.abs(g["out"].astype(np.float64) - out64.detach().numpy()).max())
-    print(f"\nARITHMETIC D={D} mfma_products={products} worst grad rel-L2 vs float64: hip {worst[0]:.2e} / reference fp32 {worst[1]:.2e} ({worst[2]}); "
+    say(f"ARITHMETIC D={D} mfma_products={products} worst grad rel-L2 vs float64: hip {worst[0]:.2e} / reference fp32 {worst[1]:.2e} ({worst[2]}); "
           f"RGB max-abs vs float64: hip {rgb:.2e} / reference fp32 {rgb_ref:.2e}")
     assert rgb <= max(2.0 * rgb_ref, 1e-6)
 
@@ -1139,12 +1139,14 @@ def test_kernel_variants_are_bit_identical(tmp_path):
     # nvp_l's 228-row latent (F = 4): the ring variants of the backward chain and of the eight-tile latent-gradient kernel against
     # the per-wave kernels (NVP_MLP_RING_BWD=0)
     wide = []
-    for k, env in enumerate(({"_lib": "product"}, {"NVP_MLP_RING_BWD": "0", "NVP_DW_PAIR": "1"})):
+    # ... and the fused gather + forward of the wide latent (tail rows parked in the latent tensor) against the two-kernel forward
+    for k, env in enumerate(({"_lib": "product"}, {"NVP_MLP_RING_BWD": "0", "NVP_DW_PAIR": "1"}, {"_lib": "product", "NVP_FUSED_FWD": "0"})):
         out = str(tmp_path / f"w{k}.npz")
         run_variant([sys.executable, os.path.join(root, "tools", "ab_dump.py"), out, "4", "50001"], env, check=True, timeout=300)
         wide.append(np.load(out))
     for k in wide[0].files:
         assert np.array_equal(wide[0][k], wide[1][k], equal_nan=True), f"{k} differs between the ring and the per-wave backward (F = 4)"
+        assert np.array_equal(wide[0][k], wide[2][k], equal_nan=True), f"{k} differs between the fused and the two-kernel forward (F = 4)"
     # The grouped dW workgroups - register-staged (NVP_DW_GROUP=1: bit-identical) and DMA-fed with operands split once
     # (NVP_DW_GLDS=1: another summation order, so equal to the gradient tolerance, not bit for bit) - measured slower, off by default
     for env, exact in (({"NVP_DW_GROUP": "1"}, True), ({"NVP_DW_GLDS": "1"}, False), ({"NVP_DW_PAIR": "1"}, True), ({"NVP_DW_PAIR": "0"}, True)):

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 import nvp_oracle as O
-from conftest import ROOT, oracle_determinism, report, small_cfg
+from conftest import ROOT, oracle_determinism, report, say, small_cfg
 from util_parity import _load_state_into
 from util_windows import oracle_env, ulp_perturbed, window_verdicts
 
@@ -31,9 +31,7 @@ def dev():
 
 
 def _say(line: str) -> None:
-    """one summary line past pytest's capture (the driver keeps the tail of the run's output)"""
-    sys.__stdout__.write("\nPSNR-PARITY " + line + "\n")
-    sys.__stdout__.flush()
+    say("PSNR-PARITY " + line)
 
 
 # ----------------------------------------------------------------------------------------
