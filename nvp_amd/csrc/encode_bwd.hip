@@ -540,11 +540,20 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
     float g_nx[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) g_nx[f] = 0.f;
+    // Visits of the EXTRA range (row r0 - 2: only a pixel whose dim-0 corner wraps reaches this band from there - decided on the coordinates
+    // alone) request the coordinates only; the latent gradient of the rare pixel that passes the test is fetched on demand
+    // (NVP_BAND_EXTRA_LEAN=0: the gradient is requested for every visit).  One-row bands (the finest levels) make three visits per pixel
+    // and level, one of them extra: 8 instead of 8 + 4 F bytes for that third.
+#ifndef NVP_BAND_EXTRA_LEAN
+#define NVP_BAND_EXTRA_LEAN 1
+#endif
     if (NVP_BAND_PREFETCH && kb + (int)threadIdx.x < ke) {
         const int p = visit_index(kb + threadIdx.x);
         c_nx = cs[p];
+        if (!NVP_BAND_EXTRA_LEAN || kb + (int)threadIdx.x >= lenX) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)p * F + f];
+            for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)p * F + f];
+        }
     }
 #ifndef NVP_BAND_PRIO
 #define NVP_BAND_PRIO 0          // experiment: wave priority of the visit loop (1) or of the flush (2) against the other workgroups of the CU
@@ -562,8 +571,10 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
             if (kk + kBandThreads < ke) {
                 const int pn = visit_index(kk + kBandThreads);
                 c_nx = cs[pn];
+                if (!NVP_BAND_EXTRA_LEAN || kk + kBandThreads >= lenX) {
 #pragma unroll
-                for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)pn * F + f];
+                    for (int f = 0; f < F; ++f) g_nx[f] = dz[(int64_t)pn * F + f];
+                }
             }
         } else {
             c = cs[p];
@@ -574,7 +585,7 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
         if (extra && ((lflags & NVP_GRID_CLAMP) || i0 + 1 < res)) continue;      // row r0-2 only reaches row r0 through the wrap
         bool any = false;
 #pragma unroll
-        for (int f = 0; f < F; ++f) { if (!NVP_BAND_PREFETCH) g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
+        for (int f = 0; f < F; ++f) { if (!NVP_BAND_PREFETCH || (NVP_BAND_EXTRA_LEAN && extra)) g[f] = dz[(int64_t)p * F + f]; any |= (g[f] != 0.f); }
         // cells first: a visit that touches no row of this band ends here, before any weight or conversion is computed
         int off[4];
         bool hit = false;

@@ -286,7 +286,14 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
         }
     }
     // ---- layers 1 and 2
+#ifndef NVP_FWD_ROLL_LAYERS
+#define NVP_FWD_ROLL_LAYERS 0    // experiment: 1 keeps the two iterations as ONE loop body (about two thirds of the code; the 64-KB instruction cache is shared by the CU's eight waves)
+#endif
+#if NVP_FWD_ROLL_LAYERS
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int k = 1; k <= 2; ++k) {
         {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
             const u32x4* w = wp + NVP_WSTRIDE(L.off[k] / 4);

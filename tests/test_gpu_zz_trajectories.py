@@ -161,10 +161,19 @@ def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(tmp_path):
     50-step windows (NVP_PSNR_WINDOW) from the oracle's state, WITH THE CONTROLS IN THE RUN (tests/util_windows.py): at every window
     start the product build, the fp32-MFMA twin build (subprocess) and two 1-ulp copies of the oracle are set to the oracle's
     parameters, Adam moments and step count; all take the oracle's batches and learning rates; train PSNR (training.py:58) is
-    compared at every window end.  north_star's +-0.02 dB is asserted unconditionally wherever the oracle reproduces itself to
-    0.01 dB (window_verdicts); where it does not, the product must stay with the fp32-MFMA twin and inside twice the envelope.
-    The final full-frame evaluation PSNR (eval.py:243-256) of the synced model is held to +-0.02 dB as well.  A free-running
-    product model is reported and bounded loosely (a real divergence still fails).  A failure names its cause."""
+    compared at every window end.
+
+    Asserted (util_windows.window_verdicts): north_star's +-0.02 dB at every window end; a window end beyond it is a violation when
+    the oracle reproduces ITSELF to 0.01 dB in that window (the two 1-ulp controls), and otherwise only tolerated when the product
+    stays with the fp32-MFMA twin (+0.005 dB) and inside twice the controls' envelope.  The final full-frame evaluation PSNR
+    (eval.py:243-256) of the synced model is held to +-0.02 dB.  A free-running product model is reported and bounded loosely (a
+    real divergence still fails).  A failure names its cause (fp16x2 split vs HIP-vs-ATen summation order vs chaos beyond the
+    controls) and carries all three series; a pass prints them too (PSNR-PARITY line).
+
+    Reproducibility: the oracle walks in a process of its own (fixed thread count, deterministic algorithms, MKL_CBWR); measured on
+    MI355X hosts its trajectory is bit-identical box to box, and the HIP side is bit-reproducible by construction - so this test's
+    outcome for a given seed is the same on every box (profiles/r05_psnr_windows_seeds_boxes.txt: seeds 7, 8, 9 on several boxes).
+    NVP_PSNR_SEED selects the seed (default 7)."""
     import math
     steps_total = int(os.environ.get("NVP_PSNR_STEPS_LONG", "1000"))
     window = int(os.environ.get("NVP_PSNR_WINDOW", "50"))
