@@ -790,7 +790,7 @@ def main():
                             "traffic_gbs": round(traffic[k] / (ms * 1e-3) / 1e9, 1) if traffic.get(k) else None})
                 if IDEAL_PX.get(k):
                     out["ideal_bytes_frac"] = round(IDEAL_PX[k] * N_PX / (ms * 1e-3) / PEAK_HBM, 4)
-                    if traffic.get(k):
+                    if traffic.get(k) and IDEAL_PX[k] >= 0.05 * BYTES_PX[k]:      # (a stage whose fused ideal is ~0 - the backward chain: 12 B/px - has no meaningful ratio; the step-level one carries it)
                         out["pmc_over_ideal"] = round(traffic[k] / (IDEAL_PX[k] * N_PX), 2)
             if k in FLOP_PX:
                 a = FLOP_PX[k] * N_PX / (ms * 1e-3)
@@ -857,7 +857,10 @@ def main():
                               "step_ideal_bytes_frac": round(value * 1e6 / world * IDEAL_PX["step"] / PEAK_HBM, 4),
                               "pmc_bytes_per_step": (sum(traffic[k] for k in kms if traffic.get(k)) or None),
                               "pmc_over_ideal": (round(sum(traffic[k] for k in kms if traffic.get(k)) / (IDEAL_PX["step"] * N_PX), 2)
-                                                 if any(traffic.get(k) for k in kms) else None)},
+                                                 if any(traffic.get(k) for k in kms) else None),
+                              # ... without the optimizer's (p, m, v) traffic that the scatter's flushes carry on one GPU (8(d)'s ideal has no optimizer in it)
+                              "pmc_over_ideal_excl_optimizer": (round((sum(traffic[k] for k in kms if traffic.get(k)) - fused_sparse_bytes_per_px * N_PX) / (IDEAL_PX["step"] * N_PX), 2)
+                                                                if any(traffic.get(k) for k in kms) else None)},
             "kernels_ms": kms,
             "stages": stages,
             "fwd_bwd_mpx_s": round(N_PX / (hot_ms * 1e-3) / 1e6, 3) if hot_ms else None,
