@@ -135,6 +135,12 @@ int nvp_sparse3x3_bwd(const float* coords, const float* dout, float* demb, int64
                       const nvp_sparse_shape* sh, void* stream);
 int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, int64_t n,
                             const nvp_sparse_shape* sh, void* stream);
+/* SparseGrid(upsample=True) (reference sparsegrid.py:26-34): the x2 bilinear pre-upsample of the (x, y) axes of the WHOLE grid that the
+ * reference runs on every call as permute -> F.interpolate(scale_factor=2, mode='bilinear') -> permute.  emb [T,X,Y,F] (sh) -> out
+ * [T,2X,2Y,F], one pass, no permutes, ATen's formula (align_corners=False); the gather / scatter above then run on `out` with the
+ * doubled resolutions.  _bwd is its adjoint as a deterministic gather: dout [T,2X,2Y,F] -> demb [T,X,Y,F] (every element written). */
+int nvp_sparse_upsample2x_fwd(const float* emb, float* out, const nvp_sparse_shape* sh, void* stream);
+int nvp_sparse_upsample2x_bwd(const float* dout, float* demb, const nvp_sparse_shape* sh, void* stream);
 
 /* ---- R11 (encoding half of NVP.forward, modules.py:57-78), fused ------------------
  * coords [N,3] -> PTM4 latent zt [ntiles][rows/4][32][4], rows = nvp_latent_rows(D),

@@ -73,6 +73,8 @@ SIGNATURES = {
     "nvp_sparse3x3_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
     "nvp_sparse3x3_bwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
     "nvp_sparse3x3_inter_fwd": [_p, _p, _p, _i64, C.POINTER(SparseShape), _vp],
+    "nvp_sparse_upsample2x_fwd": [_p, _p, C.POINTER(SparseShape), _vp],
+    "nvp_sparse_upsample2x_bwd": [_p, _p, C.POINTER(SparseShape), _vp],
     "nvp_encode_fwd": [_p, _p, _p, _p, _p, _p, _i64, C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels),
                        C.POINTER(SparseShape), C.c_int, _i32, _vp],
     "nvp_encode_mlp_fwd_supported": [C.POINTER(Levels), C.POINTER(Levels), C.POINTER(Levels), C.POINTER(SparseShape)],

@@ -372,6 +372,75 @@ int make_args(EncodeArgs& a, const nvp_levels* lv_xy, const nvp_levels* lv_yt, c
 int nvp_encode_fwd_lds_launch(const float* coords, const float* kf_xy, const float* kf_yt, float* zt, int64_t n, int64_t npad,
                               const nvp_levels* lv_xy, const nvp_levels* lv_yt, int col0_xy, int col0_yt, int rows, hipStream_t stream);
 
+
+// ---- SparseGrid(upsample=True): the x2 bilinear pre-upsample of the (x, y) axes (sparsegrid.py:26-34) --------------------------------
+// The reference runs F.interpolate(scale_factor=2, mode='bilinear') over [F, T, X, Y] on every call (align_corners=False; ATen's
+// area_pixel_compute_source_index with scale 1/2): destination index u reads source position max(0, u / 2 - 0.25), i.e.
+//   u = 0: cell 0 alone;  u = 2k (k >= 1): 0.25 * cell k-1 + 0.75 * cell min(k, R-1);  u = 2k + 1: 0.75 * cell k + 0.25 * cell min(k+1, R-1)
+// and the output is h0 * (w0 v00 + w1 v01) + h1 * (w0 v10 + w1 v11) with h along x, w along y (ATen's own formula, multiply and add rounded
+// separately: this file is compiled with FMA contraction off).  Layouts stay [T][X][Y][F] / [T][2X][2Y][F]: no permute passes.
+struct Up1 { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Up1 up_src(int u, int R) {
+    const float src = fmaxf(0.5f * ((float)u + 0.5f) - 0.5f, 0.f);
+    const int i0 = (int)src;
+    Up1 r;
+    r.i0 = i0; r.i1 = min(i0 + 1, R - 1);
+    r.l1 = src - (float)i0; r.l0 = 1.0f - r.l1;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ emb, float* __restrict__ out, int T, int X, int Y, int F) {
+    const int64_t total = (int64_t)T * (2 * X) * (2 * Y);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int uy = (int)(idx % (2 * Y));
+        const int ux = (int)((idx / (2 * Y)) % (2 * X));
+        const int64_t t = idx / ((int64_t)4 * X * Y);
+        const Up1 hx = up_src(ux, X), wy = up_src(uy, Y);
+        const float* b = emb + t * (int64_t)X * Y * F;
+        const float* v00 = b + ((int64_t)hx.i0 * Y + wy.i0) * F;
+        const float* v01 = b + ((int64_t)hx.i0 * Y + wy.i1) * F;
+        const float* v10 = b + ((int64_t)hx.i1 * Y + wy.i0) * F;
+        const float* v11 = b + ((int64_t)hx.i1 * Y + wy.i1) * F;
+        float* o = out + idx * F;
+        for (int f = 0; f < F; ++f)
+            o[f] = hx.l0 * (wy.l0 * v00[f] + wy.l1 * v01[f]) + hx.l1 * (wy.l0 * v10[f] + wy.l1 * v11[f]);
+    }
+}
+
+// adjoint, as a GATHER (deterministic, no atomics): source cell (x, y) collects every upsampled cell that read it.  In one dimension cell c is
+// read by u in {2c-1, 2c, 2c+1, 2c+2} (where they exist), with the forward's own (i0, i1, l0, l1) of that u - at the upper border both
+// references of u = 2R-1 land on cell R-1 and both weights count.
+__device__ __forceinline__ float up_weight(int u, int c, int R) {
+    if (u < 0 || u >= 2 * R) return 0.f;
+    const Up1 s = up_src(u, R);
+    return (s.i0 == c ? s.l0 : 0.f) + (s.i1 == c ? s.l1 : 0.f);
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dout, float* __restrict__ demb, int T, int X, int Y, int F) {
+    const int64_t total = (int64_t)T * X * Y;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int y = (int)(idx % Y);
+        const int x = (int)((idx / Y) % X);
+        const int64_t t = idx / ((int64_t)X * Y);
+        const float* d = dout + t * (int64_t)4 * X * Y * F;
+        float acc[16];
+        for (int f = 0; f < F; ++f) acc[f] = 0.f;
+        for (int a = -1; a <= 2; ++a) {
+            const int ux = 2 * x + a;
+            const float wx = up_weight(ux, x, X);
+            if (wx == 0.f) continue;
+            for (int b = -1; b <= 2; ++b) {
+                const int uy = 2 * y + b;
+                const float wyv = up_weight(uy, y, Y);
+                if (wyv == 0.f) continue;
+                const float w = wx * wyv;
+                const float* g = d + ((int64_t)ux * (2 * Y) + uy) * F;
+                for (int f = 0; f < F; ++f) acc[f] += w * g[f];
+            }
+        }
+        for (int f = 0; f < F; ++f) demb[idx * F + f] = acc[f];
+    }
+}
+
 extern "C" {
 
 int nvp_dense2d_fwd(const float* params, const float* x, float* out, int64_t n, const nvp_levels* lv, void* stream) {
@@ -475,6 +544,26 @@ int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t 
     if (n == 0) return 0;
     const int64_t total = nvp_ntiles(n) * (int64_t)(rows >> 2) * 32;
     hipLaunchKernelGGL(ptm_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_sparse_upsample2x_fwd(const float* emb, float* out, const nvp_sparse_shape* sh, void* stream) {
+    if (!emb || !out || !sh || sh->t_res < 1 || sh->x_res < 1 || sh->y_res < 1 || sh->n_features < 1 || sh->n_features > 16) return NVP_ERR_BADARG;
+    const int64_t total = (int64_t)sh->t_res * 4 * sh->x_res * sh->y_res;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, emb, out, sh->t_res, sh->x_res, sh->y_res, sh->n_features);
+    NVP_LAUNCH_CHECK();
+    return 0;
+}
+
+int nvp_sparse_upsample2x_bwd(const float* dout, float* demb, const nvp_sparse_shape* sh, void* stream) {
+    if (!dout || !demb || !sh || sh->t_res < 1 || sh->x_res < 1 || sh->y_res < 1 || sh->n_features < 1 || sh->n_features > 16) return NVP_ERR_BADARG;
+    const int64_t total = (int64_t)sh->t_res * sh->x_res * sh->y_res;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, demb, sh->t_res, sh->x_res, sh->y_res, sh->n_features);
     NVP_LAUNCH_CHECK();
     return 0;
 }

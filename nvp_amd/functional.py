@@ -206,6 +206,30 @@ def _sparse_shape(emb: torch.Tensor) -> L.SparseShape:
     return L.SparseShape(T, X, Y, F)
 
 
+class SparseUpsample2x(torch.autograd.Function):
+    """SparseGrid(upsample=True): emb [T,X,Y,F] -> [T,2X,2Y,F], the reference's permute -> F.interpolate(scale_factor=2, 'bilinear') ->
+    permute (sparsegrid.py:26-34) as ONE HIP pass (nvp_sparse_upsample2x_fwd); backward is its adjoint as a deterministic gather."""
+
+    @staticmethod
+    def forward(ctx, emb: torch.Tensor) -> torch.Tensor:
+        lib = L.load()
+        emb = _f32c(emb)
+        sh = _sparse_shape(emb)
+        out = torch.empty((sh.t_res, 2 * sh.x_res, 2 * sh.y_res, sh.n_features), device=emb.device, dtype=torch.float32)
+        L.check(lib.nvp_sparse_upsample2x_fwd(L.ptr(emb), L.ptr(out), C.byref(sh), L.stream_ptr()), "nvp_sparse_upsample2x_fwd")
+        ctx.sh = sh
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        lib = L.load()
+        sh = ctx.sh
+        dout = _f32c(dout)
+        demb = torch.empty((sh.t_res, sh.x_res, sh.y_res, sh.n_features), device=dout.device, dtype=torch.float32)
+        L.check(lib.nvp_sparse_upsample2x_bwd(L.ptr(dout), L.ptr(demb), C.byref(sh), L.stream_ptr()), "nvp_sparse_upsample2x_bwd")
+        return demb
+
+
 class SparseGrid3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inputs: torch.Tensor, emb: torch.Tensor, inter: bool) -> torch.Tensor:

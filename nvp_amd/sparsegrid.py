@@ -7,10 +7,12 @@ at call time (eval.py:179 rebinds it).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
-from .functional import SparseGrid3x3
+from .functional import SparseGrid3x3, SparseUpsample2x
 
 
 class SparseGrid(nn.Module):
@@ -29,15 +31,17 @@ class SparseGrid(nn.Module):
         self.embeddings.data.uniform_(-std, std)
 
     def _grid(self) -> torch.Tensor:
-        """The grid the gather reads.  With upsample=True the reference bilinearly upsamples the (x,y)
-        axes of the WHOLE grid by 2 on every call (sparsegrid.py:26-34: F.interpolate over
-        [dim, T, X, Y], a stock ATen kernel there and here); the HIP gather / scatter then run on the
-        upsampled tensor and autograd carries the gradient back through the interpolation."""
+        """The grid the gather reads.  With upsample=True the reference bilinearly upsamples the (x,y) axes of the WHOLE grid by 2 on
+        every call (sparsegrid.py:26-34: permute -> F.interpolate over [dim, T, X, Y] -> permute); here that is one HIP pass
+        (functional.SparseUpsample2x: nvp_sparse_upsample2x_fwd, ATen's formula) and the gather / scatter run on its output; the
+        gradient comes back through the pass's adjoint (nvp_sparse_upsample2x_bwd).  NVP_UPSAMPLE_ATEN=1 keeps the stock ATen route."""
         if not self.upsample:
             return self.embeddings
-        t = self.embeddings.permute(3, 0, 1, 2)
-        t = torch.nn.functional.interpolate(t, scale_factor=2, mode='bilinear')
-        return t.permute(1, 2, 3, 0).contiguous()
+        if os.environ.get("NVP_UPSAMPLE_ATEN", "0") == "1":
+            t = self.embeddings.permute(3, 0, 1, 2)
+            t = torch.nn.functional.interpolate(t, scale_factor=2, mode='bilinear')
+            return t.permute(1, 2, 3, 0).contiguous()
+        return SparseUpsample2x.apply(self.embeddings)
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         return SparseGrid3x3.apply(inputs, self._grid(), False)

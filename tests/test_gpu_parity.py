@@ -89,6 +89,40 @@ def test_sparse_grid_upsample_golden():
     assert _relerr(m.embeddings.grad.cpu().numpy(), emb_ref.grad.numpy()) < 1e-5
 
 
+def test_sparse_grid_upsample_hip_pass_vs_aten_and_adjoint():
+    """The x2 pre-upsample of upsample=True is ONE HIP pass (nvp_sparse_upsample2x_fwd / _bwd; sparsegrid.py:26-34) instead of the reference's
+    permute -> F.interpolate -> permute: (a) forward against ATen's interpolate on the same device (1-ulp-level association differences only),
+    incl. odd sizes and the borders; (b) the backward kernel is the exact adjoint of the forward one: <U e, d> == <e, U^T d> in float64; (c) the
+    module's gradient through gather + upsample against the stock ATen route (NVP_UPSAMPLE_ATEN=1)."""
+    from nvp_amd.functional import SparseUpsample2x
+    from nvp_amd.sparsegrid import SparseGrid
+    g = torch.Generator().manual_seed(5)
+    for (T, X, Y, Fd) in ((3, 5, 7, 2), (2, 1, 4, 4), (4, 33, 18, 4), (2, 300, 300, 2)):
+        emb = torch.randn((T, X, Y, Fd), generator=g).to(dev()).requires_grad_(True)
+        up = SparseUpsample2x.apply(emb)
+        ref = torch.nn.functional.interpolate(emb.detach().permute(3, 0, 1, 2), scale_factor=2, mode='bilinear').permute(1, 2, 3, 0)
+        assert up.shape == (T, 2 * X, 2 * Y, Fd)
+        assert float((up.detach() - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+        d = torch.randn(up.shape, generator=g).to(dev())
+        (demb,) = torch.autograd.grad(up, emb, d)
+        lhs = float((up.detach().double() * d.double()).sum())
+        rhs = float((emb.detach().double() * demb.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (lhs, rhs)
+    coords = torch.rand((5000, 3), generator=g).to(dev())
+    grads = []
+    for aten in ("0", "1"):
+        os.environ["NVP_UPSAMPLE_ATEN"] = aten
+        try:
+            m = SparseGrid(level_dim=2, x_resolution=12, y_resolution=9, t_resolution=6, upsample=True).to(dev())
+            with torch.no_grad():
+                m.embeddings.copy_(torch.randn(m.embeddings.shape, generator=torch.Generator().manual_seed(9)))
+            (m(coords) ** 2).sum().backward()
+            grads.append(m.embeddings.grad.cpu().numpy())
+        finally:
+            os.environ.pop("NVP_UPSAMPLE_ATEN", None)
+    assert _relerr(grads[0], grads[1]) < 1e-5
+
+
 def test_sparse_grid_border_multiplicity():
     """clamped border duplicates accumulate: a corner pixel hits the corner cell 4x."""
     from nvp_amd.sparsegrid import SparseGrid
