@@ -184,3 +184,48 @@ def test_sincos_pi_reduction_is_accurate():
     sn = np.where(odd, -sn, sn); cs = np.where(odd, -cs, cs)
     assert np.abs(sn - np.sin(x.astype(np.float64))).max() < 2e-7
     assert np.abs(cs - np.cos(x.astype(np.float64))).max() < 2e-7
+
+
+def test_upsample2x_index_and_weight_rule_matches_aten():
+    """The index / weight rule the HIP x2 pre-upsample and its gather adjoint are written from (nvp_amd/csrc/encode.hip: up_src, up_weight;
+    sparsegrid.py:26-34 = F.interpolate(scale_factor=2, mode='bilinear')), restated on the host and checked against ATen: forward to
+    1-ulp-level association differences, adjoint weights against autograd.  Odd sizes and a one-cell axis included."""
+    import numpy as np
+    f32 = np.float32
+
+    def up_src(u, R):
+        src = f32(max(f32(0.5) * (f32(u) + f32(0.5)) - f32(0.5), 0))
+        i0 = int(src)
+        l1 = f32(src - f32(i0))
+        return i0, min(i0 + 1, R - 1), f32(1) - l1, l1
+
+    def up_weight(u, c, R):
+        if u < 0 or u >= 2 * R:
+            return f32(0)
+        i0, i1, l0, l1 = up_src(u, R)
+        return (l0 if i0 == c else f32(0)) + (l1 if i1 == c else f32(0))
+
+    g = torch.Generator().manual_seed(3)
+    for (T, X, Y, Fd) in ((2, 5, 7, 2), (1, 1, 4, 4), (2, 6, 3, 1)):
+        emb = torch.randn((T, X, Y, Fd), generator=g, requires_grad=True)
+        ref = torch.nn.functional.interpolate(emb.permute(3, 0, 1, 2), scale_factor=2, mode='bilinear').permute(1, 2, 3, 0)
+        e = emb.detach().numpy()
+        out = np.zeros((T, 2 * X, 2 * Y, Fd), f32)
+        for ux in range(2 * X):
+            i0, i1, l0, l1 = up_src(ux, X)
+            for uy in range(2 * Y):
+                j0, j1, m0, m1 = up_src(uy, Y)
+                out[:, ux, uy, :] = l0 * (m0 * e[:, i0, j0, :] + m1 * e[:, i0, j1, :]) + l1 * (m0 * e[:, i1, j0, :] + m1 * e[:, i1, j1, :])
+        assert np.abs(out - ref.detach().numpy()).max() <= 1e-6 * max(1.0, float(ref.abs().max()))
+        d = torch.randn(ref.shape, generator=g)
+        (want,) = torch.autograd.grad(ref, emb, d)
+        dn, got = d.numpy(), np.zeros((T, X, Y, Fd), f32)
+        for x in range(X):
+            for y in range(Y):
+                for a in range(-1, 3):
+                    wx = up_weight(2 * x + a, x, X)
+                    for b in range(-1, 3):
+                        wy = up_weight(2 * y + b, y, Y)
+                        if wx != 0 and wy != 0:
+                            got[:, x, y, :] += (wx * wy) * dn[:, 2 * x + a, 2 * y + b, :]
+        assert np.abs(got - want.numpy()).max() <= 1e-5 * max(1.0, float(want.abs().max()))
