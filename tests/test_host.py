@@ -439,3 +439,18 @@ def test_product_library_has_no_environment_switches_and_no_experiment_entry_poi
         dyn_e = subprocess.run(["nm", "-D", exp], capture_output=True, text=True, check=True).stdout
         exported_e = set(re.findall(r" T (nvp_[a-z0-9_]+)", dyn_e))
         assert exported_e == exported | exp_names
+
+
+def test_bench_work_figures_are_surveys_8d_figures():
+    """bench.py's per-pixel work figures behind `roofline` / `step_roofline` are SURVEY.md 8(d)'s: GEMM FLOP fwd+bwd 658 688 (nvp_s) /
+    921 344 (nvp_l), fused-ideal bytes 3 256 / 6 472 B per pixel and 1 636 B per pixel for the fused forward launch of nvp_s."""
+    import bench
+    for F, flop_step, ideal_step in ((2, 658688, 3256), (4, 921344, 6472)):
+        flop, byts = bench.work_per_pixel(F)
+        assert flop["nvp_encode_mlp_fwd"] + flop["nvp_mlp_bwd_dx"] + flop["nvp_mlp_bwd_dw"] == flop_step
+        ideal = bench.ideal_bytes_per_pixel(F)
+        assert ideal["step"] == ideal_step
+        assert ideal["nvp_encode_mlp_fwd"] + ideal["nvp_mlp_bwd_dx"] + ideal["nvp_encode_bwd"] + ideal["nvp_mlp_bwd_dw"] == ideal_step
+        assert all(ideal[k] <= byts[k] for k in ideal if k in byts)          # the ideal never exceeds what the design moves
+    assert bench.ideal_bytes_per_pixel(2)["nvp_encode_mlp_fwd"] == 1636
+    assert bench.work_per_pixel(2)[0]["nvp_encode_mlp_fwd"] == 219648
