@@ -759,6 +759,40 @@ def test_nvp_no_grad_inference_and_temporal_interp():
     assert float((out_i[0, 1:] - ref_i[0, 1:]).abs().max()) <= RGB_TOL
 
 
+def test_wide_latent_fused_forward_inference_and_chunked_frames():
+    """config_nvp_l's 228-row latent through the fused gather + forward (nvp_encode_mlp_fwd_supported() == 2: the rows beyond the wave's LDS
+    tile are parked in the latent tensor, which is then the kernel's workspace for inference too): (a) the no-grad RGB equals the
+    training-mode RGB bit for bit and the oracle to 1e-5; (b) harness.render_frame, which bounds the pixels per model call whenever a
+    call materialises the latent (functional.materialises_nothing is False for this shape), gives the same frame bit for bit whatever
+    the bound - every pixel is independent."""
+    from nvp_amd import functional, harness
+    cfg, sd, model = _nvp_pair(4, seed=2)
+    from nvp_amd import _lib
+    sh = functional._sparse_shape(model.sparse_grid.embeddings)
+    import ctypes as C
+    assert int(_lib.load().nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
+                                                        C.byref(model.keyframes_xt.levels), C.byref(sh))) == 2
+    assert not functional.materialises_nothing(model, False)
+    gen = torch.Generator().manual_seed(8)
+    n = 3001
+    coords, steps = torch.rand((1, n, 3), generator=gen), torch.rand((1, n), generator=gen)
+    mi = {"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())}
+    with torch.no_grad():
+        out_ng = model(mi)["model_out"]
+        ref = O.nvp_forward(coords, steps, sd, cfg)
+    out_g = model(mi)["model_out"]
+    assert torch.equal(out_ng, out_g.detach())
+    assert float((out_ng.cpu() - ref).abs().max()) <= RGB_TOL
+    frames = []
+    for cap in (1 << 22, 97):                     # one call for the frame / chunks of 97 pixels
+        harness.MAX_PIXELS_PER_CALL = cap
+        try:
+            frames.append(harness.render_frame(model, 3, 8, (20, 31), n_slice=4))
+        finally:
+            harness.MAX_PIXELS_PER_CALL = 1 << 22
+    assert torch.equal(frames[0], frames[1])
+
+
 def test_batch_dim_and_param_rebinding_like_eval():
     """b > 1 (utils.py:70-80 uses b=4) and eval.py:170-179 style parameter re-assignment."""
     cfg, sd, model = _nvp_pair(2)
