@@ -1,6 +1,8 @@
-"""world_size-2 gloo tests (CPU) of the data-parallel path: the flat gradient bucket, the
-single all-reduce per step and the parameter broadcast.  The kernels are not
-involved: gradients are fabricated, what is tested is the collective plumbing bench.py uses."""
+"""gloo tests (CPU) of the data-parallel path at world 2, 4 and 8 (BASELINE.json configs[4] is the 8-GPU run): the flat gradient
+bucket, the all-reduce per step, the parameter broadcast, and the three exchange schemes.  The kernels are not
+involved: gradients are fabricated, what is tested is the collective plumbing bench.py uses - bucket aliasing, early + remainder
+== full all-reduce, the repair paths, piece / shard boundaries at flat sizes that are NOT multiples of 64 * world, `first=`
+pieces, sharded / all_to_all == replicated, per-rank checkpoints."""
 import os
 import socket
 
@@ -20,9 +22,30 @@ def _free_port():
     return p
 
 
+WORLDS = [2, 4, 8]
+
+
+def _spawn(target, world, *args):
+    """`world` ranks of `target(rank, world, port, q, *args)`; every rank must exit 0 and report ok."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=420)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, "ok") for r in range(world)]
+
+
 def _worker(rank, world, port, q):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
                        "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    torch.set_num_threads(1)                             # eight ranks share this container's eight cores
     from nvp_amd import parallel
     from nvp_amd.modules import NVP
     r, w, _ = parallel.init_distributed(backend="gloo")
@@ -155,19 +178,9 @@ def _worker(rank, world, port, q):
     q.put((rank, "ok"))
 
 
-def test_grad_bucket_allreduce_world2():
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=180)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    got = sorted(q.get(timeout=5) for _ in range(world))
-    assert got == [(0, "ok"), (1, "ok")]
+@pytest.mark.parametrize("world", WORLDS)
+def test_grad_bucket_allreduce(world):
+    _spawn(_worker, world)
 
 
 def test_single_process_bucket_is_a_noop_collective():
@@ -197,110 +210,180 @@ def _cpu_adamw_update(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale):
 def _sharded_worker(rank, world, port, q, algo):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
                        "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    torch.set_num_threads(1)
+    import io
     from nvp_amd import parallel
     from nvp_amd.modules import NVP
     parallel.init_distributed(backend="gloo")
     cfg = small_cfg(F=2, T=16, X=20, Y=20, n_levels=4)       # sparse grid of 12 800 elements: several 3000-element pieces lie wholly inside it
+    unit = parallel.ShardedAdamW.alignment(world)
+    STEPS, CKPT_AT = 5, 2
 
     def build():
         torch.manual_seed(7)
         return NVP(out_features=3, encoding_config=cfg)
 
-    def fake_grads(views, it):                       # what backward would write through the sink: rank- and step-dependent
+    def fake_grads(views, it, exact=True):
+        """What backward would write through the sink: rank- and step-dependent.  exact: integers in [-1024, 1024] times a power of
+        two that depends on (step, tensor) but NOT on the rank - any summation order over <= 8 ranks gives the same fp32 sum, so
+        the three exchange schemes (gloo's all-reduce order, its reduce-scatter order, the rank-order local sum of the all_to_all
+        form) must agree BIT FOR BIT at every world size.  exact=False: plain floats - the schemes then differ by fp32 summation
+        order only (checked to a tolerance)."""
         g = torch.Generator().manual_seed(1000 * it + rank)
+        ge = torch.Generator().manual_seed(77 * it)
         for v in views:
-            v.copy_(torch.randn(v.shape, generator=g) * 10.0 ** float(torch.randint(-6, 1, (1,), generator=g)))
+            e = float(torch.randint(-20, 1, (1,), generator=ge))
+            if exact:
+                v.copy_(torch.randint(-1024, 1025, v.shape, generator=g).float() * 2.0 ** e)
+            else:
+                v.copy_(torch.randn(v.shape, generator=g) * 2.0 ** e)
+
+    def grids_of(m):
+        return [m.keyframes_xy.params, m.keyframes_yt.params, m.keyframes_xt.params, m.sparse_grid.embeddings]
+
+    def make_sharded():
+        m = build()
+        ps = parallel.unique_parameters(m)
+        b = parallel.GradBucket(ps, early=grids_of(m), chunk_elems=3000, pad_to=unit)
+        o = parallel.ShardedAdamW(b, lr=1e-2, weight_decay=1e-3, algo=algo, update=_cpu_adamw_update, first=[m.sparse_grid.embeddings])
+        return m, ps, b, o, torch.optim.lr_scheduler.CosineAnnealingLR(o, T_max=STEPS, eta_min=1e-5)
 
     # ---- replicated reference: all-reduce (SUM), every rank applies the whole update with grad_scale = 1/world
     m_rep = build()
     p_rep = parallel.unique_parameters(m_rep)
-    grids = [m_rep.keyframes_xy.params, m_rep.keyframes_yt.params, m_rep.keyframes_xt.params, m_rep.sparse_grid.embeddings]
-    b_rep = parallel.GradBucket(p_rep, early=grids, chunk_elems=3000)
+    b_rep = parallel.GradBucket(p_rep, early=grids_of(m_rep), chunk_elems=3000)
     flat_p = torch.cat([p.detach().reshape(-1) for p in p_rep]).clone()
     m1, v1 = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
     # ---- sharded
-    m_sh = build()
-    p_sh = parallel.unique_parameters(m_sh)
-    grids_sh = [m_sh.keyframes_xy.params, m_sh.keyframes_yt.params, m_sh.keyframes_xt.params, m_sh.sparse_grid.embeddings]
-    b_sh = parallel.GradBucket(p_sh, early=grids_sh, chunk_elems=3000, pad_to=parallel.ShardedAdamW.alignment(world))
-    opt = parallel.ShardedAdamW(b_sh, lr=1e-2, weight_decay=1e-3, algo=algo, update=_cpu_adamw_update, first=[m_sh.sparse_grid.embeddings])
-    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=4, eta_min=1e-5)
-    assert len(opt.pieces) >= 3 and opt.n_early >= 2 and opt.pieces[-1][1] == b_sh.padded
+    m_sh, p_sh, b_sh, opt, sched = make_sharded()
+    # layout at this world size: the flat size is NOT a multiple of 64 * world (zero padding at the end), every piece splits into
+    # `world` equal 256-B aligned shards, piece boundaries fall INSIDE the early (grid) range and inside parameters, the end of
+    # the early range is not a piece boundary (its tail travels with the remainder piece)
+    assert b_sh.numel % unit != 0 and b_sh.padded % unit == 0 and 0 < b_sh.padded - b_sh.numel < unit
+    assert len(opt.pieces) >= 3 and opt.n_early >= 2 and opt.pieces[0][0] == 0 and opt.pieces[-1][1] == b_sh.padded
+    assert all(opt.pieces[i][1] == opt.pieces[i + 1][0] for i in range(len(opt.pieces) - 1))
+    assert all((b - a) % unit == 0 and (b - a) > 0 for a, b in opt.pieces)
+    e_lo, e_hi = b_sh._early_range
+    assert e_hi % unit != 0 and opt.pieces[opt.n_early - 1][1] == e_hi // unit * unit < e_hi
+    inner = {a for a, _ in opt.pieces[1:opt.n_early]}
+    assert inner and not inner & set(b_sh._offsets), "early piece boundaries should cut through parameters"
+    for (a, b), (lo, hi, off) in zip(opt.pieces, opt.shards):
+        assert hi - lo == (b - a) // world and lo == a + rank * (hi - lo) and lo % 64 == 0
     # the pieces that only hold the sparse grid can be exchanged before the dense planes' gradients exist
     emb_lo = b_sh._offsets[3]
     assert opt._first_pieces and all(opt.pieces[i][0] >= emb_lo for i in opt._first_pieces) and 0 not in opt._first_pieces
-    assert all((b - a) % (64 * world) == 0 for a, b in opt.pieces)
     assert opt.exp_avg.numel() * world == b_sh.padded                      # optimizer state is 1/world of the flat vector
     assert all(p.data_ptr() == opt.pflat[o:o + 1].data_ptr() for p, o in zip(p_sh, b_sh._offsets))    # parameters re-homed, values kept
     assert torch.equal(torch.cat([p.detach().reshape(-1) for p in p_sh]), flat_p)
+
+    def sharded_step(m, ps, b, o, it, exact=True):
+        if it % 2 == 0:
+            # SPARSE_READY_HOOK: only the sparse grid's gradient exists yet - its pieces go out; the dense planes' gradients are
+            # written AFTERWARDS (stale values in their range must not have been sent)
+            for v in b.views[:3]:
+                v.fill_(float("nan"))
+            b.sink()
+            g_all = [torch.empty_like(v) for v in b.views]
+            fake_grads(g_all, it, exact)
+            b.views[3].copy_(g_all[3])
+            o.start_first()
+            o.start_first()                         # (idempotent)
+            for v, gsrc in zip(b.views, g_all):
+                if v is not b.views[3]:
+                    v.copy_(gsrc)
+        else:
+            fake_grads(b.views, it, exact)
+            b.sink()
+        o.start_early()                             # GRIDS_READY_HOOK: the (remaining) early pieces' reduce-scatter is in flight
+        if it == 3:                                 # the MLP range lost its views (autograd cloned): repaired, exchanged once
+            for p in ps[4:]:
+                p.grad = p.grad.clone()
+            assert not b.consistent()
+        o.step()
+
     lr_now = 1e-2
-    for it in range(1, 5):
+    ckpt, after_ckpt = None, {}
+    for it in range(1, STEPS + 1):
+        exact = it < STEPS                            # the last step: plain float gradients (summation order differs between the schemes)
         # replicated
-        fake_grads(b_rep.views, it)
+        fake_grads(b_rep.views, it, exact)
         b_rep.sink(); b_rep.start_early()
         assert b_rep.consistent()
         for wait, _ in b_rep.step_schedule():
             wait()
         _cpu_adamw_update(flat_p, b_rep.flat, m1, v1, lr_now, 0.9, 0.999, 1e-8, 1e-3, it, 1.0 / world)
         # sharded: same local gradients
-        if it % 2 == 0:
-            # SPARSE_READY_HOOK: only the sparse grid's gradient exists yet - its pieces go out; the dense planes' gradients are
-            # written AFTERWARDS (stale values in their range must not have been sent)
-            for v in b_sh.views[:3]:
-                v.fill_(float("nan"))
-            b_sh.sink()
-            g_all = [torch.empty_like(v) for v in b_sh.views]
-            fake_grads(g_all, it)
-            b_sh.views[3].copy_(g_all[3])
-            opt.start_first()
-            opt.start_first()                         # (idempotent)
-            for v, gsrc in zip(b_sh.views, g_all):
-                if v is not b_sh.views[3]:
-                    v.copy_(gsrc)
-        else:
-            fake_grads(b_sh.views, it)
-            b_sh.sink()
-        opt.start_early()                             # GRIDS_READY_HOOK: the (remaining) early pieces' reduce-scatter is in flight
-        if it == 3:                                   # the MLP range lost its views (autograd cloned): repaired, exchanged once
-            for p in p_sh[4:]:
-                p.grad = p.grad.clone()
-            assert not b_sh.consistent()
         assert abs(opt.param_groups[0]["lr"] - lr_now) < 1e-15
-        opt.step()
+        sharded_step(m_sh, p_sh, b_sh, opt, it, exact)
         sched.step()
         lr_now = opt.param_groups[0]["lr"]
         got = torch.cat([p.detach().reshape(-1) for p in p_sh])
-        assert torch.equal(got, flat_p), f"step {it}: sharded parameters differ from the replicated AdamW path (max {float((got - flat_p).abs().max())})"
-    # replicas identical
-    chk = opt.pflat.double().sum().reshape(1)
-    gathered = [torch.zeros_like(chk) for _ in range(world)]
-    dist.all_gather(gathered, chk)
-    assert all(torch.equal(g, gathered[0]) for g in gathered)
-    # the moments of my shard equal the replicated moments of the same elements
-    for (lo, hi, off) in opt.shards:
-        n_real = max(0, min(hi, b_sh.numel) - lo)
-        assert torch.equal(opt.exp_avg[off:off + n_real], m1[lo:lo + n_real]) and torch.equal(opt.exp_avg_sq[off:off + n_real], v1[lo:lo + n_real])
+        if exact:
+            assert torch.equal(got, flat_p), f"step {it}: sharded parameters differ from the replicated AdamW path (max {float((got - flat_p).abs().max())})"
+        else:
+            # fp32 summation order: a gradient sum off by ulps moves m / (sqrt(v) + eps) by ~1e-6 of O(1): |dp| <= lr * 1e-5
+            assert float((got - flat_p).abs().max()) <= 1e-2 * 1e-5, float((got - flat_p).abs().max())
+        # replicas bit-identical after EVERY step, exact sums or not (every rank receives the same gathered shards)
+        chk = torch.stack([opt.pflat.double().sum(), opt.pflat.double().abs().sum()])
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), f"step {it}: replicas diverged"
+        if it == CKPT_AT:
+            buf = io.BytesIO()                        # what training.py:65-68 does, per rank (the moments exist nowhere else)
+            torch.save({"model": m_sh.state_dict(), "optimizer": opt.state_dict(), "scheduler": sched.state_dict()}, buf)
+            ckpt = buf.getvalue()
+        if it > CKPT_AT:
+            after_ckpt[it] = got.clone()
+        if it == STEPS - 1:
+            # the moments of my shard equal the replicated moments of the same elements (exact sums so far: bit for bit)
+            for (lo, hi, off) in opt.shards:
+                n_real = max(0, min(hi, b_sh.numel) - lo)
+                assert torch.equal(opt.exp_avg[off:off + n_real], m1[lo:lo + n_real]) and torch.equal(opt.exp_avg_sq[off:off + n_real], v1[lo:lo + n_real])
+    # ---- checkpoint round trip at this world size: a fresh model + optimizer per rank, resumed from its own file, continues bit for bit
+    m2, p2, b2, opt2, sched2 = make_sharded()
+    ck = torch.load(io.BytesIO(ckpt), weights_only=False)
+    m2.load_state_dict(ck["model"])
+    opt2.load_state_dict(ck["optimizer"])
+    sched2.load_state_dict(ck["scheduler"])
+    assert opt2.steps_done == CKPT_AT and ck["optimizer"]["sharded"]["world"] == world and ck["optimizer"]["sharded"]["rank"] == rank
+    assert all(p.data_ptr() == opt2.pflat[o:o + 1].data_ptr() for p, o in zip(p2, b2._offsets)), "load_state_dict must keep the parameters re-homed"
+    for it in range(CKPT_AT + 1, STEPS + 1):
+        sharded_step(m2, p2, b2, opt2, it, it < STEPS)
+        sched2.step()
+        assert torch.equal(torch.cat([p.detach().reshape(-1) for p in p2]), after_ckpt[it]), f"resumed run differs at step {it}"
+    # ... and a state saved under another layout is refused loudly: another rank's file, and a world-2 run's file at this world size
+    other = torch.load(io.BytesIO(ckpt), weights_only=False)["optimizer"]
+    other["sharded"]["rank"] = (rank + 1) % world
+    with pytest.raises(ValueError, match="rank"):
+        opt2.load_state_dict(other)
+    if world != 2:
+        w2 = torch.load(io.BytesIO(ckpt), weights_only=False)["optimizer"]
+        u2 = parallel.ShardedAdamW.alignment(2)
+        pad2 = (b_sh.numel + u2 - 1) // u2 * u2
+        w2["sharded"].update(world=2, rank=rank % 2, padded=pad2)       # what a world-2 run of the same model would have written
+        with pytest.raises(ValueError, match="world"):
+            opt2.load_state_dict(w2)
+        w2["sharded"]["world"] = world                                  # even relabelled, its padding / pieces do not fit
+        w2["sharded"]["rank"] = rank
+        if pad2 != b_sh.padded:
+            with pytest.raises(ValueError, match="padded"):
+                opt2.load_state_dict(w2)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, "ok"))
 
 
+@pytest.mark.parametrize("world", WORLDS)
 @pytest.mark.parametrize("algo", ["reduce_scatter", "all_to_all"])
-def test_sharded_adamw_matches_replicated_world2(algo):
-    """reduce-scatter -> sharded AdamW -> all-gather keeps every replica BIT-identical to the all-reduce + full-AdamW path
-    (world 2: a + b is order-independent), over 4 steps with a cosine schedule, incl. a step whose MLP gradients lost their
-    bucket views; both exchange algorithms (RCCL-style reduce_scatter, one-hop all_to_all + local sum)."""
-    world = 2
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, algo)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=180)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, "ok"), (1, "ok")]
+def test_sharded_adamw_matches_replicated(algo, world):
+    """reduce-scatter -> sharded AdamW -> all-gather against the all-reduce + full-AdamW path at world 2, 4 and 8 (configs[4] is the
+    8-GPU run), over 5 steps with a cosine schedule, incl. a step whose MLP gradients lost their bucket views and sparse-first steps;
+    both exchange algorithms (RCCL-style reduce_scatter, one-hop all_to_all + rank-order local sum).  Steps 1-4 use gradients whose
+    cross-rank sums are exact in fp32 (integers times a rank-independent power of two): the schemes must then agree BIT FOR BIT
+    whatever order a backend sums in; step 5 uses plain floats: replicas still bit-identical to each other, sharded vs replicated to
+    |dp| <= lr * 1e-5 (fp32 summation order).  Per-rank checkpoint after step 2, resumed in a fresh optimizer: bit-identical
+    continuation; a state written under another rank or world size is refused."""
+    _spawn(_sharded_worker, world, algo)
 
 
 def test_sharded_adamw_single_process_has_no_cpu_update():
