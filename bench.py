@@ -50,14 +50,14 @@ def _cpulist(text: str):
     return out
 
 
-def apply_cpu_policy() -> dict:
-    """Thread / NUMA policy of the cpu_baseline leg, applied BEFORE torch (and its OpenMP pool) is loaded, in a process of its own:
-    one hardware thread per PHYSICAL core of every socket the process may run on ("all physical cores"), the
-    OpenMP threads bound to those cores, and - on hosts with more than one NUMA node - page allocation INTERLEAVED across the nodes
-    (set_mempolicy(MPOL_INTERLEAVE)): with first-touch placement the 543 MB gradient tensors of the oracle land on whichever socket
-    the touching thread happens to run on, and the rate moved by 2x between two boxes of the same CPU model.  If the
-    kernel refuses the memory policy (seccomp), the threads are pinned to the physical cores of NUMA node 0 alone instead.
-    Returns what was applied; the caller reports it inside the cpu_baseline object."""
+def apply_cpu_policy(n_threads: int = 0) -> dict:
+    """Thread / NUMA policy of one cpu_baseline worker, applied BEFORE torch (and its OpenMP pool) is loaded, in a process of its own:
+    `n_threads` hardware threads, one per PHYSICAL core, taken in core order (NUMA node 0 first: "close"), the process pinned to exactly
+    those cores (0 = every physical core the process may run on - BASELINE.md section 3's "all physical cores").  When the chosen cores span
+    more than one NUMA node, page allocation is INTERLEAVED across those nodes (set_mempolicy(MPOL_INTERLEAVE)): with first-touch placement
+    the 543 MB gradient tensors of the oracle land on whichever socket the touching thread happens to run on, and the rate moved by 2x
+    between two boxes of the same CPU model.  If the kernel refuses the memory policy (seccomp), the threads are pinned to the
+    physical cores of the first node alone instead.  Returns what was applied; the caller reports it inside the cpu_baseline object."""
     import ctypes
     allowed = sorted(os.sched_getaffinity(0))
     phys = []
@@ -68,17 +68,17 @@ def apply_cpu_policy() -> dict:
             sib = [c]
         if c == min(x for x in sib if x in allowed):
             phys.append(c)
+    use = phys[:n_threads] if n_threads and n_threads < len(phys) else phys
     nodes = {}
     try:
         for d in sorted(os.listdir("/sys/devices/system/node")):
             if d.startswith("node") and d[4:].isdigit():
-                cs = [c for c in _cpulist(open(f"/sys/devices/system/node/{d}/cpulist").read()) if c in phys]
+                cs = [c for c in _cpulist(open(f"/sys/devices/system/node/{d}/cpulist").read()) if c in use]
                 if cs:
                     nodes[int(d[4:])] = cs
     except OSError:
         pass
-    policy = {"numa_nodes": len(nodes) or 1, "allowed_cpus": len(allowed), "physical_cores": len(phys)}
-    use = phys
+    policy = {"numa_nodes_used": len(nodes) or 1, "allowed_cpus": len(allowed), "physical_cores": len(phys)}
     if len(nodes) > 1:
         mask = ctypes.c_ulong(sum(1 << k for k in nodes))
         rc = -1
@@ -93,18 +93,25 @@ def apply_cpu_policy() -> dict:
             use = nodes[min(nodes)]
             policy["memory"] = f"first touch; threads pinned to NUMA node {min(nodes)} only (set_mempolicy refused)"
     else:
-        policy["memory"] = "single NUMA node: first touch"
+        policy["memory"] = "one NUMA node: first touch"
     os.sched_setaffinity(0, set(use))
     os.environ["OMP_NUM_THREADS"] = str(len(use))
     os.environ["MKL_NUM_THREADS"] = str(len(use))
     os.environ["OMP_PROC_BIND"] = "close"
     os.environ["OMP_PLACES"] = "cores"
     policy["threads"] = len(use)
-    policy["binding"] = "sched_setaffinity to one hardware thread per physical core, OMP_PROC_BIND=close OMP_PLACES=cores"
+    policy["binding"] = "sched_setaffinity to one hardware thread per physical core (core order, node 0 first), OMP_PROC_BIND=close OMP_PLACES=cores"
     return policy
 
 
-CPU_POLICY = apply_cpu_policy() if "--cpu-baseline-only" in sys.argv else None
+def _argv_int(flag: str, default: int = 0) -> int:
+    try:
+        return int(sys.argv[sys.argv.index(flag) + 1])
+    except (ValueError, IndexError):
+        return default
+
+
+CPU_POLICY = apply_cpu_policy(_argv_int("--cpu-threads")) if "--cpu-baseline-only" in sys.argv else None
 
 import torch  # noqa: E402
 
@@ -200,26 +207,85 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(n_sample: int, reps: int = 3):
-    """The cpu_baseline leg in a PROCESS OF ITS OWN (`bench.py --cpu-baseline-only`): its thread / NUMA policy (apply_cpu_policy) must be
+def physical_cores() -> int:
+    allowed = sorted(os.sched_getaffinity(0))
+    n = 0
+    for c in allowed:
+        try:
+            sib = _cpulist(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read())
+        except OSError:
+            sib = [c]
+        n += int(c == min(x for x in sib if x in allowed))
+    return max(n, 1)
+
+
+def _cpu_worker(n_sample: int, reps: int, threads: int, full: bool, timeout: int):
+    """One cpu_baseline worker in a PROCESS OF ITS OWN (`bench.py --cpu-baseline-only`): its thread / NUMA policy (apply_cpu_policy) must be
     in place before torch's OpenMP pool exists, and this process's pool was created long ago.  Returns the worker's JSON object."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["HIP_VISIBLE_DEVICES"] = ""            # the worker is CPU-only
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", str(n_sample), "--cpu-reps", str(reps)],
-                       env=env, capture_output=True, text=True)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-sample", str(n_sample), "--cpu-reps", str(reps), "--cpu-threads", str(threads)]
+    if full:
+        cmd.append("--cpu-full")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
-        raise RuntimeError(f"cpu_baseline worker failed (rc {r.returncode}): {r.stderr[-1500:]}")
+        raise RuntimeError(f"cpu_baseline worker ({threads} threads) failed (rc {r.returncode}): {r.stderr[-1500:]}")
     return json.loads(lines[-1])
 
 
-def cpu_baseline_worker(n_sample: int, reps: int = 3):
-    """the oracle's fwd+bwd (incl. the dense grid gradients, as the reference's autograd produces
-    them; optimizer excluded) on this host's cores, 1 warm-up + `reps` timed evaluations.  A full N = 1 245 184 step takes
-    more than 60 s here, so the sample is N/8 = 155 648 pixels of the same batch distribution and the rate is quoted per
-    pixel of the sample (= the linear extrapolation to N; it flatters the CPU slightly where costs do not shrink with the
-    sample: zero-filling and accumulating the 543 MB of dense gradients)."""
+def cpu_baseline(n_sample: int, reps: int = 2):
+    """The cpu_baseline leg.  The oracle's forward + backward is timed under a SWEEP of thread
+    counts - 8, 16, 32, 64 and every physical core, each in a process of its own, pinned close - because on the GPU hosts (2 x 64 cores, up
+    to four tenants) the all-cores figure is a fork-join artefact: ATen parallelises every small element-wise op over all 128 threads across
+    two NUMA nodes and runs ~8x SLOWER than on 8-16 threads.  Every worker times the FIXED part of a step separately (a 1-pixel batch: zero-fill
+    and accumulation of the 543 MB of dense grid gradients, which does not shrink with the sample) and the N/8 sample; only the per-pixel
+    part is extrapolated.  The best thread count then runs ONE step at the full N = 1 245 184 if its predicted time is below 60 s: `value`
+    is that measured full-N rate (no extrapolation); the all-cores figure stays in the object as `all_cores`."""
+    phys = physical_cores()
+    ks = sorted({k for k in (8, 16, 32, 64) if k < phys} | {phys})
+    sweep, errors = {}, {}
+    for k in ks:
+        try:
+            sweep[k] = _cpu_worker(n_sample, reps if k < phys or phys <= 16 else 1, k, False, 600)     # all cores of a big host: 1 warm-up + 1 timed (~30 s each)
+        except Exception as e:                          # noqa: BLE001 - one failed thread count must not cost the leg
+            errors[str(k)] = repr(e)[:300]
+    if not sweep:
+        raise RuntimeError(f"cpu_baseline: every worker failed: {errors}")
+    best_k = max(sweep, key=lambda k: sweep[k]["extrapolated"]["mpx_s"])
+    best = sweep[best_k]
+    final, measured_full = best, False
+    if best["extrapolated"]["seconds_per_full_step"] < 60.0:
+        try:
+            final = _cpu_worker(n_sample, 1, best_k, True, 900)
+            measured_full = final.get("full_step") is not None
+        except Exception as e:                          # noqa: BLE001
+            errors["full"] = repr(e)[:300]
+    value = final["full_step"]["mpx_s"] if measured_full else best["extrapolated"]["mpx_s"]
+    brief = lambda w: {"threads": w["cores"], "mpx_s_extrapolated_to_full_N": w["extrapolated"]["mpx_s"], "seconds_fixed_part": w["seconds_fixed_part"],      # noqa: E731
+                       "seconds_per_sample_step": w["seconds_per_sample_step"], "seconds_per_full_step_extrapolated": w["extrapolated"]["seconds_per_full_step"],
+                       "memory": w["policy"]["memory"], "host_loadavg_before_after": w["host_loadavg_before_after"]}
+    out = {"value": value, "unit": "Mpixels/s", "cores": best_k, "kind": "port", "cpu": best["cpu"],
+           "policy": "value = the BEST thread count of the sweep (BASELINE.md section 3 asks for all physical cores: that figure is `all_cores`; on a 2 x 64-core "
+                     "host it is a thread-oversubscription artefact); " + ("measured on ONE full-N step after a warm-up, no extrapolation" if measured_full else
+                     "per-pixel part extrapolated from the N/8 sample, fixed part (543 MB dense gradient zero-fill + accumulate) measured separately and added once"),
+           "best": dict(brief(best), full_step=final.get("full_step")), "all_cores": brief(sweep[max(sweep)]),
+           "sweep": {str(k): brief(w) for k, w in sweep.items()}, "torch_parallel_info": best["torch_parallel_info"], "binding": best["policy"]["binding"],
+           "sample": (f"full N = {N_PX} px, one timed fwd+bwd step after a warm-up on {n_sample} px" if measured_full else f"{n_sample} px (N/{N_PX // n_sample}), extrapolated") +
+                     f"; thread sweep {ks} on {n_sample} px each (1 warm-up + {reps} timed, median; all cores: 1 timed); same batch distribution, full nvp_s parameters "
+                     "(135.8M fp32), fwd+bwd incl. dense grid grads, optimizer excluded"}
+    if errors:
+        out["errors"] = errors
+    return out
+
+
+def cpu_baseline_worker(n_sample: int, reps: int = 2, full: bool = False):
+    """the oracle's fwd+bwd (incl. the dense grid gradients, as the reference's autograd produces them; optimizer
+    excluded) on this process's pinned cores.  Three measurements: (i) the FIXED part of a step - a 1-pixel batch (zero-filling and
+    accumulating 543 MB of dense gradients costs the same at any batch size), 1 warm-up + 2 timed; (ii) `n_sample` pixels of the same batch
+    distribution, 1 warm-up + `reps` timed, median; full step extrapolated as fixed + (sample - fixed) * N / n_sample; (iii) with `full`: ONE
+    step at N = 1 245 184."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nvp_oracle as O
     load0 = os.getloadavg()              # the GPU boxes are multi-tenant hosts: other jobs' CPU load is the main source of run-to-run spread
@@ -229,31 +295,33 @@ def cpu_baseline_worker(n_sample: int, reps: int = 3):
         v.requires_grad_(True)
     gen = torch.Generator().manual_seed(0)
     T, H, W = WORKLOADS["s"]["video"]
-    times = []
-    for it in range(reps + 1):
-        _, _, coords, steps = O.sample_batch(T, H, W, n_sample, gen)
-        gt = O.normalise_gt(torch.randint(0, 256, (1, n_sample, 3), generator=gen, dtype=torch.uint8))
+
+    def step(n):
+        _, _, coords, steps = O.sample_batch(T, H, W, n, gen)
+        gt = O.normalise_gt(torch.randint(0, 256, (1, n, 3), generator=gen, dtype=torch.uint8))
         t0 = time.perf_counter()
         out = O.nvp_forward(coords.unsqueeze(0), steps.unsqueeze(0), sd, cfg)
         loss = O.image_mse(out, gt)
         for v in sd.values():
             v.grad = None
         loss.backward()
-        dt = time.perf_counter() - t0
-        if it > 0:
-            times.append(dt)
-    times.sort()
+        return time.perf_counter() - t0
+
+    fixed = min([step(1) for _ in range(3)][1:])         # the first evaluation is the warm-up
+    times = sorted([step(n_sample) for _ in range(reps + 1)][1:])
     med = times[len(times) // 2]
-    rate = lambda t: round(n_sample / t / 1e6, 6)      # noqa: E731
+    per_px = max(med - fixed, 0.0) / n_sample
+    full_s = fixed + per_px * N_PX
+    rate = lambda n, t: round(n / t / 1e6, 6)      # noqa: E731
     par = [ln.strip() for ln in torch.__config__.parallel_info().splitlines() if any(k in ln for k in ("get_num_threads", "omp_get_max_threads", "mkl_get_max_threads", "ATen parallel backend"))]
-    return {"value": rate(med), "unit": "Mpixels/s", "cores": torch.get_num_threads(), "kind": "port", "policy": CPU_POLICY, "torch_parallel_info": par,
-            "host_loadavg_before_after": [round(load0[0], 1), round(os.getloadavg()[0], 1)],
-            "min": rate(times[-1]), "median": rate(med), "max": rate(times[0]),
-            "seconds_per_sample_step": [round(t, 3) for t in times], "extrapolated_seconds_per_full_step": round(med * N_PX / n_sample, 1),
-            "cpu": cpu_model(),
-            "sample": f"{n_sample} px (N/{N_PX // n_sample}) of the same batch distribution, full nvp_s parameters (135.8M fp32), fwd+bwd incl. "
-                      f"dense grid grads, optimizer excluded; 1 warm-up + {reps} timed, value = median; linear extrapolation to "
-                      f"N = {N_PX}: {med * N_PX / n_sample:.1f} s/step"}
+    res = {"cores": torch.get_num_threads(), "policy": CPU_POLICY, "torch_parallel_info": par, "cpu": cpu_model(),
+           "seconds_fixed_part": round(fixed, 3), "seconds_per_sample_step": [round(t, 3) for t in times], "sample_px": n_sample,
+           "extrapolated": {"seconds_per_full_step": round(full_s, 2), "mpx_s": rate(N_PX, full_s)}, "full_step": None}
+    if full:
+        t_full = step(N_PX)
+        res["full_step"] = {"seconds": round(t_full, 2), "mpx_s": rate(N_PX, t_full), "px": N_PX}
+    res["host_loadavg_before_after"] = [round(load0[0], 1), round(os.getloadavg()[0], 1)]
+    return res
 
 
 def arithmetic_check(dev, n: int = 4096) -> dict:
@@ -317,7 +385,7 @@ def other_configs(args) -> dict:
     out = {}
     for c in ("l", "4k"):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", c, "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--prewarm", str(args.prewarm), "--no-cpu-baseline", "--no-isolate", "--no-reference-surface", "--no-other-configs"]
+               "--prewarm", str(args.prewarm), "--no-cpu-baseline", "--no-isolate", "--no-reference-surface", "--no-other-configs", "--no-dp-floor"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -452,7 +520,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-arithmetic-check", action="store_true", help="skip the untimed HIP-vs-float64-oracle gradient check (arithmetic_check)")
     ap.add_argument("--cpu-sample", type=int, default=N_PX // 8)
-    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--cpu-reps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="worker mode: threads (one per physical core, close); 0 = every physical core")
+    ap.add_argument("--cpu-full", action="store_true", help="worker mode: also time ONE step at the full N = 1 245 184")
     ap.add_argument("--cpu-baseline-only", action="store_true",
                     help="worker mode of the cpu_baseline leg: apply the thread / NUMA policy, time the oracle on --cpu-sample pixels, print the "
                          "cpu_baseline object as one JSON line (no GPU is touched)")
@@ -467,6 +537,9 @@ def main():
     ap.add_argument("--no-reference-surface", action="store_true",
                     help="N = 1: skip the third timed pass that drives the model the way the reference's training.py:42-76 does (raw-order "
                          "batches, torch-expression MSE, torch.optim.AdamW), recorded as 'reference_surface'")
+    ap.add_argument("--no-dp-floor", action="store_true",
+                    help="N = 1: skip the short passes through the data-parallel gradient route (flat bucket + ShardedAdamW laid out for 1 / 2 / 4 / 8 "
+                         "ranks, no exchange), recorded as 'dp_floor' next to the xGMI link model")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1, --config s: skip the short child runs of --config l and --config 4k whose results are recorded as 'other_configs'")
     ap.add_argument("--dp", choices=["auto", "sharded", "a2a", "replicated"], default=os.environ.get("NVP_DP_MODE", "auto"),
@@ -477,7 +550,7 @@ def main():
     if args.cpu_baseline_only:
         if CPU_POLICY and torch.get_num_threads() != CPU_POLICY["threads"]:
             torch.set_num_threads(CPU_POLICY["threads"])
-        print(json.dumps(cpu_baseline_worker(args.cpu_sample, args.cpu_reps)))
+        print(json.dumps(cpu_baseline_worker(args.cpu_sample, args.cpu_reps, args.cpu_full)))
         return
 
     # ---- plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment): launch the N ranks ourselves, exactly as the
@@ -689,6 +762,25 @@ def main():
         finally:
             functional.TIMER = None
             harness.EARLY_ADAMW, functional.SIDE_WORK, data._side = keep
+    # ---- N = 1: the DP COMPUTE FLOOR.  What one GPU of an N-rank job computes per step, measured without any exchange: backward takes the
+    # gradient route (every gradient into the flat bucket instead of the in-flush optimizer), ShardedAdamW is laid out as rank 0 of N ranks and
+    # updates its 1/N shard.  An N-GPU step cannot be faster than this; what the exchange adds on top is the xGMI link model below.
+    dp_floor = None
+    if world == 1 and not multi and not args.no_dp_floor and args.steps > 0:
+        grids_ = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings]
+        dp_floor = {}
+        for n_emu in (1, 2, 4, 8):
+            torch.cuda.synchronize()
+            bk = parallel.GradBucket(parallel.unique_parameters(model), early=grids_, pad_to=parallel.ShardedAdamW.alignment(n_emu))
+            so = parallel.ShardedAdamW(bk, lr=1e-2, weight_decay=0.001, first=[model.sparse_grid.embeddings], emulate_world=n_emu)
+            st_ = (so, torch.optim.lr_scheduler.CosineAnnealingLR(so, T_max=max(total, 1), eta_min=1e-5), bk)
+            for _ in range(3):
+                one_step(st_)
+            dt_f, _ = timed(st_, args.steps)
+            dp_floor[str(n_emu)] = round(dt_f / args.steps * 1e3, 3)
+            del st_, so, bk
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
     # ---- third pass, N = 1: the REFERENCE SURFACE.  The model driven exactly as the reference's loop drives it (training.py:42-76):
     # batches in the sampler's raw order (no sorted_by_y promise), model(model_input)['model_out'], the torch-expression MSE on the
     # normalised ground truth (training.py:47-48, loss_functions.py:1-3), zero_grad / backward / step of a stock torch.optim.AdamW +
@@ -873,6 +965,27 @@ def main():
                                        ratio_to_headline_with_compat_optimizer=round(ref_surface["with_compat_optimizer"]["ms_per_step"] / ms_per_step, 3))
                                   if ref_surface else None),
         }
+        if dp_floor is not None:
+            # SURVEY 8(e) link model: xGMI is point-to-point, 7 links x ~153 GB/s per GPU.  Direct reduce-scatter / all-gather (every shard on the
+            # private link of its pair, all links concurrently): G / N bytes per link per phase; a ring at ONE link's speed: 2 (N-1)/N G / 153 GB/s.
+            G_, LINK = 4 * n_params, 153e9
+            pred = {}
+            for n_s, fl in dp_floor.items():
+                n_ = int(n_s)
+                if n_ == 1:
+                    continue
+                phase = G_ / n_ / LINK * 1e3
+                ring = 2 * (n_ - 1) / n_ * G_ / LINK * 1e3
+                pred[n_s] = {"per_link_bytes_per_phase": G_ // n_, "direct_ms_per_phase": round(phase, 3), "direct_two_phases_ms": round(2 * phase, 3),
+                             "ring_one_link_ms": round(ring, 3),
+                             "efficiency_upper_bound_exchange_hidden": round(ms_per_step / fl, 3),
+                             "efficiency_if_direct_exchange_fully_exposed": round(ms_per_step / (fl + 2 * phase), 3),
+                             "efficiency_if_ring_fully_exposed": round(ms_per_step / (fl + ring), 3)}
+            line["dp_floor"] = {"what": "ms per step of ONE GPU through the data-parallel route, laid out as rank 0 of N ranks, NO exchange: gradients into the flat "
+                                        "bucket (no in-flush optimizer), nvp_adamw_step on the own 1/N shard; an N-GPU step is >= this + the exposed exchange",
+                                "ms_per_step_by_world": dp_floor, "headline_ms_per_step": round(ms_per_step, 3), "gradient_bytes": G_,
+                                "xgmi_link_GBs": LINK / 1e9, "links_per_gpu": 7, "prediction_by_world": pred,
+                                "read_as": "scaling efficiency at N GPUs = headline_ms / measured N-GPU ms_per_step <= headline_ms / (ms_per_step_by_world[N] + exposed exchange)"}
         if multi:
             # what a rank spends between the end of backward and the end of the optimizer: exposed gradient exchange + its share
             # of AdamW (28 B per owned parameter at ~5.9 TB/s) + (sharded) the exposed part of the parameter all-gather

@@ -300,7 +300,11 @@ class ShardedAdamW(torch.optim.Optimizer):
         return 64 * max(world, 1)
 
     def __init__(self, bucket: GradBucket, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 algo: str = "reduce_scatter", update: Optional[Callable] = None, first: Optional[Iterable[torch.nn.Parameter]] = None):
+                 algo: str = "reduce_scatter", update: Optional[Callable] = None, first: Optional[Iterable[torch.nn.Parameter]] = None,
+                 emulate_world: int = 0):
+        """`emulate_world` (MEASUREMENT ONLY, single process without a group; bench.py's `dp_floor`): lay the pieces and shards out as rank 0
+        of a world of that size and update only that shard - the per-GPU compute of an N-rank step (gradient route + AdamW on 1/N of the
+        parameters) without any exchange.  The other (N-1)/N of the parameters are NOT updated: not a training mode."""
         if algo not in ("reduce_scatter", "all_to_all"):
             raise ValueError("algo must be 'reduce_scatter' or 'all_to_all'")
         super().__init__(bucket.params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
@@ -309,7 +313,10 @@ class ShardedAdamW(torch.optim.Optimizer):
         self.update = update or _hip_adamw_update
         self.world = dist.get_world_size() if _multi() else 1
         self.rank = dist.get_rank() if _multi() else 0
-        unit = self.alignment(self.world)
+        if emulate_world > 1 and (self.world > 1 or _multi()):
+            raise ValueError("emulate_world is a single-process measurement aid")
+        self.layout_world = int(emulate_world) if emulate_world > 1 else self.world
+        unit = self.alignment(self.layout_world)
         if bucket.padded % unit:
             raise ValueError(f"GradBucket must be padded to a multiple of {unit} elements (pad_to=ShardedAdamW.alignment(world))")
         dev = bucket.flat.device
@@ -332,7 +339,7 @@ class ShardedAdamW(torch.optim.Optimizer):
         # ---- this rank's shard of every piece, and where it lives in the (sharded) moment buffers
         self.shards, off = [], 0
         for a, b in self.pieces:
-            s = (b - a) // self.world
+            s = (b - a) // self.layout_world
             self.shards.append((a + self.rank * s, a + (self.rank + 1) * s, off))
             off += s
         self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)

@@ -26,14 +26,14 @@ def _free_port():
     return p
 
 
-def _batches(T, H, W):
-    """the same STEPS x 2 half-batches in every process"""
+def _batches(T, H, W, parts=2):
+    """the same STEPS x `parts` part-batches of N_HALF pixels in every process"""
     g = torch.Generator().manual_seed(11)
     video = torch.randint(0, 256, (T, H, W, 3), generator=g, dtype=torch.uint8)
     out = []
     for _ in range(STEPS):
         halves = []
-        for _ in range(2):
+        for _ in range(parts):
             ti = torch.randint(0, T, (N_HALF,), generator=g)
             pi = torch.randint(0, H * W, (N_HALF,), generator=g)
             coords = torch.stack((torch.linspace(0, 1, T)[ti], torch.div(pi, W, rounding_mode="floor").float() / (H - 1),
@@ -97,7 +97,7 @@ def _worker(rank, world, port, q):
     early = [model.keyframes_xy.params, model.keyframes_yt.params, model.keyframes_xt.params, model.sparse_grid.embeddings]
     bucket = parallel.GradBucket(parallel.unique_parameters(model), early=early, chunk_elems=3_000_000)   # pieces split tensors
     assert bucket._early_range is not None and len(bucket.early_chunks()) >= 8
-    mine = [halves[rank] for halves in _batches(T, H, W)]
+    mine = [halves[rank] for halves in _batches(T, H, W, world)]
     grads = _grads(model, mine[0], bucket)          # gradient-level check first (no AdamW in between)
     params = _run(model, mine, bucket)
     chk = torch.stack([p.double().sum() for p in params])
@@ -110,23 +110,25 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process_on_the_whole_batch():
+@pytest.mark.parametrize("world", [2, 8])
+def test_n_rank_step_equals_single_process_on_the_whole_batch(world):
+    """world 8 = the rank count of BASELINE.json configs[4]: eight ranks share the box's one GPU over gloo."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     dp_grads, dp = q.get(timeout=600)
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    # single process, whole batch (both halves concatenated), no bucket
+    # single process, whole batch (all parts concatenated), no bucket
     T, H, W = 8, 32, 32
     cfg = small_cfg(F=2, T=T, X=9, Y=7)
     model = _model(cfg)
-    whole = [tuple(torch.cat((a, b)) for a, b in zip(*halves)) for halves in _batches(T, H, W)]
-    # mean over the whole batch == average of the two half-batch means: gradients agree to summation order
+    whole = [tuple(torch.cat(parts) for parts in zip(*halves)) for halves in _batches(T, H, W, world)]
+    # mean over the whole batch == average of the part-batch means: gradients agree to summation order
     for a, b in zip(dp_grads, _grads(model, whole[0], None)):
         a = torch.from_numpy(a)
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
@@ -152,7 +154,7 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index, fast=False):
     T, H, W = 8, 32, 32
     # fast: a sparse grid large enough (8 M elements) for whole 3 M-element exchange pieces to lie inside it
     cfg = small_cfg(F=2, T=100, X=200, Y=200) if fast else small_cfg(F=2, T=T, X=9, Y=7)
-    mine = [halves[rank] for halves in _batches(T, H, W)]
+    mine = [halves[rank] for halves in _batches(T, H, W, world)]
     dev = f"cuda:{dev_index}"
     if fast:
         # the DEFAULT-ON fast path of the product: y-sorted batches with the promise flag -> level-major hand-over ->
@@ -212,9 +214,23 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index, fast=False):
         inorder = run(algo, early_update=False)           # NVP_DP_EARLY_UPDATE=0: update + all-gather in order on the compute stream
         for a, b in zip(sh, inorder):
             assert torch.equal(a, b), f"side-stream early update differs from the in-order one: max {float((a - b).abs().max())}"
-    # world 2: a + b is order independent, the AdamW kernel is element-wise -> the sharded path is BIT-identical to all-reduce + full AdamW
-    for a, b in zip(rep, sh):
-        assert torch.equal(a, b), f"sharded ({algo}) and replicated parameters differ: max {float((a - b).abs().max())}"
+    if world == 2:
+        # world 2: a + b is order independent, the AdamW kernel is element-wise -> the sharded path is BIT-identical to all-reduce + full AdamW
+        for a, b in zip(rep, sh):
+            assert torch.equal(a, b), f"sharded ({algo}) and replicated parameters differ: max {float((a - b).abs().max())}"
+    else:
+        # more than two addends: gloo's all-reduce, its reduce-scatter and the rank-order sum of the all_to_all form add the ranks' fp32
+        # gradients in different orders.  A gradient sum off by an ulp moves AdamW's m / (sqrt(v) + eps) by ~1e-6 (|dp| <= lr * 1e-4 with
+        # margin); only where a sum CANCELS to ~0 can the normalised step flip sign (|dp| <= 2 lr per step) - rare.  A plumbing error (a
+        # shard missing from a sum, a shifted boundary) changes whole 1/world-th parts of a piece by O(lr): caught by the fraction bound.
+        lr, n_bad, n_all, worst = 1e-2, 0, 0, 0.0
+        for a, b in zip(rep, sh):
+            d = (a - b).abs()
+            n_bad += int((d > lr * 1e-4).sum())
+            n_all += d.numel()
+            worst = max(worst, float(d.max()))
+        assert n_bad <= 1e-3 * n_all, f"sharded ({algo}) vs replicated at world {world}: {n_bad} of {n_all} parameters differ by more than lr * 1e-4"
+        assert worst <= 2 * lr * STEPS * 1.01, worst
     chk = torch.stack([p.double().sum() for p in sh])
     gathered = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(gathered, chk.to(dev) if backend == "nccl" else chk)
@@ -225,16 +241,17 @@ def _sharded_worker(rank, world, port, q, algo, backend, dev_index, fast=False):
 
 
 def _spawn_sharded(algo, backend, devs, fast=False):
+    world = len(devs)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, algo, backend, devs[r], fast)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, algo, backend, devs[r], fast)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=900)
         assert p.exitcode == 0
-    assert sorted(q.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(r, "ok") for r in range(world)]
 
 
 @pytest.mark.parametrize("algo", ["sharded", "a2a"])
@@ -250,6 +267,16 @@ def test_two_rank_default_fast_path_sorted_batches_sparse_first(algo):
     two-call scatter firing StepHooks.sparse_ready -> ShardedAdamW.start_first (checked: once per step), make_dp-style `first=`,
     the two-event side-stream shard update - bit-identical to the replicated path AND to NVP_DP_EARLY_UPDATE=0."""
     _spawn_sharded(algo, "gloo", (0, 0), fast=True)
+
+
+@pytest.mark.parametrize("algo", ["sharded", "a2a"])
+def test_eight_rank_layout_on_one_gpu_sparse_first(algo):
+    """The 8-rank layout of BASELINE.json configs[4] on HIP tensors (eight ranks share cuda:0 over gloo): 64 * 8-element shard alignment,
+    piece boundaries inside the grids, seven-peer reduce-scatter / all_to_all + rank-order sum, `first=` pieces exchanged while the dense
+    planes scatter, the two-event side-stream shard update, nvp_adamw_step on 1/8 shards, in-place parameter all-gather.  Replicas
+    bit-identical to each other, the side-stream update bit-identical to the in-order one, sharded vs replicated to the summation-order
+    rule in _sharded_worker."""
+    _spawn_sharded(algo, "gloo", (0,) * 8, fast=True)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (RCCL refuses two ranks on one device)")
