@@ -235,7 +235,7 @@ def _cpu_worker(n_sample: int, reps: int, threads: int, full: bool, timeout: int
     return json.loads(lines[-1])
 
 
-def cpu_baseline(n_sample: int, reps: int = 2):
+def cpu_baseline(n_sample: int, reps: int = 2, full: bool = True):
     """The cpu_baseline leg.  The oracle's forward + backward is timed under a SWEEP of thread
     counts - 8, 16, 32, 64 and every physical core, each in a process of its own, pinned close - because on the GPU hosts (2 x 64 cores, up
     to four tenants) the all-cores figure is a fork-join artefact: ATen parallelises every small element-wise op over all 128 threads across
@@ -256,7 +256,7 @@ def cpu_baseline(n_sample: int, reps: int = 2):
     best_k = max(sweep, key=lambda k: sweep[k]["extrapolated"]["mpx_s"])
     best = sweep[best_k]
     final, measured_full = best, False
-    if best["extrapolated"]["seconds_per_full_step"] < 60.0:
+    if full and best["extrapolated"]["seconds_per_full_step"] < 60.0:
         try:
             final = _cpu_worker(n_sample, 1, best_k, True, 900)
             measured_full = final.get("full_step") is not None

@@ -31,30 +31,29 @@ def install_optimizer() -> None:
     from .optim import AdamW as NvpAdamW
 
     class _Routing(type(stock)):
-        # isinstance(opt, torch.optim.AdamW) stays true for the routed optimizer (LR-scheduler wrappers, checkpoint loaders, Lightning)
+        # isinstance(opt, torch.optim.AdamW) stays true for whatever the routed call returned - the one-launch optimizer or a plain stock
+        # instance (LR-scheduler wrappers, checkpoint loaders, Lightning)
         def __instancecheck__(cls, obj):
-            return isinstance(obj, NvpAdamW) or type.__instancecheck__(cls, obj)
+            return isinstance(obj, (NvpAdamW, stock)) or type.__instancecheck__(cls, obj)
 
     class AdamW(stock, metaclass=_Routing):
         """torch.optim.AdamW, routed to nvp_amd.optim.AdamW for fp32 HIP parameters (nvp_amd.compat.install_optimizer).  A SUBCLASS of the
-        stock class - subclassing it, isinstance checks, __name__ / pickle lookups keep working; `foreach` / `fused` are accepted and
-        ignored on the routed path (the routed step is one launch over all tensors already)."""
+        stock class, so subclassing it, isinstance / issubclass checks and __name__ lookups keep working - but never instantiated itself:
+        the call returns either the one-launch optimizer or a PLAIN instance of the stock class (CPU parameters, param-group dicts,
+        amsgrad, ...), which pickles and deep-copies like any stock optimizer.  `foreach` / `fused` are accepted and ignored on the
+        routed path (the routed step is one launch over all tensors already)."""
 
-        def __new__(cls, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
-            if cls is AdamW:                                            # (subclasses of this class keep the stock behaviour)
+        def __new__(cls, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
+            if cls is AdamW and params is not None:                     # (subclasses of this class keep the stock behaviour)
                 plist = list(params)
                 plain = all(torch.is_tensor(p) for p in plist)          # (param groups given as dicts keep the stock class)
                 ok = (plain and plist and all(p.is_cuda and p.dtype == torch.float32 for p in plist)
                       and not any(kw.get(k) for k in ("amsgrad", "maximize", "capturable", "differentiable")) and isinstance(lr, float))
                 if ok:
-                    return NvpAdamW(plist, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)      # not an instance of cls: __init__ is not re-run
-                self = object.__new__(cls)
-                self._nvp_params = plist                                # a generator was consumed above: hand the list to __init__
-                return self
-            return object.__new__(cls)
-
-        def __init__(self, params, *a, **kw):
-            super().__init__(self.__dict__.pop("_nvp_params", params), *a, **kw)
+                    return NvpAdamW(plist, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+                return stock(plist, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+            # neither return value above is an instance of cls, so type.__call__ does not run __init__ on it again
+            return object.__new__(cls)                                  # subclasses; copyreg's argument-less reconstruction (pickle, deepcopy)
 
     AdamW.__name__ = AdamW.__qualname__ = "AdamW"
     AdamW.__module__ = stock.__module__

@@ -425,12 +425,13 @@ def materialises_nothing(model, temporal_interp: bool) -> bool:
     frame can go through one call whatever its size (harness.render_frame); otherwise the call writes the latent [n, D] and callers bound n."""
     if temporal_interp or not FUSED_FWD:
         return False
-    try:
-        sh = _sparse_shape(model.sparse_grid._grid())
-        return int(L.load().nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
-                                                          C.byref(model.keyframes_xt.levels), C.byref(sh))) == 1      # (2: fused, but the latent tensor is its workspace)
-    except Exception:
-        return False
+    sg = model.sparse_grid
+    # the shape from the module's attributes: sg._grid() would run the whole x2 upsample pass (and allocate [T, 2X, 2Y, F]) only to be measured
+    T_, X_, Y_, F_ = (int(v) for v in sg.embeddings.shape)
+    up = 2 if getattr(sg, "upsample", False) else 1
+    sh = L.SparseShape(T_, X_ * up, Y_ * up, F_)
+    return int(L.load().nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
+                                                      C.byref(model.keyframes_xt.levels), C.byref(sh))) == 1      # (2: fused, but the latent tensor is its workspace)
 
 
 class NVPFused(torch.autograd.Function):

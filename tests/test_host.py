@@ -4,6 +4,7 @@ reference's (names, state_dict keys, init stream, loud failure without a HIP dev
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -350,16 +351,41 @@ def test_bench_plain_multi_gpu_launch_needs_the_devices():
 
 
 def test_bench_cpu_baseline_worker_reports_its_thread_and_numa_policy():
-    """VERDICT r3 item 9: the cpu_baseline leg runs in its own process under a stated policy (one thread per physical core, bound;
-    memory interleaved across NUMA nodes where there are several) and reports it next to the rate."""
+    """every cpu_baseline worker runs in its own process under a stated policy (--cpu-threads hardware threads,
+    one per physical core in core order, bound; memory interleaved where the cores span NUMA nodes) and reports it next to its timings: the
+    fixed part of a step (1-pixel batch) apart from the sample, and the full-N step extrapolated from the per-pixel part only."""
     import json
-    r = _run_bench(["--cpu-baseline-only", "--cpu-sample", "2048", "--cpu-reps", "1"], {})
+    r = _run_bench(["--cpu-baseline-only", "--cpu-sample", "2048", "--cpu-reps", "1", "--cpu-threads", "2"], {})
     assert r.returncode == 0, r.stderr[-1500:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["kind"] == "port" and d["unit"] == "Mpixels/s" and d["value"] > 0
     pol = d["policy"]
-    assert pol["threads"] == d["cores"] >= 1 and pol["physical_cores"] <= pol["allowed_cpus"]
+    assert pol["threads"] == d["cores"] == min(2, pol["physical_cores"]) and pol["physical_cores"] <= pol["allowed_cpus"]
     assert "memory" in pol and "binding" in pol and any("get_num_threads" in ln for ln in d["torch_parallel_info"])
+    assert d["seconds_fixed_part"] > 0 and len(d["seconds_per_sample_step"]) == 1 and d["full_step"] is None
+    n_px = 1245184
+    want = d["seconds_fixed_part"] + max(d["seconds_per_sample_step"][0] - d["seconds_fixed_part"], 0.0) * n_px / 2048
+    assert abs(d["extrapolated"]["seconds_per_full_step"] - want) <= 0.02 * want + 0.02
+    assert abs(d["extrapolated"]["mpx_s"] - n_px / d["extrapolated"]["seconds_per_full_step"] / 1e6) < 1e-3
+
+
+def test_bench_cpu_baseline_sweep_picks_the_best_thread_count():
+    """The parent leg: one worker per thread count (8 / 16 / 32 / 64 / all physical cores, as far as the host has them), value = the best
+    one's rate, the all-cores figure kept beside it (full-N step disabled here: 30 s)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+        d = bench.cpu_baseline(2048, reps=1, full=False)
+    finally:
+        sys.argv = argv
+    phys = bench.physical_cores()
+    assert d["kind"] == "port" and d["unit"] == "Mpixels/s" and d["value"] > 0
+    assert set(d["sweep"]) == {str(k) for k in (8, 16, 32, 64) if k < phys} | {str(phys)}
+    assert d["all_cores"]["threads"] == phys and d["cores"] == d["best"]["threads"]
+    assert d["value"] == max(w["mpx_s_extrapolated_to_full_N"] for w in d["sweep"].values()) and d["best"]["full_step"] is None
 
 
 def test_compat_optimizer_routing_is_opt_in_and_falls_back_to_the_stock_class():
@@ -380,10 +406,23 @@ def test_compat_optimizer_routing_is_opt_in_and_falls_back_to_the_stock_class():
         assert isinstance(torch.optim.AdamW, type) and issubclass(torch.optim.AdamW, stock) and torch.optim.AdamW.__name__ == "AdamW"
         assert isinstance(opt, torch.optim.AdamW) and isinstance(opt2, torch.optim.AdamW)
         opt.zero_grad(); lin(torch.ones(2, 4)).sum().backward(); opt.step()                  # a working optimizer, generator argument and all
+        # what the fallback path returns must pickle and deep-copy like any stock optimizer (checkpoint code does both)
+        import copy
+        import pickle
+        assert type(opt) is stock and type(opt2) is stock
+        for o in (opt, opt2):
+            back = pickle.loads(pickle.dumps(o))
+            assert type(back) is stock and back.defaults == o.defaults and len(back.param_groups[0]["params"]) == 2
+            dup = copy.deepcopy(o)
+            assert type(dup) is stock and dup.state_dict()["param_groups"] == o.state_dict()["param_groups"]
+        opt_g = torch.optim.AdamW([{"params": [lin.weight]}, {"params": [lin.bias], "lr": 1e-4}], lr=1e-3)      # param-group dicts: stock
+        assert type(opt_g) is stock and opt_g.param_groups[1]["lr"] == 1e-4 and type(copy.deepcopy(opt_g)) is stock
 
         class Mine(torch.optim.AdamW):
             pass
-        assert isinstance(Mine(lin.parameters(), lr=1e-3), stock)
+        mine = Mine(lin.parameters(), lr=1e-3)
+        assert isinstance(mine, stock) and type(mine) is Mine and mine.defaults["lr"] == 1e-3
+        assert type(copy.deepcopy(mine)) is Mine                                             # copyreg rebuilds through cls.__new__(cls)
         from nvp_amd.optim import AdamW as NvpAdamW
         assert isinstance(NvpAdamW.__new__(NvpAdamW), torch.optim.AdamW)                     # what a routed call returns passes the same check
     finally:

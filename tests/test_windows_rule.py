@@ -21,6 +21,15 @@ def test_window_rule():
     assert len(window_verdicts([0.036], [0.03], [hot])) == 1                     # leaves the twin
     assert len(window_verdicts([0.07], [0.07], [hot])) == 1                      # with the twin but outside 2 x envelope
     assert [w for w, _ in window_verdicts([0.0, 0.5, 0.0], [0.0] * 3, [0.0, 0.1, 0.0])] == [1]
+    # absolute guards - a gap above 0.1 dB is a violation however hot the window and however close the twin ...
+    bad = window_verdicts([0.15], [0.15], [0.2])
+    assert len(bad) == 1 and "absolute ceiling" in bad[0][1]
+    assert window_verdicts([0.09], [0.088], [0.05]) == []
+    # ... and the tolerant rule may cover at most a quarter of the schedule
+    env = [0.03] * 6 + [0.001] * 14
+    bad = window_verdicts([0.001] * 20, [0.001] * 20, env)
+    assert len(bad) == 1 and bad[0][0] == -1 and "6 of 20 windows are hot" in bad[0][1]
+    assert window_verdicts([0.001] * 20, [0.001] * 20, [0.03] * 5 + [0.001] * 15) == []
 
 
 def test_oracle_walk_is_reproducible(tmp_path):

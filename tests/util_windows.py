@@ -178,20 +178,29 @@ def hip_walk(out_dir: str, free: bool = False):
             "lib": _lib.LIB_PATH, "mfma_products": int(_lib.load().nvp_mlp_mfma_products())}
 
 
-def window_verdicts(gp, gt, env, abs_bound=0.02, calm=0.01, twin_margin=0.005, env_factor=2.0):
+def window_verdicts(gp, gt, env, abs_bound=0.02, calm=0.01, twin_margin=0.005, env_factor=2.0, hot_cap=0.1, max_hot_fraction=0.25):
     """The rule of the windowed test, per window end (all in dB): gp = |product - oracle|, gt = |fp32-MFMA twin - oracle|, env = the
     in-run envelope (largest |1-ulp oracle - oracle| over the controls).
       gp <= 0.02: north_star's bound holds - nothing else is asked, in any window;
       gp  > 0.02 in a calm window (env <= 0.01: the oracle reproduces itself there): a violation;
       gp  > 0.02 in a hot window (env > 0.01: the oracle does NOT reproduce itself to 0.01 dB there): the product is held to what
-                 fp32 arithmetic shows in the same window - gp <= gt + 0.005 and gp <= 2 env - else a violation.
+                 fp32 arithmetic shows in the same window - gp <= gt + 0.005 and gp <= 2 env - else a violation;
+      ADVICE r5: the hot-window tolerance scales with the run's OWN envelope and the twin shares the scatter / AdamW / gather code with the
+      product, so a defect common to both could ride a drifting envelope.  Two absolute guards: gp <= hot_cap (0.1 dB) in ANY window, and
+      at most max_hot_fraction (a quarter) of the windows may be hot at all - most of the schedule is held to the plain 0.02 dB
+      (measured: 1 hot window of 20 for seeds 7, 8, 9).
     -> list of (window index, cause) for every violation; the cause names the arithmetic (fp16x2 split) only when the fp32-MFMA twin
     stays inside the bound the product left."""
     bad = []
+    n_hot = sum(1 for e in env if e > calm)
+    if len(env) >= 4 and n_hot > max_hot_fraction * len(env):
+        bad.append((-1, f"{n_hot} of {len(env)} windows are hot (envelope > {calm}): the tolerant rule would cover more than {max_hot_fraction:.0%} of the schedule"))
     for w, (p, t, e) in enumerate(zip(gp, gt, env)):
         if p <= abs_bound:
             continue
-        if e <= calm:
+        if p > hot_cap:
+            bad.append((w, f"product gap {p:.4f} > the absolute ceiling {hot_cap} dB (envelope {e:.4f}, twin gap {t:.4f})"))
+        elif e <= calm:
             bad.append((w, f"calm window (envelope {e:.4f}): product gap {p:.4f} > {abs_bound}; fp32-MFMA twin gap {t:.4f} -> "
                            + ("the twin leaves too: HIP-vs-ATen fp32 summation order, not the fp16x2 split" if t > abs_bound else
                               "the twin stays: the fp16x2 split-operand arithmetic is the cause")))

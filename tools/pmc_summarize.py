@@ -10,7 +10,7 @@ tag = sys.argv[1]
 config = sys.argv[2] if len(sys.argv) > 2 else "s"           # bench.py --config this pass was collected with
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"mlp_fwd_kernel": "nvp_mlp_fwd", "mlp_fwd_b3_kernel<true, 2>": "nvp_encode_mlp_fwd", "mlp_fwd_b3_kernel<true, 4>": "nvp_encode_mlp_fwd",
-        "mlp_fwd_b3_kernel<false, 2>": "nvp_encode_mlp_fwd", "mlp_fwd_b3_kernel": "nvp_mlp_fwd", "mlp_dw_group_kernel": "nvp_mlp_bwd_dw", "mlp_dw_glds_kernel": "nvp_mlp_bwd_dw",
+        "mlp_fwd_b3_kernel<false, 2>": "nvp_encode_mlp_fwd", "mlp_fwd_b3_kernel<false, 4>": "nvp_encode_mlp_fwd", "mlp_fwd_b3_kernel": "nvp_mlp_fwd", "mlp_dw_group_kernel": "nvp_mlp_bwd_dw", "mlp_dw_glds_kernel": "nvp_mlp_bwd_dw",
         "csort_hist_kernel": "nvp_encode_bwd", "csort_scan_kernel": "nvp_encode_bwd", "csort_tilesum_kernel": "nvp_encode_bwd", "csort_scatter_kernel": "nvp_encode_bwd", "mlp_fwd_b3r_kernel": "nvp_mlp_fwd", "mlp_bwd_b3_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_b3r_kernel": "nvp_mlp_bwd_dx", "encode_fwd_lds_kernel": "nvp_encode_fwd", "mlp_bwd_dx_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_b3_kernel": "nvp_mlp_bwd_dx", "mlp_bwd_dz_b3r_kernel": "nvp_mlp_bwd_dx", "mlp_dw_pair_kernel": "nvp_mlp_bwd_dw",
         "mlp_dw_kernel": "nvp_mlp_bwd_dw", "dw_reduce_kernel": "nvp_mlp_bwd_dw", "dw_records_kernel": "nvp_mlp_bwd_dw", "encode_fwd_kernel": "nvp_encode_fwd",
         "band_kernel": "nvp_encode_bwd", "permute_kernel": "nvp_encode_bwd", "sparse_band_kernel": "nvp_encode_bwd",
