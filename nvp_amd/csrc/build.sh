@@ -5,7 +5,8 @@
 #                              gather, forward weight ring, per-wave backward chain, merged / paired / grouped / DMA-fed dW jobs) and the
 #                              NVP_* environment switches that select them; tests/test_gpu_parity.py::test_kernel_variants_are_bit_identical
 #                              loads it through NVP_HIP_LIB and compares every variant with the product library bit for bit.
-#                              NVP_SKIP_EXPERIMENTS=1 skips it.
+#                              Built ONLY with NVP_BUILD_EXPERIMENTS=1 (round 6: __graft_entry__.build() compiles the product and its twin;
+#                              the two tests that need this library skip when it is absent or was built from other sources).
 # and its all-fp32-MFMA twin
 # libnvp_hip_fp32mfma.so (same sources, -DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0: every MLP GEMM on v_mfma_f32_32x32x2_f32).
 # The twin is TEST INFRASTRUCTURE: tests/test_gpu_zz_trajectories.py trains both builds on identical batches to bound what the
@@ -45,13 +46,15 @@ build_lib() {
   done
   if [ $rc -ne 0 ]; then rm -f "$out"; exit 1; fi
   "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$out"
+  echo "$SRC_HASH" > "$out.srchash"      # which sources this library was built from (tests compare the experiments library's with the product's)
   echo "built $(pwd)/$out"
 }
+SRC_HASH=$(cat *.hip *.h ../../include/*.h | sha256sum | cut -c1-16)
 
 build_lib libnvp_hip.so obj "" "$SRCS_PRODUCT"
 if [ -z "${NVP_SKIP_TWIN:-}" ]; then
   build_lib libnvp_hip_fp32mfma.so obj_fp32mfma "-DNVP_FWD_B3=0 -DNVP_BWD_B3=0 -DNVP_DW_B3=0" "$SRCS_PRODUCT"
 fi
-if [ -z "${NVP_SKIP_EXPERIMENTS:-}" ]; then
+if [ -n "${NVP_BUILD_EXPERIMENTS:-}" ]; then
   build_lib libnvp_hip_experiments.so obj_experiments "-DNVP_EXPERIMENTS=1" "$SRCS_EXPERIMENTS"
 fi

@@ -167,25 +167,9 @@ __device__ __forceinline__ void mac_parts(f32x16& acc, const u32x4 (&a)[kP], con
 #else
 #define NVP_WSTRIDE(x) (x)
 #endif
-#ifndef NVP_STEP_PF_ALL
-#define NVP_STEP_PF_ALL 0        // experiment: all 4 kP operand quads of a k-step requested before its first MFMA (32 registers in flight)
-#endif
 template <bool PF = true>
 __device__ __forceinline__ void step_b3(f32x16 (&acc)[4], const u32x4* __restrict__ w, const BOp& b, int lane) {
     const unsigned ul = (unsigned)lane;
-#if NVP_STEP_PF_ALL
-    if (PF) {
-        u32x4 q[4][kP];
-#pragma unroll
-        for (int T = 0; T < 4; ++T)
-#pragma unroll
-            for (int k = 0; k < kP; ++k) q[T][k] = (w + (T * kP + k) * 64)[ul];
-        NVP_CHAIN_FENCE();
-#pragma unroll
-        for (int T = 0; T < 4; ++T) mac_parts(acc[T], q[T], b);
-        return;
-    }
-#endif
     u32x4 a[2][kP];
     if (PF) {
 #pragma unroll
@@ -251,15 +235,6 @@ __device__ __forceinline__ void chain_in8(float (&x)[8], const f32x16 (&hin)[4],
     for (int q = 0; q < 8; ++q) x[q] = hin[c >> 1][8 * (c & 1) + q];
 }
 
-// one k-step's operand quads (all four output tiles) requested at once
-struct StepOps { u32x4 q[4][kP]; };
-__device__ __forceinline__ void load_step(StepOps& o, const u32x4* __restrict__ w, int lane) {
-    const unsigned ul = (unsigned)lane;
-#pragma unroll
-    for (int T = 0; T < 4; ++T)
-#pragma unroll
-        for (int k = 0; k < kP; ++k) o.q[T][k] = (w + (T * kP + k) * 64)[ul];
-}
 // experiment: wave priority around the MFMA chains (two waves share a SIMD; whose instructions win when both are ready?)
 //   1: a wave inside a chain outranks its partner (keeps the matrix pipe fed), 2: the opposite (element-wise stages outrank chains)
 #ifndef NVP_MFMA_PRIO
@@ -275,86 +250,14 @@ __device__ __forceinline__ void load_step(StepOps& o, const u32x4* __restrict__ 
 #define NVP_CHAIN_ENTER()
 #define NVP_CHAIN_LEAVE()
 #endif
-#ifndef NVP_PF_DEPTH
-#define NVP_PF_DEPTH 2           // NVP_CHAIN_PF_STEP == 3: k-steps of weights in flight
-#endif
-#ifndef NVP_CHAIN_PF_STEP
-#define NVP_CHAIN_PF_STEP 0      // experiment: a whole k-step of weights requested one k-step ahead (64 operand registers double-buffered)
-#endif
 
-// 8 k-steps over the previous layer's D registers, scaled by s.  post(c) runs after k-step c's MFMAs have been issued (default
-// prefetch scheme only): the forward kernel issues the PREVIOUS layer's stream stores there, a few per k-step, so that no weight
-// fetch ever has a burst of sixteen stores ahead of it in the (in-order) vector-memory return queue.
+// 8 k-steps over the previous layer's D registers, scaled by s.  post(c) runs after k-step c's MFMAs have been issued (independent work
+// a caller wants in the shadow of the chain).  Weight prefetch: step_b3's - the next output tile's operand quads are requested while the
+// current tile's MFMAs issue.  The schemes measured against it in rounds 4-5 (a whole k-step one to three steps ahead, tile pairs, all
+// quads of a step at once; all bit-identical, none faster: HISTORY.md / DESIGN.md 4.1) were removed from this header in round 6; the
+// last commit that carries them is named in HISTORY.md.
 template <bool PF = true, typename Post>
 __device__ __forceinline__ void chain_h_b3(f32x16 (&acc)[4], const f32x16 (&hin)[4], const float s, const u32x4* __restrict__ w, int lane, Post post) {
-#if NVP_CHAIN_PF_STEP == 1
-    if (PF) {
-        StepOps o[2];
-        load_step(o[0], w, lane);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c + 1 < 8) load_step(o[(c + 1) & 1], w + NVP_WSTRIDE((c + 1) * kB3StepQuads), lane);
-            float x[8];
-            chain_in8(x, hin, c);
-            BOp b;
-            split8(x, s, b);
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[c & 1].q[T], b);
-        }
-        return;
-    }
-#elif NVP_CHAIN_PF_STEP == 3
-    if (PF) {
-        // NVP_PF_DEPTH whole k-steps of weights in flight ahead of the one being multiplied (32 operand registers each): for kernels
-        // built at ONE wave per SIMD (512 registers), where nothing but the wave's own prefetch distance hides the ~700-cycle L2 round trip
-        constexpr int DPT = NVP_PF_DEPTH;
-        StepOps o[DPT + 1];
-#pragma unroll
-        for (int c = 0; c < DPT && c < 8; ++c) load_step(o[c], w + NVP_WSTRIDE(c * kB3StepQuads), lane);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (c + DPT < 8) load_step(o[(c + DPT) % (DPT + 1)], w + NVP_WSTRIDE((c + DPT) * kB3StepQuads), lane);
-            float x[8];
-            chain_in8(x, hin, c);
-            BOp b;
-            split8(x, s, b);
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[c % (DPT + 1)].q[T], b);
-        }
-        return;
-    }
-#elif NVP_CHAIN_PF_STEP == 2
-    if (PF) {
-        // tile PAIRS: while pair p (two output tiles of k-step p >> 1) issues its MFMAs, pair p + 1 - possibly of the next
-        // k-step - is in flight: twice the prefetch distance of step_b3 for 16 more operand registers
-        const unsigned ul = (unsigned)lane;
-        u32x4 a[2][2][kP];
-        auto load_pair = [&](int p, int buf) {
-            const u32x4* wp = w + NVP_WSTRIDE((p >> 1) * kB3StepQuads) + (p & 1) * 2 * kP * 64;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int k = 0; k < kP; ++k) a[buf][t][k] = (wp + (t * kP + k) * 64)[ul];
-        };
-        load_pair(0, 0);
-        BOp b;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            if (p + 1 < 16) load_pair(p + 1, (p + 1) & 1);
-            if ((p & 1) == 0) {
-                float x[8];
-                chain_in8(x, hin, p >> 1);
-                split8(x, s, b);
-            }
-            NVP_CHAIN_FENCE();
-            mac_parts(acc[2 * (p & 1)], a[p & 1][0], b);
-            mac_parts(acc[2 * (p & 1) + 1], a[p & 1][1], b);
-        }
-        return;
-    }
-#endif
     NVP_CHAIN_ENTER();
 #pragma unroll
     for (int c = 0; c < 8; ++c) {

@@ -8,36 +8,14 @@
 #include "mlp_b3.h"
 #include "encode_tile.h"      // in-wave tile gather (FMA contraction off inside, restored after)
 
-#ifndef NVP_B3_ZUNROLL
-#define NVP_B3_ZUNROLL 1        // straight-line latent chain for the 8-step (nvp_s) case: 1.854 vs 1.879 ms
-#endif
-#ifndef NVP_FWD_LATE_STORES
-#define NVP_FWD_LATE_STORES 0  // 1: the h0 / h1 / h2 stream stores are issued inside the FOLLOWING chain, four per second k-step (bit-identical; not faster)
-#endif
-#ifndef NVP_FWD_SYNC
-#define NVP_FWD_SYNC 0          // experiment: s_barrier at every layer start keeps the workgroup's four waves in phase (their weight loads then hit in L1)
-#endif
-#if NVP_FWD_SYNC
-#define NVP_LAYER_SYNC() asm volatile("s_barrier" ::: "memory")
-#else
-#define NVP_LAYER_SYNC()
-#endif
-
 namespace {
 
 
 // `ns` k-steps over the latent tile in LDS (PTM4: row-group rg = rows 4rg..4rg+3 of pixel j at zl[rg*32 + j]);
 // step s, lane half h consumes rows 16 s + 8 h .. + 7 = row-groups 4s + 2h, 4s + 2h + 1
-// zg / rg_end (optional, NVP_FWD_LATE_STORES): the latent tensor's tile - the two row-groups this lane reads anyway are written out from
-// here (every row-group of the tile is read by exactly one lane of one k-step), instead of a 15-KB store burst in front of the first layer
-__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane,
-                                                float4* __restrict__ zg = nullptr, int rg_end = 0) {
+__device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* __restrict__ zl, int s, const float sc, const u32x4* __restrict__ w, int j, int h, int lane) {
     const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
     const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
-    if (zg) {
-        if (4 * s + 2 * h < rg_end) zg[(4 * s + 2 * h) * 32 + j] = t0;
-        if (4 * s + 2 * h + 1 < rg_end) zg[(4 * s + 2 * h + 1) * 32 + j] = t1;
-    }
     const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
     BOp b;
     split8(x, sc, b);
@@ -47,75 +25,23 @@ __device__ __forceinline__ void chain_z_b3_step(f32x16 (&acc)[4], const float4* 
 // sc: the pixel's operand scale (mlp_b3.h; 1 for bf16 x 3).  post(s) (optional) runs after k-step s of the straight-line 8-step path only -
 // independent VALU work the caller wants issued in the shadow of that step's MFMAs; returns true when post ran for every step.
 template <typename Post>
-__device__ __forceinline__ bool chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
-                                           float4* __restrict__ zg, int rg_end, Post post) {
+__device__ __forceinline__ bool chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane, Post post) {
     const int j = lane & 31, h = lane >> 5;
-#if NVP_B3_ZUNROLL
-    if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch)
-#if NVP_CHAIN_PF_STEP == 3
-        constexpr int DPT = NVP_PF_DEPTH;
-        StepOps o[DPT + 1];
-#pragma unroll
-        for (int s = 0; s < DPT && s < 8; ++s) load_step(o[s], w + NVP_WSTRIDE(s * kB3StepQuads), lane);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s + DPT < 8) load_step(o[(s + DPT) % (DPT + 1)], w + NVP_WSTRIDE((s + DPT) * kB3StepQuads), lane);
-            const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
-            const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
-            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-            BOp b;
-            split8(x, sc, b);
-            NVP_CHAIN_FENCE();
-#pragma unroll
-            for (int T = 0; T < 4; ++T) mac_parts(acc[T], o[s % (DPT + 1)].q[T], b);
-        }
-        return false;
-#elif NVP_CHAIN_PF_STEP == 2
-        // tile pairs, one pair of operand quads in flight ahead of the pair being multiplied (see chain_h_b3)
-        const unsigned ul = (unsigned)lane;
-        u32x4 a[2][2][kP];
-        auto load_pair = [&](int p, int buf) {
-            const u32x4* wp = w + NVP_WSTRIDE((p >> 1) * kB3StepQuads) + (p & 1) * 2 * kP * 64;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int k = 0; k < kP; ++k) a[buf][t][k] = (wp + (t * kP + k) * 64)[ul];
-        };
-        load_pair(0, 0);
-        BOp b;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            if (p + 1 < 16) load_pair(p + 1, (p + 1) & 1);
-            if ((p & 1) == 0) {
-                const int s = p >> 1;
-                const float4 t0 = zl[(4 * s + 2 * h) * 32 + j];
-                const float4 t1 = zl[(4 * s + 2 * h + 1) * 32 + j];
-                const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                split8(x, sc, b);
-            }
-            NVP_CHAIN_FENCE();
-            mac_parts(acc[2 * (p & 1)], a[p & 1][0], b);
-            mac_parts(acc[2 * (p & 1) + 1], a[p & 1][1], b);
-        }
-        return false;
-#else
+    if (ns == 8) {                               // nvp_s: straight-line code (wave-uniform branch): 1.854 vs 1.879 ms for the rolled loop
         NVP_CHAIN_ENTER();
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end); post(s); }
+        for (int s = 0; s < 8; ++s) { chain_z_b3_step(acc, zl, s, sc, w, j, h, lane); post(s); }
         NVP_CHAIN_LEAVE();
         return true;
-#endif
     }
-#endif
     NVP_CHAIN_ENTER();
 #pragma unroll 1
-    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane, zg, rg_end);
+    for (int s = 0; s < ns; ++s) chain_z_b3_step(acc, zl, s, sc, w, j, h, lane);
     NVP_CHAIN_LEAVE();
     return false;
 }
-__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane,
-                                           float4* __restrict__ zg = nullptr, int rg_end = 0) {
-    chain_z_b3(acc, zl, ns, sc, w, lane, zg, rg_end, [](int) {});
+__device__ __forceinline__ void chain_z_b3(f32x16 (&acc)[4], const float4* __restrict__ zl, int ns, const float sc, const u32x4* __restrict__ w, int lane) {
+    chain_z_b3(acc, zl, ns, sc, w, lane, [](int) {});
 }
 
 // Stage this wave's latent tile into its LDS region (as stage_z, mlp_chain.h) and return the largest |z| this lane saw: every
@@ -144,9 +70,6 @@ __device__ __forceinline__ float stage_z_absmax(float4* __restrict__ zl, const f
 
 // k-steps [s0, s1) straight from the latent tensor (wide latents: rows the LDS tile does not hold); row-groups at or
 // beyond rg_end (the tensor's rows / 4) read as zero - the tile of the LAST pixels is followed by nothing
-#ifndef NVP_ZG_PREFETCH
-#define NVP_ZG_PREFETCH 0        // experiment (wide latents): the tensor rows of k-step s + 1 requested before k-step s is multiplied, the first step's before the LDS part: measured neutral (profiles/r04_ab_nvpl_zg_prefetch.txt)
-#endif
 struct ZgRows { float4 t0, t1; };
 __device__ __forceinline__ ZgRows zg_rows(const float4* __restrict__ zg, int s, int rg_end, int j, int h) {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -156,22 +79,17 @@ __device__ __forceinline__ ZgRows zg_rows(const float4* __restrict__ zg, int s, 
     r.t1 = rg + 1 < rg_end ? zg[(rg + 1) * 32 + j] : zero;
     return r;
 }
-// `first`: the rows of k-step s0, requested by the caller ahead of the LDS part (only read when NVP_ZG_PREFETCH and s0 < s1)
 __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __restrict__ zg, int s0, int s1, int rg_end, const float sc,
-                                            const u32x4* __restrict__ w, int lane, ZgRows first) {
+                                            const u32x4* __restrict__ w, int lane) {
     const int j = lane & 31, h = lane >> 5;
     NVP_CHAIN_ENTER();
-    ZgRows cur = first;
 #pragma unroll 1
     for (int s = s0; s < s1; ++s) {
-        ZgRows nxt = cur;
-        if (NVP_ZG_PREFETCH) { if (s + 1 < s1) nxt = zg_rows(zg, s + 1, rg_end, j, h); }
-        else cur = zg_rows(zg, s, rg_end, j, h);
+        const ZgRows cur = zg_rows(zg, s, rg_end, j, h);
         const float x[8] = {cur.t0.x, cur.t0.y, cur.t0.z, cur.t0.w, cur.t1.x, cur.t1.y, cur.t1.z, cur.t1.w};
         BOp b;
         split8(x, sc, b);
         step_b3(acc, w + s * kB3StepQuads, b, lane);
-        cur = nxt;
     }
     NVP_CHAIN_LEAVE();
 }
@@ -194,17 +112,12 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
     const int z4 = (nvp_rows4(d) / 4) * 32;
     const float4* zg = reinterpret_cast<const float4*>(zt) + tile * (int64_t)z4;
     float mz;                                                 // per-pixel max |z|: the latent's share of the operand scale
-#ifndef NVP_GATHER_PRIO
-#define NVP_GATHER_PRIO 0       // experiment: the tile gather (address arithmetic + fetch issue) outranks the partner wave's MLP
-#endif
-    if (NVP_GATHER_PRIO && GF != 0) __builtin_amdgcn_s_setprio(3);
     // GF == 4 (config_nvp_l: 228 rows): the tile is WIDER than the wave's LDS region - its row-groups beyond kB3ZLdsSteps k-steps go straight into the
     // latent tensor (which the caller then always provides) and are read back from there by the chains, like the staged path's tail
     constexpr bool kWide = GF == 4;
     if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
-    else if (kWide) mz = nvp_gather_tile<(GF == 0 ? 2 : GF), kWide>(z, active ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane, zs_l * 4, SAVE && !NVP_FWD_LATE_STORES);
-    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active && !NVP_FWD_LATE_STORES) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
-    if (NVP_GATHER_PRIO && GF != 0) __builtin_amdgcn_s_setprio(0);
+    else if (kWide) mz = nvp_gather_tile<(GF == 0 ? 2 : GF), kWide>(z, active ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane, zs_l * 4, SAVE);
+    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
     if (kWide && zs_l < L.zs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail rows this wave has just stored are read back below (a wave reading its own stores: the count suffices)
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();
@@ -228,19 +141,14 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
     // ---- modulator layer 0: h0 = lrelu(W0 z + b0)                 modulation.py:112-121
     {
         const u32x4* w = wp + NVP_WSTRIDE(L.off[0] / 4);
-        NVP_LAYER_SYNC();
 #pragma unroll
         for (int T = 0; T < 4; ++T) hm[T] = nvp_zero16();
         const PxScale ps = px_scale(fmaxf(mz, 1.0f));                // the bias (B = 1) shares the scale
-        ZgRows zg_first = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        if (GF == 0 && NVP_ZG_PREFETCH && zs_l < L.zs) zg_first = zg_rows(zg, zs_l, rg_end, j, h);        // wide latents: first tensor-resident k-step, requested now
         bias_b3(hm, w, ps.s, lane);
-        // fused gather + NVP_FWD_LATE_STORES: the latent tile leaves for the tensor from inside this chain (the whole latent is in LDS: fused_ok)
 #ifndef NVP_FWD_SIR0_EARLY
 #define NVP_FWD_SIR0_EARLY 1     // SIREN layer 0's sines - sin(30 (w s + c)), independent of everything the MLP has computed so far - are issued eight per
 #endif                           // k-step in the shadow of this chain's MFMAs instead of as a serial 900-instruction VALU stage behind it (same bits)
         sir0_early = chain_z_b3(hm, z, zs_l, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,
-                   (GF != 0 && NVP_FWD_LATE_STORES && SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, rg_end,
                    [&](int ks) {
                        if (!NVP_FWD_SIR0_EARLY) return;
                        const int T = ks >> 1, r0 = 8 * (ks & 1);
@@ -252,13 +160,11 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
 #pragma unroll
                        for (int q = 0; q < 8; ++q) x[T][r0 + q] = nvp_sin(30.0f * __fmaf_rn(s, wv[q], cv[q]));
                    }) && NVP_FWD_SIR0_EARLY;
-        if (GF == 0 || GF == 4) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane, zg_first);
+        if (GF == 0 || GF == 4) chain_zg_b3(hm, zg, zs_l, L.zs, rg_end, ps.s, w + kB3StepQuads, lane);
         lrelu4_scaled(hm, ps.u * winv[0]);
 #pragma unroll
         for (int T = 0; T < 4; ++T) nvp_pin(hm[T]);
-#if !NVP_FWD_LATE_STORES
         if (SAVE && active) store_ptm(sv + 0 * act, hm, lane);
-#endif
     }
     // ---- SIREN layer 0: x0 = sin(30 (w s + c)) * h0                modulation.py:53-56,90
     {
@@ -286,54 +192,29 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
         }
     }
     // ---- layers 1 and 2
-#ifndef NVP_FWD_ROLL_LAYERS
-#define NVP_FWD_ROLL_LAYERS 0    // experiment: 1 keeps the two iterations as ONE loop body (about two thirds of the code; the 64-KB instruction cache is shared by the CU's eight waves)
-#endif
-#if NVP_FWD_ROLL_LAYERS
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int k = 1; k <= 2; ++k) {
         {   // modulator: h_k = lrelu(Wh h_{k-1} + Wz z + b)
             const u32x4* w = wp + NVP_WSTRIDE(L.off[k] / 4);
-            NVP_LAYER_SYNC();
-#pragma unroll
+    #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             const PxScale ps = px_scale(fmaxf(fmaxf(px_absmax(hm), mz), 1.0f));
-            ZgRows zg_first = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-            if (GF == 0 && NVP_ZG_PREFETCH && zs_l < L.zs) zg_first = zg_rows(zg, zs_l, rg_end, j, h);
             bias_b3(acc, w, ps.s, lane);
-#if NVP_FWD_LATE_STORES
-            // h_{k-1} (k = 1: h0) is this chain's input and stays untouched until the epilogue below: its stream stores ride along,
-            // one 32-row tile after every second k-step
-            if (k == 1) chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane, [&](int c) { if (SAVE && active && (c & 1)) store_ptm16(sv + 0 * act, hm[c >> 1], c >> 1, lane); });
-            else chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
-#else
             chain_h_b3(acc, hm, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
-#endif
             chain_z_b3(acc, z, zs_l, ps.s, w + NVP_WSTRIDE(9 * kB3StepQuads), lane);
-            if (GF == 0 || GF == 4) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane, zg_first);
+            if (GF == 0 || GF == 4) chain_zg_b3(acc, zg, zs_l, L.zs, rg_end, ps.s, w + 9 * kB3StepQuads, lane);
             lrelu4_scaled(acc, ps.u * winv[k]);
 #pragma unroll
             for (int T = 0; T < 4; ++T) { hm[T] = acc[T]; nvp_pin(hm[T]); }
-#if !NVP_FWD_LATE_STORES
             if (SAVE && active) store_ptm(sv + (int64_t)k * act, hm, lane);
-#endif
         }
         {   // SIREN: q_k = V x_{k-1} + c ; x_k = sin(q_k) * h_k
             const u32x4* w = wp + NVP_WSTRIDE(L.off[2 + k] / 4);
-            NVP_LAYER_SYNC();
-#pragma unroll
+    #pragma unroll
             for (int T = 0; T < 4; ++T) acc[T] = nvp_zero16();
             const PxScale ps = px_scale(fmaxf(px_absmax(x), 1.0f));
             bias_b3(acc, w, ps.s, lane);
-#if NVP_FWD_LATE_STORES
-            chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane,             // h_k (hm) is only read again in the epilogue: its stores ride along here
-                       [&](int c) { if (SAVE && active && (c & 1)) store_ptm16(sv + (int64_t)k * act, hm[c >> 1], c >> 1, lane); });
-#else
             chain_h_b3(acc, x, ps.s, w + NVP_WSTRIDE(kB3StepQuads), lane);
-#endif
             scale4(acc, ps.u * winv[2 + k]);
             if (SAVE && active) store_ptm(sv + (int64_t)(2 + k) * act, acc, lane);
 #pragma unroll

@@ -73,6 +73,23 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def pytest_collection_finish(session):
+    """The CPU oracle's long trainings start NOW, as background processes underneath the deterministic parity tests (VERDICT r5 item 3;
+    tests/util_background.py): the trajectory tests, collected last, only pick their results up."""
+    import torch
+    if not torch.cuda.is_available() or session.config.option.collectonly:
+        return
+    ids = [it.nodeid for it in session.items if "zz_trajectories" in it.nodeid and not any(m.name == "skip" for m in it.iter_markers())]
+    if ids:
+        import test_gpu_zz_trajectories as zz
+        zz.background_jobs(ids)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if "util_background" in sys.modules:
+        sys.modules["util_background"].cleanup()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

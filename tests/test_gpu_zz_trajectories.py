@@ -7,7 +7,13 @@ problem, their margins are statistical, and a margin must never stand in front o
 The checker is made reproducible: the oracle's trainings run with a FIXED intra-op thread count and torch's deterministic
 algorithms (conftest.oracle_determinism); the 1 000-step oracle walks in a process of its own with MKL's conditional numerical
 reproducibility switched on (util_windows.oracle_env).  The HIP side is bit-reproducible by construction (fixed-point scatter,
-ordered dW reduction).  Every test prints ONE summary line (`PSNR-PARITY ...`) so the numbers reach the driver's tail."""
+ordered dW reduction).  Every test prints ONE summary line (`PSNR-PARITY ...`) so the numbers reach the driver's tail.
+
+Round 6: the oracle's trainings depend on nothing the GPU computes, so they no longer run INSIDE the tests:
+conftest.pytest_collection_finish starts them as background processes (`background_jobs()` below, tests/util_background.py,
+tests/util_traj.py, tests/util_windows.py --oracle 1) underneath the deterministic parity tests; a test only replays the same
+seeded batches on the HIP path and compares.  Every oracle process runs under util_windows.oracle_env() - bit-identical
+results whenever and wherever it runs, so moving it changes no verdict."""
 import json
 import os
 import subprocess
@@ -17,9 +23,10 @@ import pytest
 import torch
 
 import nvp_oracle as O
-from conftest import ROOT, oracle_determinism, report, say, small_cfg
+import util_background as background
+from conftest import ROOT, report, say, small_cfg
 from util_parity import _load_state_into
-from util_windows import oracle_env, ulp_perturbed, window_verdicts
+from util_windows import window_verdicts
 
 pytestmark = pytest.mark.gpu
 
@@ -35,73 +42,81 @@ def _say(line: str) -> None:
 
 
 # ----------------------------------------------------------------------------------------
+# the oracle's trainings: background jobs (started by conftest.pytest_collection_finish, or on demand)
+# ----------------------------------------------------------------------------------------
+WINDOW_SEEDS = [int(v) for v in os.environ.get("NVP_PSNR_SEEDS", os.environ.get("NVP_PSNR_SEED", "7,8")).split(",")]
+STEPS_100 = int(os.environ.get("NVP_PSNR_STEPS", "100"))
+STEPS_FULL = int(os.environ.get("NVP_PSNR_STEPS_FULL", "50"))
+STEPS_LONG = int(os.environ.get("NVP_PSNR_STEPS_LONG", "1000"))
+WINDOW = int(os.environ.get("NVP_PSNR_WINDOW", "50"))
+SPECS_100 = [{"name": f"s{seed}", "seed": seed, "video_seed": seed, "gen_seed": seed, "steps": STEPS_100, "n_levels": 12, "ulp_twin": True,
+              "clip": "procedural"} for seed in (3, 4, 5)]
+SPEC_FULL = {"name": "full16", "seed": 3, "video_seed": 1, "gen_seed": 0, "steps": STEPS_FULL, "n_levels": 16, "ulp_twin": False, "clip": "procedural"}
+
+
+def _windows_argv(seed):
+    d = background.job_dir(f"windows_seed{seed}")
+    return [os.path.join(ROOT, "tests", "util_windows.py"), "--oracle", "1", "--dir", d, "--out", os.path.join(d, "oracle.json"),
+            "--seed", str(seed), "--steps", str(STEPS_LONG), "--window", str(WINDOW), "--controls", "2"]
+
+
+def _traj_argv(name, specs):
+    return [os.path.join(ROOT, "tests", "util_traj.py"), "--dir", background.job_dir(name), "--specs", json.dumps(specs)]
+
+
+def background_jobs(nodeids):
+    """Start the oracle processes the selected tests will ask for - the longest first (conftest calls this once collection is done)."""
+    ids = " ".join(nodeids)
+    if "test_psnr_tracks_the_oracle_along_a_1000_step_schedule" in ids:
+        for seed in WINDOW_SEEDS:
+            if f"schedule[{seed}]" in ids:
+                background.start(f"windows_seed{seed}", _windows_argv(seed))
+    if "test_psnr_at_equal_steps_full_levels" in ids:
+        background.start("traj_full", _traj_argv("traj_full", [SPEC_FULL]))
+    if "test_psnr_at_equal_steps_matches_oracle" in ids:
+        background.start("traj100", _traj_argv("traj100", SPECS_100))
+
+
+def _oracle_trajectory(job, specs, spec):
+    """(result dict, u8 clip) of one spec of a util_traj.py job"""
+    d = background.result(job, _traj_argv(job, specs))
+    return json.load(open(os.path.join(d, f"traj_{spec['name']}.json"))), torch.load(os.path.join(d, f"video_{spec['name']}.pt"))
+
+
+# ----------------------------------------------------------------------------------------
 # PSNR at equal step count: the HIP path and the oracle trained on IDENTICAL batches
 # (BASELINE.json configs[0]: 64x64x16 synthetic RGB, config_nvp_s values; north_star: +-0.02 dB)
 # ----------------------------------------------------------------------------------------
-def _psnr_trajectories(seed, steps_total, n_levels=16, log=None, ulp_twin=True, clip="procedural"):
-    """Train (a) the oracle, (b) the oracle started <= 1 ulp away, (c) the HIP path with the product's own AdamW kernel on
-    IDENTICAL batches drawn with the reference's sampler; returns per-step train PSNRs (training.py:58) and the three
-    final parameter sets' full-frame eval PSNRs (eval.py:243-256)."""
+def _hip_trajectory(spec, video, log=None):
+    """The HIP half: the product's modules and its own AdamW kernel trained on the batches util_traj.oracle_trajectory drew (same
+    seeded generator, the reference's sampler order) from the same init; returns per-step train PSNRs (training.py:58) and the final
+    parameters' full-frame eval PSNR (eval.py:243-256)."""
     import math
     from nvp_amd import harness
     from nvp_amd.modules import NVP
     from nvp_amd.optim import AdamW as _NvpAdamW
-    T, H, W, n = 16, 64, 64, 8192
-    cfg = small_cfg(F=2, T=T, X=20, Y=20, n_levels=n_levels)
-    sd = O.init_state(cfg, seed=seed)                       # reference init distributions
+    from util_traj import FRAMES, H, N_BATCH, T, W
+    cfg = small_cfg(F=2, T=T, X=20, Y=20, n_levels=spec["n_levels"])
+    sd = O.init_state(cfg, seed=spec["seed"])               # reference init distributions
     model = NVP(out_features=3, encoding_config=cfg)
     _load_state_into(model, sd)
     model = model.to(dev())
-    if clip == "natural":          # 1/f texture + edges + motion + sensor grain (harness.natural_video): the PSNR saturates at the grain floor
-        video = harness.natural_video(T, H, W, torch.device("cpu"), seed=seed, grain=4.0)
-    else:
-        video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=seed)       # u8 [T,H,W,3]
     flat = video.reshape(T, H * W, 3)
-
-    def make_ref(state):
-        ref = {k: v.clone().requires_grad_(True) for k, v in state.items()}
-        opt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)
-        return ref, opt, torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps_total, eta_min=1e-5)
-
-    ref_a, opt_a, sch_a = make_ref(sd)
-    ref_b, opt_b, sch_b = make_ref(ulp_perturbed(sd, seed + 1000))
-    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)      # the product's optimiser: nvp_adamw_step + cosine
+    opt_g, sch_g = harness.make_optimizer(model, total_steps=spec["steps"])      # the product's optimiser: nvp_adamw_step + cosine
     assert isinstance(opt_g, _NvpAdamW)
-    gen = torch.Generator().manual_seed(seed)
-    pa, pb, pg = [], [], []
-    for it in range(steps_total):
-        ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)          # the reference's sampler order
-        gt_u8 = flat[ti, pi].unsqueeze(0)
-        with oracle_determinism():                                                          # the checker: same trajectory on every box
-            for ref, opt, sch, acc in ((ref_a, opt_a, sch_a, pa), (ref_b, opt_b, sch_b, pb))[:2 if ulp_twin else 1]:
-                out_r = O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg)        # training.py:50-76 order
-                loss_r = O.image_mse(out_r, O.normalise_gt(gt_u8))
-                opt.zero_grad(); loss_r.backward(); opt.step(); sch.step()
-                acc.append(10 * math.log10(4 / float(loss_r.detach())))                         # training.py:58
+    gen = torch.Generator().manual_seed(spec["gen_seed"])
+    pg = []
+    for it in range(spec["steps"]):
+        ti, pi, coords, tstep = O.sample_batch(T, H, W, N_BATCH, gen)          # the reference's sampler order
         mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
-        out_g = model(mi)["model_out"]
-        loss_g = harness.image_mse_u8(out_g, gt_u8.to(dev()))
+        loss_g = harness.image_mse_u8(model(mi)["model_out"], flat[ti, pi].unsqueeze(0).to(dev()))
         opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
         pg.append(10 * math.log10(4 / float(loss_g)))
         if log:
             with open(log, "a") as f:
-                f.write(f'{{"seed": {seed}, "step": {it + 1}, "psnr_oracle": {pa[-1]:.4f}, "psnr_oracle_1ulp": {(pb[-1] if pb else float("nan")):.4f}, "psnr_hip": {pg[-1]:.4f}}}\n')
-    # evaluation PSNR on full frames (eval.py:243-256) with the final parameter sets
-    frames = (0, 7, 15)
-    data = harness.DeviceVideo(video.to(dev()), n_samples=n, seed=0)
-    ev_g = harness.eval_psnr(model, data, frames=list(frames), n_slice=4)
-
-    def eval_ref(ref):
-        with torch.no_grad():
-            mg, ps = O.get_mgrid_2d(H, W), []
-            for f in frames:
-                c = torch.cat((torch.linspace(0, 1, T)[f].expand(H * W, 1), mg), dim=1).unsqueeze(0)
-                s_ = torch.linspace(0.5 / T, 1 - 0.5 / T, T)[f].expand(1, H * W)
-                img = torch.clamp((O.nvp_forward(c, s_, {k: v.detach() for k, v in ref.items()}, cfg) + 1) / 2, 0, 1)
-                ps.append(10 * math.log10(1 / float(((img.reshape(-1, 3) - flat[f].float() / 255.0) ** 2).mean())))
-            return sum(ps) / len(ps)
-
-    return pa, pb, pg, eval_ref(ref_a), (eval_ref(ref_b) if ulp_twin else float("nan")), ev_g
+                f.write(f'{{"seed": {spec["seed"]}, "step": {it + 1}, "psnr_hip": {pg[-1]:.4f}}}\n')
+    data = harness.DeviceVideo(video.to(dev()), n_samples=N_BATCH, seed=0)
+    return pg, harness.eval_psnr(model, data, frames=list(FRAMES), n_slice=4)
 
 
 @pytest.mark.parametrize("seed", [3, 4, 5])
@@ -114,11 +129,15 @@ def test_psnr_at_equal_steps_matches_oracle(seed):
     (measured on MI355X: gap 0.008-0.013 dB, envelope 0.006-0.011 dB, signed final differences -0.008 ... +0.011 dB: no
     systematic sign - profiles/r02_parity_report.jsonl; against a float64 training the HIP path is closer than the fp32 oracle,
     profiles/r02_psnr_bisect_f64_f32_hip.txt).  12 of the 16 keyframe levels (0.36 M cells per
-    plane instead of 4.6 M) keep the three CPU trainings of the checker affordable; the 16-level model is covered by
-    test_psnr_at_equal_steps_full_levels."""
-    steps_total = int(os.environ.get("NVP_PSNR_STEPS", "100"))
-    pa, pb, pg, ev_a, ev_b, ev_g = _psnr_trajectories(seed, steps_total, 12, log=os.environ.get("NVP_PSNR_LOG"))
+    plane instead of 4.6 M) keep the CPU trainings of the checker affordable; the 16-level model is covered by
+    test_psnr_at_equal_steps_full_levels.  The oracle's two trainings run in the background job `traj100`."""
     import math
+    spec = next(s_ for s_ in SPECS_100 if s_["seed"] == seed)
+    orc, video = _oracle_trajectory("traj100", SPECS_100, spec)
+    pa, pb, ev_a, ev_b = orc["psnr"], orc["psnr_1ulp"], orc["eval"], orc["eval_1ulp"]
+    pg, ev_g = _hip_trajectory(spec, video, log=os.environ.get("NVP_PSNR_LOG"))
+    steps_total = spec["steps"]
+    assert len(pa) == len(pb) == len(pg) == steps_total and orc["threads"] == 16
     assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
     gap = [abs(a - g) for a, g in zip(pa, pg)]
     env = [abs(a - b) for a, b in zip(pa, pb)]
@@ -133,22 +152,24 @@ def test_psnr_at_equal_steps_matches_oracle(seed):
     assert abs(ev_g - ev_a) <= 0.02, f"eval-PSNR gap {abs(ev_g - ev_a):.4f} dB (1-ulp control {abs(ev_b - ev_a):.4f})"
 
 
-def _walk_windows(tmp_path, seed, steps_total, window, n_controls):
-    """oracle (own process, reproducible) -> product (this process) -> fp32-MFMA twin (own process); returns the three results"""
+def _walk_windows(seed):
+    """oracle (background process, reproducible) -> product (this process) and fp32-MFMA twin (own process, at the same time: the
+    walks are chains of small launches with host round trips in between - two of them share the GPU without slowing each other
+    much); returns the three results"""
     from util_windows import hip_walk
-    d = str(tmp_path / f"windows_seed{seed}")
-    cmd = [sys.executable, os.path.join(ROOT, "tests", "util_windows.py"), "--oracle", "1", "--dir", d, "--out", os.path.join(d, "oracle.json"),
-           "--seed", str(seed), "--steps", str(steps_total), "--window", str(window), "--controls", str(n_controls)]
-    os.makedirs(d, exist_ok=True)
-    r = subprocess.run(cmd, cwd=ROOT, env=oracle_env(), capture_output=True, text=True, timeout=3000)
-    assert r.returncode == 0, f"oracle walk: {r.stderr[-2000:]}"
+    d = background.result(f"windows_seed{seed}", _windows_argv(seed))
     orc = json.load(open(os.path.join(d, "oracle.json")))
-    prod = hip_walk(d, free=True)
     env = dict(os.environ)
     env["NVP_HIP_LIB"] = TWIN
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "util_windows.py"), "--dir", d, "--out", os.path.join(d, "twin.json")],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, f"twin walk: {r.stderr[-2000:]}"
+    tw = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "util_windows.py"), "--dir", d, "--out", os.path.join(d, "twin.json")],
+                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        prod = hip_walk(d, free=True)
+        _, err = tw.communicate(timeout=1500)
+    finally:
+        if tw.poll() is None:
+            tw.kill()
+    assert tw.returncode == 0, f"twin walk: {err[-2000:]}"
     twin = json.load(open(os.path.join(d, "twin.json")))
     for f in os.listdir(d):
         if f.endswith(".pt"):
@@ -156,7 +177,8 @@ def _walk_windows(tmp_path, seed, steps_total, window, n_controls):
     return orc, prod, twin
 
 
-def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(tmp_path):
+@pytest.mark.parametrize("seed", WINDOW_SEEDS)
+def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(seed):
     """The HIP path against the ORACLE over a whole cosine schedule of 1 000 steps (NVP_PSNR_STEPS_LONG) at the small size, walked in
     50-step windows (NVP_PSNR_WINDOW) from the oracle's state, WITH THE CONTROLS IN THE RUN (tests/util_windows.py): at every window
     start the product build, the fp32-MFMA twin build (subprocess) and two 1-ulp copies of the oracle are set to the oracle's
@@ -173,13 +195,12 @@ def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(tmp_path):
     Reproducibility: the oracle walks in a process of its own (fixed thread count, deterministic algorithms, MKL_CBWR); measured on
     MI355X hosts its trajectory is bit-identical box to box, and the HIP side is bit-reproducible by construction - so this test's
     outcome for a given seed is the same on every box (profiles/r05_psnr_windows_seeds_boxes.txt: seeds 7, 8, 9 on several boxes).
-    NVP_PSNR_SEED selects the seed (default 7)."""
+    Two seeds are graded (NVP_PSNR_SEEDS, default "7,8": seed 8 has the largest product gap measured, 0.0185 dB in its one hot
+    window); their oracle walks run as background processes from the start of the session."""
     import math
-    steps_total = int(os.environ.get("NVP_PSNR_STEPS_LONG", "1000"))
-    window = int(os.environ.get("NVP_PSNR_WINDOW", "50"))
-    seed = int(os.environ.get("NVP_PSNR_SEED", "7"))
+    steps_total, window = STEPS_LONG, WINDOW
     assert os.path.exists(TWIN), f"{TWIN} missing: run nvp_amd/csrc/build.sh"
-    orc, prod, twin = _walk_windows(tmp_path, seed, steps_total, window, n_controls=2)
+    orc, prod, twin = _walk_windows(seed)
     assert prod["mfma_products"] == 3 and twin["mfma_products"] == 1, (prod["lib"], twin["lib"])
     pa = orc["psnr"]
     ends = [min(s + window, steps_total) - 1 for s in range(0, steps_total, window)]
@@ -205,46 +226,23 @@ def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(tmp_path):
 
 def test_psnr_at_equal_steps_full_levels():
     """The same check on the full 16-level keyframes (config_nvp_s values, BASELINE.json configs[0]) over 50 steps, without the
-    1-ulp twin (each CPU step of the checker updates 27.8 M parameters)."""
+    1-ulp twin (each CPU step of the checker updates 27.8 M parameters; background job `traj_full`)."""
     import math
-    from nvp_amd import harness
-    from nvp_amd.modules import NVP
-    T, H, W, n, steps_total, seed = 16, 64, 64, 8192, int(os.environ.get("NVP_PSNR_STEPS_FULL", "50")), 3
-    cfg = small_cfg(F=2, T=T, X=20, Y=20)
-    sd = O.init_state(cfg, seed=seed)
-    model = NVP(out_features=3, encoding_config=cfg)
-    _load_state_into(model, sd)
-    model = model.to(dev())
-    video = harness.procedural_video(T, H, W, torch.device("cpu"), seed=1)
-    flat = video.reshape(T, H * W, 3)
-    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    opt_r = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)
-    sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=steps_total, eta_min=1e-5)
-    opt_g, sch_g = harness.make_optimizer(model, total_steps=steps_total)
-    gen = torch.Generator().manual_seed(0)
-    gap = []
-    for it in range(steps_total):
-        ti, pi, coords, tstep = O.sample_batch(T, H, W, n, gen)
-        gt_u8 = flat[ti, pi].unsqueeze(0)
-        with oracle_determinism():
-            loss_r = O.image_mse(O.nvp_forward(coords.unsqueeze(0), tstep.unsqueeze(0), ref, cfg), O.normalise_gt(gt_u8))
-            opt_r.zero_grad(); loss_r.backward(); opt_r.step(); sch_r.step()
-            loss_r = loss_r.detach()
-        mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
-        loss_g = harness.image_mse_u8(model(mi)["model_out"], gt_u8.to(dev()))
-        opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
-        gap.append(abs(10 * math.log10(4 / float(loss_r)) - 10 * math.log10(4 / float(loss_g))))
-    report("psnr_equal_steps_full", steps=steps_total, gap=max(gap), final_gap=gap[-1], final_psnr=10 * math.log10(4 / float(loss_r)))
-    assert 10 * math.log10(4 / float(loss_g)) > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
+    orc, video = _oracle_trajectory("traj_full", [SPEC_FULL], SPEC_FULL)
+    pg, _ = _hip_trajectory(SPEC_FULL, video)
+    pa = orc["psnr"]
+    assert len(pa) == len(pg) == SPEC_FULL["steps"]
+    gap = [abs(a_ - g_) for a_, g_ in zip(pa, pg)]
+    report("psnr_equal_steps_full", steps=SPEC_FULL["steps"], gap=max(gap), final_gap=gap[-1], final_psnr=pa[-1])
+    assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
     _say(f"50-step 16-level train_gap_max={max(gap):.4f} final_gap={gap[-1]:.4f} dB")
     assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"
-
 
 
 # ----------------------------------------------------------------------------------------
 # FULL SIZE (configs[1]): the fp16x2 build against the fp32-MFMA twin over a 1 000-step schedule
 # ----------------------------------------------------------------------------------------
-def _run(tag, lib, steps, every, out, ulp=0):
+def _start(tag, lib, steps, every, out, ulp=0):
     env = dict(os.environ)
     env.pop("NVP_HIP_LIB", None)
     if lib:
@@ -253,8 +251,17 @@ def _run(tag, lib, steps, every, out, ulp=0):
         os.remove(out)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "long_horizon.py"), "--steps", str(steps), "--every", str(every),
            "--video", "natural", "--tag", tag, "--out", out, "--ulp", str(ulp)]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, f"{tag}: {r.stderr[-2000:]}"
+    return tag, out, subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+
+
+def _finish(job):
+    tag, out, proc = job
+    try:
+        _, err = proc.communicate(timeout=1500)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    assert proc.returncode == 0, f"{tag}: {err[-2000:]}"
     recs = [json.loads(line) for line in open(out) if line.startswith("{")]
     return {x["step"]: x for x in recs if "step" in x}, [x for x in recs if x.get("summary")][0]
 
@@ -280,9 +287,16 @@ def test_fp16x2_split_tracks_the_fp32_mfma_twin_at_full_size(tmp_path):
     assert os.path.exists(TWIN), f"{TWIN} missing: run nvp_amd/csrc/build.sh (it builds the fp32-MFMA twin next to libnvp_hip.so)"
     steps = int(os.environ.get("NVP_LH_STEPS", "1000"))
     every = int(os.environ.get("NVP_LH_EVERY", "250"))
-    a, sa = _run("f16x2", None, steps, every, str(tmp_path / "a.jsonl"))
-    b, sb = _run("fp32mfma", TWIN, steps, every, str(tmp_path / "b.jsonl"))
-    c, sc = _run("fp32mfma_1ulp", TWIN, steps, every, str(tmp_path / "c.jsonl"), ulp=1)
+    # the three trainings are independent processes (13 GB of the 288 GB each): started together, their start-up, clip synthesis and
+    # evaluation phases overlap; every one of them is bit-reproducible, so sharing the GPU changes no number
+    jobs = [_start("f16x2", None, steps, every, str(tmp_path / "a.jsonl")), _start("fp32mfma", TWIN, steps, every, str(tmp_path / "b.jsonl")),
+            _start("fp32mfma_1ulp", TWIN, steps, every, str(tmp_path / "c.jsonl"), ulp=1)]
+    try:
+        (a, sa), (b, sb), (c, sc) = (_finish(j) for j in jobs)
+    finally:
+        for _, _, pr in jobs:
+            if pr.poll() is None:
+                pr.kill()
     # the processes really ran different arithmetic on the same problem
     assert sa["mfma_products"] == 3 and sb["mfma_products"] == 1 and sc["mfma_products"] == 1, (sa["mfma_products"], sb["mfma_products"])
     assert sa["samples"] == sb["samples"] == 1245184 and sa["geometry"] == sb["geometry"] == [600, 1080, 1920]

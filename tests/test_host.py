@@ -474,7 +474,8 @@ def test_product_library_has_no_environment_switches_and_no_experiment_entry_poi
     assert not (exp_names & exported)
     assert exported == set(L.SIGNATURES)
     exp = os.path.join(ROOT, "nvp_amd", "csrc", "libnvp_hip_experiments.so")
-    if os.path.exists(exp):
+    tag = lambda p_: open(p_ + ".srchash").read().strip() if os.path.exists(p_ + ".srchash") else None      # noqa: E731
+    if os.path.exists(exp) and tag(exp) is not None and tag(exp) == tag(prod):       # built (NVP_BUILD_EXPERIMENTS=1) from the same sources
         dyn_e = subprocess.run(["nm", "-D", exp], capture_output=True, text=True, check=True).stdout
         exported_e = set(re.findall(r" T (nvp_[a-z0-9_]+)", dyn_e))
         assert exported_e == exported | exp_names
