@@ -1,5 +1,5 @@
 // In-wave tile gather: the encoding half of NVP.forward (modules.py:57-78: three tinycudann.Encoding planes + SparseGrid.forward /
-// concatenated xy | yt | xt | sparse; SparseGrid.forward_inter, eval.py --t_interp, takes the two-kernel path) for the 32 pixels of ONE MLP tile, written straight into the wave's LDS latent
+// concatenated xy | yt | xt | sparse; INTER: SparseGrid.forward_inter, sparsegrid.py:76-156, eval.py --t_interp - inference kernels only) for the 32 pixels of ONE MLP tile, written straight into the wave's LDS latent
 // tile - the forward MLP kernel (mlp_fwd_b3.hip) calls it instead of staging a latent that a separate gather kernel had to write to
 // HBM first ("grid lookups fused with the modulated coordinate MLP").  Same helpers, same arithmetic, same order of operations as
 // encode.hip's encode_fwd_kernel: the latent is BIT-identical.
@@ -162,9 +162,11 @@ __device__ __forceinline__ float tile_plane(const TileDst<WIDE>& dst, const floa
 template <int F>
 struct SparseFetch { float lo[2][3 * F]; int sel[3]; };
 
-template <int F>
+// INTER (SparseGrid.forward_inter): the same rows of the t_hi slice too, blended as sparse_fwd_ptm (encode.hip) does - lo * w_lo + hi * w_hi,
+// separately rounded; at t == 1 the reference's weights are 0 / 0 and the row is NaN (the quirk eval.py --t_interp's last frame hits): kept.
+template <int F, bool INTER = false>
 __device__ __forceinline__ void tile_sparse_fetch(SparseFetch<F>& sf, const NvpTileEnc& a, float t, float x, float y, int h) {
-    const Patch p = patch_setup(t, x, y, a.sh, false);
+    const Patch p = patch_setup(t, x, y, a.sh, INTER);
     const int y0 = min(max(p.vy[1] - 1, 0), a.sh.y_res - 3);
     const int64_t plane = (int64_t)a.sh.x_res * a.sh.y_res;
 #pragma unroll
@@ -181,6 +183,14 @@ __device__ __forceinline__ void tile_sparse_fetch(SparseFetch<F>& sf, const NvpT
         } else {
 #pragma unroll
             for (int c = 0; c < 3 * F; ++c) sf.lo[s2][c] = pl[c];
+        }
+        if constexpr (INTER) {
+            const float* ph = a.emb + ((int64_t)p.t_hi * plane + cell) * F;
+            float hi[3 * F];
+#pragma unroll
+            for (int c = 0; c < 3 * F; ++c) hi[c] = ph[c];
+#pragma unroll
+            for (int c = 0; c < 3 * F; ++c) sf.lo[s2][c] = __fadd_rn(__fmul_rn(sf.lo[s2][c], p.w_lo), __fmul_rn(hi[c], p.w_hi));
         }
     }
 }
@@ -223,7 +233,7 @@ __device__ __forceinline__ float tile_sparse_write(const TileDst<WIDE>& dst, con
 // tensor's tile zg (TileDst).  copy_lds: also write the LDS part to zg (training: the dW GEMMs read the whole latent) - from LDS, after the
 // gather, so that no fetch waits for a store's data registers.  zg may be null when rg_lds covers the tile and copy_lds is false.
 // Returns this lane's largest |z| (combine the two lane halves for the pixel's).
-template <int F, bool WIDE = false>
+template <int F, bool WIDE = false, bool INTER = false>
 __device__ __forceinline__ float nvp_gather_tile(float4* __restrict__ zl, float4* __restrict__ zg, const NvpTileEnc& a, int64_t tile, int64_t n, int lane,
                                                  int rg_lds = 1 << 20, bool copy_lds = true) {
     const int j = lane & 31, h = lane >> 5;
@@ -233,7 +243,7 @@ __device__ __forceinline__ float nvp_gather_tile(float4* __restrict__ zl, float4
     if (valid) { const float* c = a.coords + px * 3; t = c[0]; x = c[1]; y = c[2]; }
     const TileDst<WIDE> dst = {zl, zg, rg_lds};
     SparseFetch<F> sf;
-    tile_sparse_fetch<F>(sf, a, t, x, y, h);
+    tile_sparse_fetch<F, INTER>(sf, a, t, x, y, h);
     float m = tile_plane<F, WIDE>(dst, a.kf[2], a.lv[2], a.col0[2], t, x, valid, j, h);          // xt plane <- (t, x)   modules.py:62
     m = fmaxf(m, tile_plane<F, WIDE>(dst, a.kf[0], a.lv[0], a.col0[0], x, y, valid, j, h));      // xy plane <- (x, y)   modules.py:61
     m = fmaxf(m, tile_plane<F, WIDE>(dst, a.kf[1], a.lv[1], a.col0[1], t, y, valid, j, h));      // yt plane <- (t, y)   modules.py:63

@@ -22,7 +22,7 @@ namespace {
 constexpr int kWaves = NVP_FWD_WAVES;
 
 // two workgroups per CU = two waves per SIMD (the one-wave-per-SIMD build with 512 registers and deeper weight prefetch: 2.19 vs 1.82 ms)
-template <bool SAVE, int GF>
+template <bool SAVE, int GF, bool INTER = false>
 __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __restrict__ zt, const float* __restrict__ steps,
                                                                     nvp_mlp_params p, const unsigned* __restrict__ packed,
                                                                     float* __restrict__ rgb, float* __restrict__ saved,
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void mlp_fwd_b3_kernel(float* __res
     const NvpFwdLayoutB3 Lz = nvp_fwd_layout_b3(d);
     float4* z = zlds + wv * (min(Lz.zs, kB3ZLdsSteps) * 4 * 32);       // this wave's latent tile
     float rgb_px[3];
-    fwd_b3_tile<SAVE, GF>(zt, steps, p, packed, rgb, saved, n, ntiles, d, enc, tile, active, z, lane, rgb_px);
+    fwd_b3_tile<SAVE, GF, INTER>(zt, steps, p, packed, rgb, saved, n, ntiles, d, enc, tile, active, z, lane, rgb_px);
 }
 
 #if NVP_EXPERIMENTS
@@ -97,7 +97,8 @@ extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const
                                   const nvp_sparse_shape* sh, int temporal_interp, void* stream) {
     int d = 0;
     bool wide = false;
-    if (!fused_ok(lv_xy, lv_yt, lv_xt, sh, &d, &wide) || temporal_interp) return NVP_ERR_UNSUPPORTED;
+    if (!fused_ok(lv_xy, lv_yt, lv_xt, sh, &d, &wide)) return NVP_ERR_UNSUPPORTED;
+    if (temporal_interp && saved) return NVP_ERR_UNSUPPORTED;          // SparseGrid.forward_inter is an inference path (eval.py --t_interp): no backward exists for it
     if (!coords || !steps || !kf_xy || !kf_yt || !kf_xt || !emb || !p || !packed_fwd || !rgb || n < 0) return NVP_ERR_BADARG;
     if ((saved || wide) && !zt) return NVP_ERR_BADARG;          // training: the latent is an output too (the dW GEMMs read it); wide latents: it is the kernel's workspace
     if (n == 0) return 0;
@@ -134,8 +135,9 @@ extern "C" int nvp_encode_mlp_fwd(const float* coords, const float* steps, const
         return 0;
     }
 #endif
-#define NVP_FUSED_LAUNCH(SV, GF) hipLaunchKernelGGL((mlp_fwd_b3_kernel<SV, GF>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d, e)
-    if (saved) { if (F == 2) NVP_FUSED_LAUNCH(true, 2); else NVP_FUSED_LAUNCH(true, 4); }
+#define NVP_FUSED_LAUNCH(SV, GF, ...) hipLaunchKernelGGL((mlp_fwd_b3_kernel<SV, GF, ##__VA_ARGS__>), grid, dim3(kWaves * 64), lds, (hipStream_t)stream, zt, steps, *p, pk, rgb, saved, n, ntiles, d, e)
+    if (temporal_interp) { if (F == 2) NVP_FUSED_LAUNCH(false, 2, true); else NVP_FUSED_LAUNCH(false, 4, true); }
+    else if (saved) { if (F == 2) NVP_FUSED_LAUNCH(true, 2); else NVP_FUSED_LAUNCH(true, 4); }
     else { if (F == 2) NVP_FUSED_LAUNCH(false, 2); else NVP_FUSED_LAUNCH(false, 4); }
 #undef NVP_FUSED_LAUNCH
     NVP_LAUNCH_CHECK();

@@ -99,7 +99,8 @@ __device__ __forceinline__ void chain_zg_b3(f32x16 (&acc)[4], const float4* __re
 // read it) and may be null otherwise.
 // One 32-pixel tile, all seven layers.  `z`: this wave's LDS latent region; `active` false: a duplicate walk whose results are not stored.
 // rgb_out: the tile pixel lane & 31's RGB (the tile-fused kernel derives the loss gradient from it).
-template <bool SAVE, int GF>
+// INTER (inference kernels only): the sparse grid's rows are SparseGrid.forward_inter's (encode_tile.h).
+template <bool SAVE, int GF, bool INTER = false>
 __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float* __restrict__ steps, const nvp_mlp_params& p, const unsigned* __restrict__ packed,
                                             float* __restrict__ rgb, float* __restrict__ saved, int64_t n, int64_t ntiles, int d, const NvpTileEnc& enc,
                                             int64_t tile, bool active, float4* __restrict__ z, int lane, float (&rgb_out)[3]) {
@@ -116,8 +117,8 @@ __device__ __forceinline__ void fwd_b3_tile(float* __restrict__ zt, const float*
     // latent tensor (which the caller then always provides) and are read back from there by the chains, like the staged path's tail
     constexpr bool kWide = GF == 4;
     if (GF == 0) mz = stage_z_absmax(z, zg, min(z4, zl4), lane);
-    else if (kWide) mz = nvp_gather_tile<(GF == 0 ? 2 : GF), kWide>(z, active ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane, zs_l * 4, SAVE);
-    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF)>(z, (SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
+    else if (kWide) mz = nvp_gather_tile<(GF == 0 ? 2 : GF), kWide, INTER>(z, active ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane, zs_l * 4, SAVE);
+    else mz = nvp_gather_tile<(GF == 0 ? 2 : GF), false, INTER>(z, (SAVE && active) ? reinterpret_cast<float4*>(zt) + tile * (int64_t)z4 : nullptr, enc, tile, n, lane);
     if (kWide && zs_l < L.zs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail rows this wave has just stored are read back below (a wave reading its own stores: the count suffices)
     for (int idx = z4 + lane; idx < zl4; idx += 64) z[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_wave_barrier();

@@ -423,7 +423,7 @@ def _scatter_ws_bytes(lib, n, lv_xy, lv_yt, lv_xt, sh) -> int:
 def materialises_nothing(model, temporal_interp: bool) -> bool:
     """True when a no-grad forward of `model` writes no per-pixel tensor besides the RGB (the fused forward takes the call): then a whole
     frame can go through one call whatever its size (harness.render_frame); otherwise the call writes the latent [n, D] and callers bound n."""
-    if temporal_interp or not FUSED_FWD:
+    if not FUSED_FWD:
         return False
     sg = model.sparse_grid
     # the shape from the module's attributes: sg._grid() would run the whole x2 upsample pass (and allocate [T, 2X, 2Y, F]) only to be measured
@@ -462,7 +462,8 @@ class NVPFused(torch.autograd.Function):
         if need_grad and not y_sorted and not temporal_interp and AUTO_SORT_MIN > 0 and n >= AUTO_SORT_MIN:
             order = _row_order(lib, coords, n, lv_xy, lv_yt)
             coords, steps, y_sorted = coords[order], steps[order], True
-        sup = int(lib.nvp_encode_mlp_fwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh))) if (bool(n) and FUSED_FWD and not temporal_interp) else 0
+        # (SparseGrid.forward_inter - eval.py --t_interp - has inference kernels only: under grad mode it takes the two-kernel path and raises below)
+        sup = int(lib.nvp_encode_mlp_fwd_supported(C.byref(lv_xy), C.byref(lv_yt), C.byref(lv_xt), C.byref(sh))) if (bool(n) and FUSED_FWD and not (temporal_interp and need_grad)) else 0
         fused = sup > 0
         fused_parks_rows = sup == 2        # config_nvp_l-sized latents: the rows beyond the wave's LDS tile pass through the latent tensor even without a backward pass
         # the latent tensor: an intermediate of the two-kernel path; with the fused forward it only exists for the backward pass (or as that workspace)

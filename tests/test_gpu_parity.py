@@ -793,6 +793,56 @@ def test_wide_latent_fused_forward_inference_and_chunked_frames():
     assert torch.equal(frames[0], frames[1])
 
 
+@pytest.mark.parametrize("F", [2, 4])
+def test_forward_inter_through_the_fused_forward(F):
+    """SparseGrid.forward_inter (sparsegrid.py:76-156; eval.py --t_interp, modules.py:72-73) inside the ONE-launch forward (round 6:
+    nvp_encode_mlp_fwd with temporal_interp = 1, inference kernels; the in-wave gather blends the t_lo / t_hi rows as the stand-alone
+    gather does).  No-grad NVP.forward(temporal_interp=True): (a) bit-identical to the two-kernel path (gather kernel -> latent in HBM
+    -> MLP kernel), NaN rows included - pixels at t == 1 hit the reference's 0 / 0 weights; (b) the oracle's forward_inter to 1e-5 on
+    the finite rows, the same NaN pattern; (c) under grad mode the call still raises (no backward exists for this path, as in the
+    reference, which only evaluates with it); both latent widths (config_nvp_s 114 rows / config_nvp_l 228 rows)."""
+    from nvp_amd import _lib as L, functional
+    cfg, sd, model = _nvp_pair(F, seed=6, T=6, X=11, Y=9)
+    gen = torch.Generator().manual_seed(12)
+    n = 1000 + 37
+    coords, steps = torch.rand((1, n, 3), generator=gen), torch.rand((1, n), generator=gen)
+    coords[0, :40, 0] = 1.0                                  # the NaN quirk: tf == T - 1
+    coords[0, 40:80, 0] = torch.arange(40) / 39.0            # lattice values of t incl. exact 0
+    mi = {"all_coords": coords.to(dev()), "temporal_steps": steps.to(dev())}
+    lib = L.load()
+    import ctypes as C
+    sh = functional._sparse_shape(model.sparse_grid.embeddings)
+    assert int(lib.nvp_encode_mlp_fwd_supported(C.byref(model.keyframes_xy.levels), C.byref(model.keyframes_yt.levels),
+                                                C.byref(model.keyframes_xt.levels), C.byref(sh))) == (1 if F == 2 else 2)
+    calls = []
+    orig = functional._call
+
+    def spy(name, fn, *a):
+        calls.append(name)
+        return orig(name, fn, *a)
+    functional._call = spy
+    try:
+        with torch.no_grad():
+            fused = model(mi, temporal_interp=True)["model_out"]
+            assert "nvp_encode_mlp_fwd" in calls and "nvp_encode_fwd" not in calls, calls
+            calls.clear()
+            functional.FUSED_FWD = False
+            try:
+                two = model(mi, temporal_interp=True)["model_out"]
+            finally:
+                functional.FUSED_FWD = True
+            assert "nvp_encode_fwd" in calls and "nvp_encode_mlp_fwd" not in calls, calls
+            want = O.nvp_forward(coords, steps, sd, cfg, temporal_interp=True)
+    finally:
+        functional._call = orig
+    assert torch.equal(fused.isnan(), two.isnan()) and torch.equal(torch.nan_to_num(fused), torch.nan_to_num(two)), "fused forward_inter != two-kernel path"
+    got = fused.cpu()
+    assert torch.equal(got.isnan(), want.isnan()) and bool(got[0, :40].isnan().all()) and not bool(got[0, 80:].isnan().any())
+    assert float((got - want)[~want.isnan()].abs().max()) <= RGB_TOL
+    with pytest.raises(NotImplementedError):
+        model(mi, temporal_interp=True)
+
+
 def test_batch_dim_and_param_rebinding_like_eval():
     """b > 1 (utils.py:70-80 uses b=4) and eval.py:170-179 style parameter re-assignment."""
     cfg, sd, model = _nvp_pair(2)
