@@ -11,12 +11,12 @@
 // where the 32 pixels of a tile are contiguous -> every store/load is a full 128-B line.
 //
 // Index arithmetic reproduces the reference's separately rounded fp32 ops
-// (sparsegrid.py:44-46): products and sums go through __fmul_rn/__fadd_rn so hipcc cannot
+// (sparsegrid.py:44-46): products and sums go through nvp_mul_rn / nvp_add_rn (nvp_common.h) so hipcc cannot
 // contract them into an FMA and flip a cell at a .5 boundary.
 #include <cstdlib>
 #include "encode_gather.h"
 
-// __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
+// (__fmul_rn / __fadd_rn are plain operators in this HIP and fuse after inlining.)  Also forbid FMA contraction for the whole TU so
 // index and interpolation arithmetic keeps the reference's separately rounded multiply and add.
 #pragma clang fp contract(off)
 
@@ -129,7 +129,7 @@ __device__ __forceinline__ void sparse_fwd(const float* __restrict__ emb, const 
             for (int f = 0; f < F && f < 8; ++f) {
                 float v;
                 if (!inter) v = lo[f];
-                else v = __fadd_rn(__fmul_rn(lo[f], p.w_lo), __fmul_rn(hi[f], p.w_hi));
+                else v = nvp_add_rn(nvp_mul_rn(lo[f], p.w_lo), nvp_mul_rn(hi[f], p.w_hi));
                 row[j * F + f] = v;
             }
         }
@@ -172,7 +172,7 @@ __device__ __forceinline__ void sparse_fwd_ptm(const float* __restrict__ emb, co
 #pragma unroll
                 for (int c = 0; c < 3 * F; ++c) hi[c] = ph[c];
 #pragma unroll
-                for (int c = 0; c < 3 * F; ++c) lo[c] = __fadd_rn(__fmul_rn(lo[c], p.w_lo), __fmul_rn(hi[c], p.w_hi));
+                for (int c = 0; c < 3 * F; ++c) lo[c] = nvp_add_rn(nvp_mul_rn(lo[c], p.w_lo), nvp_mul_rn(hi[c], p.w_hi));
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {

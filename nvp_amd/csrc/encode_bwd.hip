@@ -595,15 +595,15 @@ __global__ __launch_bounds__(kBandThreads) void band_kernel(BandArgs A, int64_t 
             hit |= (unsigned)off[cnr] < (unsigned)span;
         }
         if (!any || !hit) continue;
-        const float w0 = __fsub_rn(p0, f0), w1 = __fsub_rn(p1, f1);
-        const float u0 = __fsub_rn(1.0f, w0), u1 = __fsub_rn(1.0f, w1);
-        const float w[4] = {__fmul_rn(u0, u1), __fmul_rn(w0, u1), __fmul_rn(u0, w1), __fmul_rn(w0, w1)};      // == nvp_bilerp_setup
+        const float w0 = nvp_sub_rn(p0, f0), w1 = nvp_sub_rn(p1, f1);
+        const float u0 = nvp_sub_rn(1.0f, w0), u1 = nvp_sub_rn(1.0f, w1);
+        const float w[4] = {nvp_mul_rn(u0, u1), nvp_mul_rn(w0, u1), nvp_mul_rn(u0, w1), nvp_mul_rn(w0, w1)};      // == nvp_bilerp_setup
 #pragma unroll
         for (int cnr = 0; cnr < 4; ++cnr) {
             if ((unsigned)off[cnr] >= (unsigned)span) continue;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const long long q = to_fixed(__fmul_rn(w[cnr], g[f]), fs);
+                const long long q = to_fixed(nvp_mul_rn(w[cnr], g[f]), fs);
                 atomicAdd(&tab[off[cnr] * F + f], (unsigned long long)q);
             }
         }

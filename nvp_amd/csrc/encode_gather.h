@@ -57,13 +57,13 @@ __device__ __forceinline__ Patch patch_setup(float t, float x, float y, const nv
         p.w_lo = 1.f; p.w_hi = 0.f;
     } else {
         // reference sparsegrid.py:98-109 (note: lc is divided by the UPDATED uc + lc)
-        float tf = __fmul_rn((float)(sh.t_res - 1), t);
+        float tf = nvp_mul_rn((float)(sh.t_res - 1), t);
         int lo = (int)tf;
-        int hi = min(max((int)__fadd_rn(tf, 1.0f), 0), sh.t_res - 1);
-        float uc = __fsub_rn(tf, (float)lo);
-        float lc = __fsub_rn((float)hi, tf);
-        uc = __fdiv_rn(uc, __fadd_rn(uc, lc));
-        lc = __fdiv_rn(lc, __fadd_rn(uc, lc));
+        int hi = min(max((int)nvp_add_rn(tf, 1.0f), 0), sh.t_res - 1);
+        float uc = nvp_sub_rn(tf, (float)lo);
+        float lc = nvp_sub_rn((float)hi, tf);
+        uc = nvp_div_rn(uc, nvp_add_rn(uc, lc));
+        lc = nvp_div_rn(lc, nvp_add_rn(uc, lc));
         p.t_lo = min(max(lo, 0), sh.t_res - 1);   // reference indexes E[lo] unclamped; lo is in range for t in [0,1]
         p.t_hi = hi;
         p.w_lo = lc; p.w_hi = uc;

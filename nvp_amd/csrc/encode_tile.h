@@ -82,9 +82,9 @@ __device__ __forceinline__ float tile_plane(const TileDst<WIDE>& dst, const floa
         // == nvp_bilerp_setup(x0, x1, scale, res, kTileFlags), with the cell wrap as selects
         const float p0 = nvp_grid_pos(x0, scale, kTileFlags), p1 = nvp_grid_pos(x1, scale, kTileFlags);
         const float f0 = floorf(p0), f1 = floorf(p1);
-        const float w0 = __fsub_rn(p0, f0), w1 = __fsub_rn(p1, f1);
-        const float u0 = __fsub_rn(1.0f, w0), u1 = __fsub_rn(1.0f, w1);
-        w[k][0] = __fmul_rn(u0, u1); w[k][1] = __fmul_rn(w0, u1); w[k][2] = __fmul_rn(u0, w1); w[k][3] = __fmul_rn(w0, w1);
+        const float w0 = nvp_sub_rn(p0, f0), w1 = nvp_sub_rn(p1, f1);
+        const float u0 = nvp_sub_rn(1.0f, w0), u1 = nvp_sub_rn(1.0f, w1);
+        w[k][0] = nvp_mul_rn(u0, u1); w[k][1] = nvp_mul_rn(w0, u1); w[k][2] = nvp_mul_rn(u0, w1); w[k][3] = nvp_mul_rn(w0, w1);
         const int i0 = (int)f0, i1 = (int)f1;
         const int size = res * res;
         int c[4];
@@ -190,7 +190,7 @@ __device__ __forceinline__ void tile_sparse_fetch(SparseFetch<F>& sf, const NvpT
 #pragma unroll
             for (int c = 0; c < 3 * F; ++c) hi[c] = ph[c];
 #pragma unroll
-            for (int c = 0; c < 3 * F; ++c) sf.lo[s2][c] = __fadd_rn(__fmul_rn(sf.lo[s2][c], p.w_lo), __fmul_rn(hi[c], p.w_hi));
+            for (int c = 0; c < 3 * F; ++c) sf.lo[s2][c] = nvp_add_rn(nvp_mul_rn(sf.lo[s2][c], p.w_lo), nvp_mul_rn(hi[c], p.w_hi));
         }
     }
 }

@@ -17,7 +17,7 @@
 // pos along one axis; floor / fract are taken by the caller
 __device__ __forceinline__ float nvp_grid_pos(float x, float scale, int flags) {
     if (flags & NVP_GRID_POS_FMA) return __builtin_fmaf(scale, x, 0.5f);
-    return __fadd_rn(__fmul_rn(x, scale), 0.5f);
+    return nvp_add_rn(nvp_mul_rn(x, scale), 0.5f);
 }
 
 struct NvpBilerp {
@@ -41,14 +41,14 @@ __device__ __forceinline__ int nvp_grid_cell(int i0, int i1, int a, int b, int r
 __device__ __forceinline__ NvpBilerp nvp_bilerp_setup(float x0, float x1, float scale, int res, int flags) {
     const float p0 = nvp_grid_pos(x0, scale, flags), p1 = nvp_grid_pos(x1, scale, flags);
     const float f0 = floorf(p0), f1 = floorf(p1);
-    const float w0 = __fsub_rn(p0, f0), w1 = __fsub_rn(p1, f1);
-    const float u0 = __fsub_rn(1.0f, w0), u1 = __fsub_rn(1.0f, w1);
+    const float w0 = nvp_sub_rn(p0, f0), w1 = nvp_sub_rn(p1, f1);
+    const float u0 = nvp_sub_rn(1.0f, w0), u1 = nvp_sub_rn(1.0f, w1);
     NvpBilerp b;
     b.i0 = (int)f0; b.i1 = (int)f1;
-    b.w[0] = __fmul_rn(u0, u1);
-    b.w[1] = __fmul_rn(w0, u1);
-    b.w[2] = __fmul_rn(u0, w1);
-    b.w[3] = __fmul_rn(w0, w1);
+    b.w[0] = nvp_mul_rn(u0, u1);
+    b.w[1] = nvp_mul_rn(w0, u1);
+    b.w[2] = nvp_mul_rn(u0, w1);
+    b.w[3] = nvp_mul_rn(w0, w1);
 #pragma unroll
     for (int c = 0; c < 4; ++c) b.cell[c] = nvp_grid_cell(b.i0, b.i1, c & 1, c >> 1, res, flags);
     return b;
@@ -57,23 +57,23 @@ __device__ __forceinline__ NvpBilerp nvp_bilerp_setup(float x0, float x1, float 
 // one feature of the 4-corner blend, corners in order, in the arithmetic `flags` selects
 __device__ __forceinline__ float nvp_blend4(const float (&w)[4], float v0, float v1, float v2, float v3, int flags) {
     if (flags & NVP_GRID_INTERP_FMA) {
-        float a = __fmul_rn(w[0], v0);           // fma(w, v, 0) == fl(w*v)
+        float a = nvp_mul_rn(w[0], v0);           // fma(w, v, 0) == fl(w*v)
         a = __builtin_fmaf(w[1], v1, a);
         a = __builtin_fmaf(w[2], v2, a);
         a = __builtin_fmaf(w[3], v3, a);
         return a;
     }
-    float a = __fmul_rn(w[0], v0);
-    a = __fadd_rn(a, __fmul_rn(w[1], v1));
-    a = __fadd_rn(a, __fmul_rn(w[2], v2));
-    a = __fadd_rn(a, __fmul_rn(w[3], v3));
+    float a = nvp_mul_rn(w[0], v0);
+    a = nvp_add_rn(a, nvp_mul_rn(w[1], v1));
+    a = nvp_add_rn(a, nvp_mul_rn(w[2], v2));
+    a = nvp_add_rn(a, nvp_mul_rn(w[3], v3));
     return a;
 }
 
 // clamp(int64(fp32((res-1)*c) + 0.5), 0, res-1)   reference sparsegrid.py:44-46 (mul and add rounded separately,
 // conversion truncates toward zero like .type(int64))
 __device__ __forceinline__ int nvp_nearest_idx(float c, int res) {
-    const float f = __fmul_rn((float)(res - 1), c);
-    const int i = (int)__fadd_rn(f, 0.5f);
+    const float f = nvp_mul_rn((float)(res - 1), c);
+    const int i = (int)nvp_add_rn(f, 0.5f);
     return min(max(i, 0), res - 1);
 }

@@ -4,7 +4,7 @@
 // fused with its own gradient.
 #include "grid_math.h"
 
-// __fmul_rn/__fadd_rn are plain operators in this HIP: forbid FMA contraction for the whole TU so
+// (__fmul_rn / __fadd_rn are plain operators in this HIP and fuse after inlining.)  Also forbid FMA contraction for the whole TU so
 // index and interpolation arithmetic keeps the reference's separately rounded multiply and add.
 #pragma clang fp contract(off)
 
@@ -23,8 +23,8 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const uint8_t* __res
     const int64_t t = ti[src_k], p = pi[src_k];
     const int row = (int)(p / width), col = (int)(p - (int64_t)row * width);
     coords[k * 3 + 0] = tcoord_tab[t];
-    coords[k * 3 + 1] = __fdiv_rn((float)row, (float)(height - 1));
-    coords[k * 3 + 2] = __fdiv_rn((float)col, (float)(width - 1));
+    coords[k * 3 + 1] = nvp_div_rn((float)row, (float)(height - 1));
+    coords[k * 3 + 2] = nvp_div_rn((float)col, (float)(width - 1));
     steps[k] = tstep_tab[t];
     const uint8_t* src = video + (t * (int64_t)height * width + p) * 3;
     gt[k * 3 + 0] = src[0];
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(1024) void mse_u8_kernel(const float* __restrict__ 
         float dv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float g = __fdiv_rn(__fsub_rn(uv[e], 127.5f), 127.5f);
+            const float g = nvp_div_rn(nvp_sub_rn(uv[e], 127.5f), 127.5f);
             const float df = rv[e] - g;
             local = __fmaf_rn(df, df, local);
             dv[e] = df * gscale;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(1024) void mse_u8_kernel(const float* __restrict__ 
         if (drgb) reinterpret_cast<float4*>(drgb)[q] = make_float4(dv[0], dv[1], dv[2], dv[3]);
     }
     for (int64_t k = 4 * n4 + tid; k < n3; k += nthr) {
-        const float g = __fdiv_rn(__fsub_rn((float)gt[k], 127.5f), 127.5f);
+        const float g = nvp_div_rn(nvp_sub_rn((float)gt[k], 127.5f), 127.5f);
         const float df = rgb[k] - g;
         local = __fmaf_rn(df, df, local);
         if (drgb) drgb[k] = df * gscale;

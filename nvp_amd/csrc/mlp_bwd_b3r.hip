@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void step_b3_kernel(float* __restri
     if (px < n) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float q = __fdiv_rn(__fsub_rn((float)gt[px * 3 + c], 127.5f), 127.5f);
+            const float q = nvp_div_rn(nvp_sub_rn((float)gt[px * 3 + c], 127.5f), 127.5f);
             const float df = rgb_px[c] - q;
             g[c] = df * gscale;
         }

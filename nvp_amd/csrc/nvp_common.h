@@ -11,6 +11,32 @@
 #define NVP_EXPERIMENTS 0
 #endif
 
+// ---- separately rounded fp32 operations --------------------------------------------------------------------------------------------
+// hipcc's __fmul_rn / __fadd_rn / __fsub_rn / __fdiv_rn are plain `*` `+` `-` `/` compiled INSIDE clang's own header, where contraction
+// is allowed: once inlined, a product that feeds a sum fuses into ONE v_fma_f32 whatever `#pragma clang fp contract` the caller is
+// under (round 6, seen in the ISA of the fused forward - a translation unit built with contraction on: SparseGrid.forward_inter's blend
+// lo * w_lo + hi * w_hi came out as fma(lo, w_lo, hi * w_hi), one ulp away from the stand-alone gather kernel on 80 % of the pixels; the
+// nearest index trunc(fl((res - 1) c) + 0.5) was a v_fma too - harmless there: rounding to the grid of ulp(p) commutes with adding 0.5,
+// an exhaustive-ish host search over 24 M coordinates finds no index that differs).  The operations below are compiled under
+// contract(off) INSIDE their own bodies: they carry no contract flag, so nothing fuses through them, in any translation unit.  Every
+// index / weight / blend computation that must keep the reference's separately rounded operations uses these.
+__device__ __forceinline__ float nvp_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float nvp_add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float nvp_sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float nvp_div_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 #define NVP_H NVP_HIDDEN
 #define NVP_T NVP_TILE
 

@@ -9,7 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-ORACLE_THREADS = 16
+ORACLE_THREADS = 8
+# Thread count of the oracle's background TRAININGS (util_windows.py --oracle, util_traj.py).  The GPU boxes give a container a CPU
+# quota of 16 cores (cgroup cpu.max) on a 256-thread host: a training of the small problem (8 192-pixel batches) gains nothing from 16
+# threads (fork-join per small op), and several trainings share the quota.  Fixed (not host-dependent) for the same reason as above.
+# Measured on an MI355X host (gpurun_out/r06_oracle_threads.txt -> profiles/): 100 steps of the windowed walk with two controls take 20.7 /
+# 22.1 / 24.1 / 29.5 s on 16 / 8 / 4 / 2 threads; four walks at once on 4 threads each: 25.1 s for all four.  Two threads per training
+# leave half of the quota to the foreground tests while four trainings run underneath them.
+ORACLE_TRAIN_THREADS = int(os.environ.get("NVP_ORACLE_TRAIN_THREADS", "2"))
 
 
 class oracle_determinism:
@@ -17,10 +24,13 @@ class oracle_determinism:
     so the checker's trajectory is reproducible run to run and box to box.  Scoped, because deterministic mode makes some ATen
     device kernels used elsewhere in the suite raise."""
 
+    def __init__(self, threads=None):
+        self.threads = threads or ORACLE_THREADS
+
     def __enter__(self):
         import torch
         self._n, self._det = torch.get_num_threads(), torch.are_deterministic_algorithms_enabled()
-        torch.set_num_threads(ORACLE_THREADS)
+        torch.set_num_threads(self.threads)
         torch.use_deterministic_algorithms(True)
         return self
 
@@ -51,8 +61,9 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # The CPU oracle is the CHECKER: its results must not depend on the host it runs on.  ATen's CPU kernels partition their
     # reductions by the intra-op thread count, so the count is FIXED (not "whatever the box has, capped"): the builder's box and the
-    # driver's box then walk the same oracle trajectory.  (16 is also faster than the GPU hosts' default 128: fork-join over two NUMA
-    # nodes per small op.)
+    # driver's box then walk the same oracle trajectory.  8: the GPU boxes give the container a quota of 16 CPUs (cgroup cpu.max) of a
+    # 256-thread host, the oracle's background trainings (util_background.py) take half of it, and bench.py's thread sweep measures the
+    # oracle's forward + backward fastest on 8 threads there (1.53 s against 1.81 s on 16, 27 s on 128 for 155 648 pixels).
     import torch
     torch.set_num_threads(ORACLE_THREADS)
     os.environ.setdefault("NVP_QUIET", "1")        # NVP.__init__ prints the module tree like the reference (modules.py:49): keep the driver's tail for numbers

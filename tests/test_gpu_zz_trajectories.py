@@ -24,7 +24,7 @@ import torch
 
 import nvp_oracle as O
 import util_background as background
-from conftest import ROOT, report, say, small_cfg
+from conftest import ORACLE_TRAIN_THREADS, ROOT, report, say, small_cfg
 from util_parity import _load_state_into
 from util_windows import window_verdicts
 
@@ -137,7 +137,7 @@ def test_psnr_at_equal_steps_matches_oracle(seed):
     pa, pb, ev_a, ev_b = orc["psnr"], orc["psnr_1ulp"], orc["eval"], orc["eval_1ulp"]
     pg, ev_g = _hip_trajectory(spec, video, log=os.environ.get("NVP_PSNR_LOG"))
     steps_total = spec["steps"]
-    assert len(pa) == len(pb) == len(pg) == steps_total and orc["threads"] == 16
+    assert len(pa) == len(pb) == len(pg) == steps_total and orc["threads"] == ORACLE_TRAIN_THREADS
     assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
     gap = [abs(a - g) for a, g in zip(pa, pg)]
     env = [abs(a - b) for a, b in zip(pa, pb)]

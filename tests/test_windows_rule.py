@@ -5,7 +5,7 @@ import os
 import subprocess
 import sys
 
-from conftest import ROOT
+from conftest import ORACLE_TRAIN_THREADS, ROOT
 from util_windows import oracle_env, window_verdicts
 
 
@@ -42,4 +42,4 @@ def test_oracle_walk_is_reproducible(tmp_path):
         outs.append(json.load(open(os.path.join(d, "o.json"))))
         assert sorted(f for f in os.listdir(d) if f.startswith("win_")) == ["win_000.pt", "win_001.pt"]
     assert outs[0]["psnr"] == outs[1]["psnr"] and outs[0]["controls"] == outs[1]["controls"] and outs[0]["eval"] == outs[1]["eval"]
-    assert outs[0]["threads"] == 16 and len(outs[0]["lr"]) == 4
+    assert outs[0]["threads"] == ORACLE_TRAIN_THREADS and len(outs[0]["lr"]) == 4

@@ -40,7 +40,7 @@ def problem(spec: dict):
 
 def oracle_trajectory(spec: dict, out_dir: str) -> dict:
     import nvp_oracle as O
-    from conftest import oracle_determinism
+    from conftest import ORACLE_TRAIN_THREADS, oracle_determinism
     from util_windows import ulp_perturbed
     cfg, sd, video = problem(spec)
     torch.save(video, os.path.join(out_dir, f"video_{spec['name']}.pt"))
@@ -56,7 +56,7 @@ def oracle_trajectory(spec: dict, out_dir: str) -> dict:
     if spec.get("ulp_twin"):
         runs.append(make_ref(ulp_perturbed(sd, spec["seed"] + 1000)))
     gen = torch.Generator().manual_seed(spec["gen_seed"])
-    with oracle_determinism():
+    with oracle_determinism(ORACLE_TRAIN_THREADS):
         for _ in range(steps_total):
             ti, pi, coords, tstep = O.sample_batch(T, H, W, N_BATCH, gen)          # the reference's sampler order
             gt = O.normalise_gt(flat[ti, pi].unsqueeze(0))
@@ -84,8 +84,8 @@ if __name__ == "__main__":
     ap.add_argument("--dir", required=True)
     ap.add_argument("--specs", required=True, help="JSON list of specs; one result file traj_<name>.json per spec, written as each finishes")
     a = ap.parse_args()
-    from conftest import ORACLE_THREADS
-    torch.set_num_threads(ORACLE_THREADS)
+    from conftest import ORACLE_TRAIN_THREADS
+    torch.set_num_threads(ORACLE_TRAIN_THREADS)
     os.makedirs(a.dir, exist_ok=True)
     for spec in json.loads(a.specs):
         r = oracle_trajectory(spec, a.dir)

@@ -62,12 +62,12 @@ def _psnr(loss) -> float:
 def oracle_walk(seed: int, steps_total: int, window: int, n_controls: int, out_dir: str):
     """-> {"psnr": [...], "controls": [[...]] * n_controls, "eval": dB}; writes win_###.pt and meta.json into out_dir."""
     import nvp_oracle as O
-    from conftest import oracle_determinism
+    from conftest import ORACLE_TRAIN_THREADS, oracle_determinism
     cfg, sd, video = problem(seed)
     flat = video.reshape(T, H * W, 3)
     os.makedirs(out_dir, exist_ok=True)
     torch.save(video, os.path.join(out_dir, "video.pt"))      # the replaying processes take THIS clip (no second synthesis under other thread settings)
-    with oracle_determinism():
+    with oracle_determinism(ORACLE_TRAIN_THREADS):
         ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         opt = torch.optim.AdamW(list(ref.values()), lr=1e-2, weight_decay=0.001)                       # training.py:13
         sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps_total, eta_min=1e-5)          # training.py:14
@@ -217,9 +217,9 @@ def oracle_env():
     """Environment of the oracle's process: MKL's conditional numerical reproducibility on one code path (run-to-run and
     alignment-independent sgemm results), a fixed thread count for OpenMP and MKL.  Set before the process starts - MKL reads
     MKL_CBWR once - which is why the oracle of this comparison runs in a process of its own."""
-    from conftest import ORACLE_THREADS
+    from conftest import ORACLE_TRAIN_THREADS
     env = dict(os.environ)
-    env.update(MKL_CBWR="AVX2", OMP_NUM_THREADS=str(ORACLE_THREADS), MKL_NUM_THREADS=str(ORACLE_THREADS), MKL_DYNAMIC="FALSE", OMP_DYNAMIC="FALSE")
+    env.update(MKL_CBWR="AVX2", OMP_NUM_THREADS=str(ORACLE_TRAIN_THREADS), MKL_NUM_THREADS=str(ORACLE_TRAIN_THREADS), MKL_DYNAMIC="FALSE", OMP_DYNAMIC="FALSE")
     env.pop("NVP_HIP_LIB", None)
     return env
 
@@ -236,8 +236,8 @@ if __name__ == "__main__":
     ap.add_argument("--controls", type=int, default=2)
     a = ap.parse_args()
     if a.oracle:
-        from conftest import ORACLE_THREADS
-        torch.set_num_threads(ORACLE_THREADS)
+        from conftest import ORACLE_TRAIN_THREADS
+        torch.set_num_threads(ORACLE_TRAIN_THREADS)
         r = oracle_walk(a.seed, a.steps, a.window, a.controls, a.dir)
     else:
         r = hip_walk(a.dir, free=bool(a.free))
