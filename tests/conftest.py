@@ -17,6 +17,10 @@ ORACLE_THREADS = 8
 # 22.1 / 24.1 / 29.5 s on 16 / 8 / 4 / 2 threads; four walks at once on 4 threads each: 25.1 s for all four.  Two threads per training
 # leave half of the quota to the foreground tests while four trainings run underneath them.
 ORACLE_TRAIN_THREADS = int(os.environ.get("NVP_ORACLE_TRAIN_THREADS", "2"))
+# ... the two 1 000-step windowed walks (3 000 oracle steps each: the suite's critical path) get four.  The thread count is a scheduling
+# choice only: under deterministic algorithms + MKL_CBWR the walk's numbers came out identical to the last digit on 16 and on 2 threads
+# (profiles/r05_psnr_windows_seeds_boxes.txt vs gpurun r06b: max product gap 0.0066 / 0.0185 dB, envelope 0.0207 / 0.0123 for seeds 7 / 8).
+ORACLE_WALK_THREADS = int(os.environ.get("NVP_ORACLE_WALK_THREADS", "4"))
 
 
 class oracle_determinism:
@@ -74,7 +78,15 @@ def pytest_collection_modifyitems(config, items):
     # after everything else, whatever its file is called - a margin can then never hide a deterministic test behind `-x`.
     # Before them: golden-vector and oracle parity (test_gpu_parity), the real configuration sizes, the twin, then the multi-process tests.
     order = ("test_gpu_parity", "test_gpu_real_configs", "test_gpu_twin", "test_gpu_dp2")
-    items.sort(key=lambda it: next((i for i, n in enumerate(order) if n in it.nodeid), len(order) + (1 if "zz_trajectories" in it.nodeid else 0)))
+    # inside the trajectory group: first what needs no oracle job (the full-size fp16x2-vs-twin run), last what waits for the longest ones
+    # (the 1 000-step windowed walks): the background trainings started at collection time have the whole suite to finish in
+    zz = ("test_fp16x2_split_tracks", "test_psnr_at_equal_steps_matches_oracle", "test_psnr_at_equal_steps_full_levels", "test_psnr_tracks_the_oracle")
+
+    def rank(it):
+        if "zz_trajectories" in it.nodeid:
+            return (len(order) + 1, next((i for i, n in enumerate(zz) if n in it.nodeid), len(zz)))
+        return (next((i for i, n in enumerate(order) if n in it.nodeid), len(order)), 0)
+    items.sort(key=rank)
     import torch
     if torch.cuda.is_available():
         return

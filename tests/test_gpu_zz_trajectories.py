@@ -24,9 +24,9 @@ import torch
 
 import nvp_oracle as O
 import util_background as background
-from conftest import ORACLE_TRAIN_THREADS, ROOT, report, say, small_cfg
+from conftest import ORACLE_TRAIN_THREADS, ORACLE_WALK_THREADS, ROOT, report, say, small_cfg
 from util_parity import _load_state_into
-from util_windows import window_verdicts
+from util_windows import oracle_env, window_verdicts
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +70,7 @@ def background_jobs(nodeids):
     if "test_psnr_tracks_the_oracle_along_a_1000_step_schedule" in ids:
         for seed in WINDOW_SEEDS:
             if f"schedule[{seed}]" in ids:
-                background.start(f"windows_seed{seed}", _windows_argv(seed))
+                background.start(f"windows_seed{seed}", _windows_argv(seed), env=oracle_env(ORACLE_WALK_THREADS))
     if "test_psnr_at_equal_steps_full_levels" in ids:
         background.start("traj_full", _traj_argv("traj_full", [SPEC_FULL]))
     if "test_psnr_at_equal_steps_matches_oracle" in ids:
@@ -157,7 +157,8 @@ def _walk_windows(seed):
     walks are chains of small launches with host round trips in between - two of them share the GPU without slowing each other
     much); returns the three results"""
     from util_windows import hip_walk
-    d = background.result(f"windows_seed{seed}", _windows_argv(seed))
+    background.start(f"windows_seed{seed}", _windows_argv(seed), env=oracle_env(ORACLE_WALK_THREADS))        # (no-op when collection started it)
+    d = background.result(f"windows_seed{seed}")
     orc = json.load(open(os.path.join(d, "oracle.json")))
     env = dict(os.environ)
     env["NVP_HIP_LIB"] = TWIN

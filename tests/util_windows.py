@@ -213,13 +213,14 @@ def window_verdicts(gp, gt, env, abs_bound=0.02, calm=0.01, twin_margin=0.005, e
     return bad
 
 
-def oracle_env():
+def oracle_env(threads=None):
     """Environment of the oracle's process: MKL's conditional numerical reproducibility on one code path (run-to-run and
     alignment-independent sgemm results), a fixed thread count for OpenMP and MKL.  Set before the process starts - MKL reads
     MKL_CBWR once - which is why the oracle of this comparison runs in a process of its own."""
     from conftest import ORACLE_TRAIN_THREADS
+    n = str(threads or ORACLE_TRAIN_THREADS)
     env = dict(os.environ)
-    env.update(MKL_CBWR="AVX2", OMP_NUM_THREADS=str(ORACLE_TRAIN_THREADS), MKL_NUM_THREADS=str(ORACLE_TRAIN_THREADS), MKL_DYNAMIC="FALSE", OMP_DYNAMIC="FALSE")
+    env.update(MKL_CBWR="AVX2", OMP_NUM_THREADS=n, MKL_NUM_THREADS=n, MKL_DYNAMIC="FALSE", OMP_DYNAMIC="FALSE", NVP_ORACLE_TRAIN_THREADS=n)
     env.pop("NVP_HIP_LIB", None)
     return env
 

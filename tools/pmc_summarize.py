@@ -5,7 +5,7 @@ HBM bytes per launch follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WR
 and come from separate --pmc passes; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
 (16 B/lane) coalesced read, which is what every stream in these kernels is, so it is doubled;
 WRITE_SIZE is used as reported (uncalibrated in the guide)."""
-import collections, csv, json, os, sys
+import collections, csv, json, os, re, sys
 tag = sys.argv[1]
 config = sys.argv[2] if len(sys.argv) > 2 else "s"           # bench.py --config this pass was collected with
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,9 @@ def short(name):
 
 
 def stage_of(name):
+    m = re.search(r"mlp_fwd_b3_kernel<(?:true|false), (\d+)", name)
+    if m:                                            # <SAVE, GF, INTER>: GF != 0 = the gather runs inside the forward (nvp_encode_mlp_fwd)
+        return "nvp_encode_mlp_fwd" if int(m.group(1)) else "nvp_mlp_fwd"
     for k, v in KEYS.items():
         if k in name and ("sparse_" in name) == ("sparse_" in k):
             return v
