@@ -22,9 +22,13 @@ Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
   "roofline":     dominant kernel's algorithmic FLOP (or bytes) per launch / its HIP-event
                   duration inside the timed region, vs the gfx950 peak;
   "cpu_baseline": the oracle (pure-PyTorch CPU port of the reference path) timed on this
-                  host's cores on a bounded sample of the same workload (N=1 run only);
+                  host's cores (N=1 run only): a thread sweep on N/8 samples, `value` = the best
+                  thread count on one full-N step, the all-cores figure beside it;
   "kernels_ms":   mean ms of every hot-path kernel stage, "fwd_bwd_mpx_s": hot path only;
+  "confirmation": the timed loop continued for 10 x K (100 ... 300) steps without stage events: a second clock on `value`;
   "isolated":     (N=1) the same steps with every side stream off: each stage's span alone;
+  "dp_floor":     (N=1) ms per step of one GPU through the data-parallel gradient route laid out as rank 0 of 1 / 2 / 4 / 8 ranks, no
+                  exchange, next to the xGMI link model (SURVEY 8e): what an N-GPU step cannot be faster than;
   "reference_surface": (N=1) the same model driven through the reference's own loop shape (training.py:42-76: raw-order
                   batches, torch-expression MSE, torch.optim.AdamW - stock, and routed by compat.install(optimizer=True));
   "dp" (N>1):     the exchange scheme, the autotune timings and, per rank, the HIP-event time between
@@ -385,7 +389,7 @@ def other_configs(args) -> dict:
     out = {}
     for c in ("l", "4k"):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config", c, "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--prewarm", str(args.prewarm), "--no-cpu-baseline", "--no-isolate", "--no-reference-surface", "--no-other-configs", "--no-dp-floor"]
+               "--prewarm", str(args.prewarm), "--no-cpu-baseline", "--no-isolate", "--no-reference-surface", "--no-other-configs", "--no-dp-floor", "--no-confirm"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -537,6 +541,9 @@ def main():
     ap.add_argument("--no-reference-surface", action="store_true",
                     help="N = 1: skip the third timed pass that drives the model the way the reference's training.py:42-76 does (raw-order "
                          "batches, torch-expression MSE, torch.optim.AdamW), recorded as 'reference_surface'")
+    ap.add_argument("--no-confirm", action="store_true",
+                    help="skip the confirmation pass: 10 x --steps (100 ... 300) more steps of the same loop right after the timed region, without "
+                         "stage events, reported as 'confirmation' (the timed region of the default run is 0.13 s long)")
     ap.add_argument("--no-dp-floor", action="store_true",
                     help="N = 1: skip the short passes through the data-parallel gradient route (flat bucket + ShardedAdamW laid out for 1 / 2 / 4 / 8 "
                          "ranks, no exchange), recorded as 'dp_floor' next to the xGMI link model")
@@ -607,7 +614,8 @@ def main():
     data = harness.DeviceVideo(video, n_samples=N_PX, seed=rank,   # rank-offset sampler seed
                                sort_by_y=os.environ.get("NVP_BENCH_UNSORTED", "0") != "1",
                                prefetch=os.environ.get("NVP_SAMPLER_PREFETCH", "1") != "0")   # next batch drawn on a side stream: -0.05 ms (eight interleaved 40-step runs: 7.42-7.44 vs 7.47-7.49)
-    total = args.prewarm + args.warmup + 2 * args.steps       # cosine horizon: pre-warm + warm-up + the timed pass + the isolated pass
+    n_confirm = min(max(10 * args.steps, 100), 300) if args.steps > 0 and not args.no_confirm else 0
+    total = args.prewarm + args.warmup + 2 * args.steps + n_confirm       # cosine horizon: pre-warm + warm-up + the timed pass + the isolated pass + the confirmation pass
     multi = world > 1 or os.environ.get("NVP_FORCE_BUCKET") or os.environ.get("NVP_DP_FORCE_COLLECTIVES") == "1"
 
     def make_state(mode):
@@ -743,6 +751,13 @@ def main():
     dt, loss = timed(state, args.steps, record=True, timer=ktimer)
     host_ms = list(host_enqueue_ms)
     kernels = ktimer.summary()
+    # ---- confirmation pass: the same loop, ten times as many steps, no stage events - a second clock on the headline (the timed
+    # region of the default run lasts 0.13 s)
+    confirm = None
+    if n_confirm:
+        dt_c, _ = timed(state, n_confirm)
+        confirm = {"steps": n_confirm, "ms_per_step": round(dt_c / n_confirm * 1e3, 3), "value": round(world * N_PX / (dt_c / n_confirm) / 1e6, 3),
+                   "what": "the timed loop continued for 10 x --steps (100 ... 300) steps without per-stage events; `value` / `ms_per_step` above stay the contract's K steps"}
     n_inst = max(stage_steps[0], 1)
     # ---- second pass, N = 1: the same steps with every side stream OFF, so that each stage's HIP-event span is that stage alone
     # (in the default pass the grids' AdamW, the scatter's coordinate-only kernels, the weight packing and the sampler run
@@ -960,6 +975,7 @@ def main():
             "host_enqueue_ms_per_step": {"mean": host_ms[0], "max": host_ms[1]},
             "stage_event_steps": n_inst,
             "prewarm_steps": args.prewarm,
+            "confirmation": confirm,
             "isolated": iso_line,
             "reference_surface": (dict(ref_surface, ratio_to_headline=round(ref_surface["ms_per_step"] / ms_per_step, 3),
                                        ratio_to_headline_with_compat_optimizer=round(ref_surface["with_compat_optimizer"]["ms_per_step"] / ms_per_step, 3))

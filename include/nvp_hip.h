@@ -165,6 +165,9 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
  *   2  supported, and `zt` is REQUIRED for inference too: the latent is wider than the wave's LDS tile (config_nvp_l: F = 4, 228 rows)
  *      - rows beyond the first 144 are stored straight into `zt` by the gather and read back from there by the modulator chains
  *      (each wave reads only what it has just written); with `saved` == NULL the rest of `zt` is left unwritten.
+ * temporal_interp != 0 (round 6): the sparse grid's rows are SparseGrid.forward_inter's (sparsegrid.py:76-156: the 3x3 patches of the t_lo and
+ * t_hi slices blended with the reference's weights, NaN at t == 1 as in the reference; eval.py --t_interp, modules.py:72-73) - INFERENCE
+ * only: with `saved` != NULL the call returns NVP_ERR_UNSUPPORTED (the reference never differentiates through forward_inter either).
  * packed_fwd: nvp_mlp_pack_fwd's output. */
 int32_t nvp_encode_mlp_fwd_supported(const nvp_levels* lv_xy, const nvp_levels* lv_yt, const nvp_levels* lv_xt, const nvp_sparse_shape* sh);
 int nvp_encode_mlp_fwd(const float* coords, const float* steps, const float* kf_xy, const float* kf_yt, const float* kf_xt,

@@ -1,5 +1,6 @@
-"""Data parallelism end to end on the HIP path (-m gpu): two ranks share cuda:0 and talk over gloo
-(RCCL refuses two ranks on one device; the collective backend is not what is under test).  Each rank runs
+"""Data parallelism end to end on the HIP path (-m gpu): two ranks - and eight, the rank count of BASELINE.json configs[4] - share cuda:0
+and talk over gloo (RCCL refuses two ranks on one device; the collective backend is not what is under test; the real RCCL calls run with one
+rank in test_bench_real_rccl_calls_with_one_rank).  Each rank runs
 the product's train_step - backward writing into the flat GradBucket, the grid range all-reduced early and
 asynchronously, SUM + 1/world folded into nvp_adamw_step - on its own half of a batch.  The result must be
 identical on both ranks and equal (to summation order) to ONE process stepping on the whole batch, because
@@ -334,7 +335,7 @@ def test_bench_two_ranks_through_the_scheme_autotune():
     env = {**os.environ, "NVP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0",
-                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-confirm"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -357,7 +358,7 @@ def test_bench_plain_launch_starts_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update({"NVP_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--prewarm", "0",
-                        "--no-cpu-baseline", "--dp", "sharded"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-confirm", "--dp", "sharded"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -379,7 +380,7 @@ def test_bench_real_rccl_calls_with_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NVP_DIST_BACKEND")}
     env.update({"NVP_DP_FORCE_COLLECTIVES": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--no-cpu-baseline",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--prewarm", "0", "--no-cpu-baseline", "--no-confirm",
                         "--no-arithmetic-check", "--no-isolate", "--no-reference-surface", "--no-other-configs", "--no-dp-floor", "--dp", "auto"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -399,7 +400,7 @@ def test_bench_plain_launch_refuses_more_ranks_than_devices():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NVP_DIST_BACKEND")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-confirm"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-( cd /tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/${TAG}_prof" -o prof --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --prewarm 0 --no-cpu-baseline --no-arithmetic-check --no-isolate --no-reference-surface --no-other-configs --no-dp-floor ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/${TAG}_rocprof.log" 2>&1 )
+( cd /tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/${TAG}_prof" -o prof --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --prewarm 0 --no-cpu-baseline --no-arithmetic-check --no-isolate --no-reference-surface --no-other-configs --no-dp-floor --no-confirm ${BENCH_ARGS:-} > "$OLDPWD/gpurun_out/${TAG}_rocprof.log" 2>&1 )
 echo "rocprof rc=$?"
 f=$(find gpurun_out/${TAG}_prof -name "*kernel_stats*" | head -1)
 python - "$f" <<'PY' | tee gpurun_out/${TAG}_kernel_stats.txt

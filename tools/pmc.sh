@@ -11,7 +11,7 @@ rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|GRBM_[A-Z_]+|TCC_[A-Z_0-9]
 grep -cE "." gpurun_out/${TAG}_counters.txt
 run() { # name counters...
   local name=$1; shift
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/${TAG}_$name" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --prewarm 0 --no-cpu-baseline --no-arithmetic-check --no-isolate --no-reference-surface --no-other-configs --no-dp-floor $BENCH_ARGS > "$OLDPWD/gpurun_out/${TAG}_$name.log" 2>&1 ); echo "$name rc=$?"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/${TAG}_$name" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --prewarm 0 --no-cpu-baseline --no-arithmetic-check --no-isolate --no-reference-surface --no-other-configs --no-dp-floor --no-confirm $BENCH_ARGS > "$OLDPWD/gpurun_out/${TAG}_$name.log" 2>&1 ); echo "$name rc=$?"
 }
 for P in $PASSES; do
   case $P in
