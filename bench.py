@@ -751,6 +751,7 @@ def main():
     dt, loss = timed(state, args.steps, record=True, timer=ktimer)
     host_ms = list(host_enqueue_ms)
     kernels = ktimer.summary()
+    n_inst = max(stage_steps[0], 1)            # steps of the timed region that carried stage events (before any later pass resets the counter)
     # ---- confirmation pass: the same loop, ten times as many steps, no stage events - a second clock on the headline (the timed
     # region of the default run lasts 0.13 s)
     confirm = None
@@ -758,7 +759,6 @@ def main():
         dt_c, _ = timed(state, n_confirm)
         confirm = {"steps": n_confirm, "ms_per_step": round(dt_c / n_confirm * 1e3, 3), "value": round(world * N_PX / (dt_c / n_confirm) / 1e6, 3),
                    "what": "the timed loop continued for 10 x --steps (100 ... 300) steps without per-stage events; `value` / `ms_per_step` above stay the contract's K steps"}
-    n_inst = max(stage_steps[0], 1)
     # ---- second pass, N = 1: the same steps with every side stream OFF, so that each stage's HIP-event span is that stage alone
     # (in the default pass the grids' AdamW, the scatter's coordinate-only kernels, the weight packing and the sampler run
     # underneath the gather / scatter / dW stages and stretch their spans: not reproducible from a kernel trace to better than +-8 %)
