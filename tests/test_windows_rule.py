@@ -43,3 +43,33 @@ def test_oracle_walk_is_reproducible(tmp_path):
         assert sorted(f for f in os.listdir(d) if f.startswith("win_")) == ["win_000.pt", "win_001.pt"]
     assert outs[0]["psnr"] == outs[1]["psnr"] and outs[0]["controls"] == outs[1]["controls"] and outs[0]["eval"] == outs[1]["eval"]
     assert outs[0]["threads"] == ORACLE_TRAIN_THREADS and len(outs[0]["lr"]) == 4
+
+
+def test_background_oracle_job_runs_and_is_reproducible():
+    """tests/util_background.py + tests/util_traj.py (the oracle's free-running trainings as background processes of the GPU suite): a tiny
+    job started twice under different names gives identical numbers (fixed threads, deterministic algorithms, MKL_CBWR), writes the clip the
+    GPU side loads, reports failures with the job's stderr, and cleanup() leaves no process behind."""
+    import pytest
+    import torch
+    import util_background as bg
+    spec = [{"name": "t", "seed": 3, "video_seed": 3, "gen_seed": 3, "steps": 3, "n_levels": 12, "ulp_twin": True, "clip": "procedural"}]
+    try:
+        outs = []
+        for name in ("job_a", "job_b"):
+            d = bg.start(name, [os.path.join(ROOT, "tests", "util_traj.py"), "--dir", bg.job_dir(name), "--specs", json.dumps(spec)])
+            assert bg.start(name, ["never", "run"]) == d                       # idempotent: the second start is ignored
+        for name in ("job_a", "job_b"):
+            d = bg.result(name, timeout=600)
+            outs.append(json.load(open(os.path.join(d, "traj_t.json"))))
+            assert tuple(torch.load(os.path.join(d, "video_t.pt")).shape) == (16, 64, 64, 3)
+        assert outs[0]["psnr"] == outs[1]["psnr"] and outs[0]["psnr_1ulp"] == outs[1]["psnr_1ulp"] and outs[0]["eval"] == outs[1]["eval"]
+        assert len(outs[0]["psnr"]) == 3 and outs[0]["threads"] == ORACLE_TRAIN_THREADS
+        bg.start("job_bad", [os.path.join(ROOT, "tests", "util_traj.py"), "--dir", bg.job_dir("job_bad"), "--specs", "not json"])
+        with pytest.raises(AssertionError, match="job_bad"):
+            bg.result("job_bad", timeout=300)
+        with pytest.raises(KeyError):
+            bg.result("never_started")
+    finally:
+        procs = [j["proc"] for j in bg._JOBS.values()]
+        bg.cleanup()
+        assert all(p.poll() is not None or p.wait(10) is not None for p in procs) and not bg._JOBS
