@@ -311,7 +311,7 @@ def cpu_baseline_worker(n_sample: int, reps: int = 2, full: bool = False):
         loss.backward()
         return time.perf_counter() - t0
 
-    fixed = min([step(1) for _ in range(3)][1:])         # the first evaluation is the warm-up
+    fixed = min([step(1) for _ in range(3 if reps > 1 else 2)][1:])         # the first evaluation is the warm-up (all cores of a big host: one timed, ~17 s each)
     times = sorted([step(n_sample) for _ in range(reps + 1)][1:])
     med = times[len(times) // 2]
     per_px = max(med - fixed, 0.0) / n_sample
