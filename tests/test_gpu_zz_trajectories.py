@@ -51,7 +51,13 @@ STEPS_LONG = int(os.environ.get("NVP_PSNR_STEPS_LONG", "1000"))
 WINDOW = int(os.environ.get("NVP_PSNR_WINDOW", "50"))
 SPECS_100 = [{"name": f"s{seed}", "seed": seed, "video_seed": seed, "gen_seed": seed, "steps": STEPS_100, "n_levels": 12, "ulp_twin": True,
               "clip": "procedural"} for seed in (3, 4, 5)]
+# a 64 x larger problem than configs[0]: 32 x 256 x 256 clip, 65 536-pixel batches, all 16 levels, a 64 x 64 x 32 sparse grid
+SPEC_MID = {"name": "mid16", "seed": 6, "video_seed": 6, "gen_seed": 6, "steps": int(os.environ.get("NVP_PSNR_STEPS_MID", "30")), "n_levels": 16,
+            "ulp_twin": False, "clip": "natural", "T": 32, "H": 256, "W": 256, "n_batch": 65536, "sparse_xy": 64}
 SPEC_FULL = {"name": "full16", "seed": 3, "video_seed": 1, "gen_seed": 0, "steps": STEPS_FULL, "n_levels": 16, "ulp_twin": False, "clip": "procedural"}
+
+
+SPECS_16 = [SPEC_FULL, SPEC_MID]
 
 
 def _windows_argv(seed):
@@ -71,8 +77,8 @@ def background_jobs(nodeids):
         for seed in WINDOW_SEEDS:
             if f"schedule[{seed}]" in ids:
                 background.start(f"windows_seed{seed}", _windows_argv(seed), env=oracle_env(ORACLE_WALK_THREADS))
-    if "test_psnr_at_equal_steps_full_levels" in ids:
-        background.start("traj_full", _traj_argv("traj_full", [SPEC_FULL]))
+    if "test_psnr_at_equal_steps_full_levels" in ids or "test_psnr_at_equal_steps_larger_problem" in ids:
+        background.start("traj_16", _traj_argv("traj_16", SPECS_16))          # the two 16-level trainings one after the other in ONE process (CPU quota)
     if "test_psnr_at_equal_steps_matches_oracle" in ids:
         background.start("traj100", _traj_argv("traj100", SPECS_100))
 
@@ -95,8 +101,9 @@ def _hip_trajectory(spec, video, log=None):
     from nvp_amd import harness
     from nvp_amd.modules import NVP
     from nvp_amd.optim import AdamW as _NvpAdamW
-    from util_traj import FRAMES, H, N_BATCH, T, W
-    cfg = small_cfg(F=2, T=T, X=20, Y=20, n_levels=spec["n_levels"])
+    from util_traj import geometry
+    T, H, W, N_BATCH, sxy, FRAMES = geometry(spec)
+    cfg = small_cfg(F=2, T=T, X=sxy, Y=sxy, n_levels=spec["n_levels"])
     sd = O.init_state(cfg, seed=spec["seed"])               # reference init distributions
     model = NVP(out_features=3, encoding_config=cfg)
     _load_state_into(model, sd)
@@ -111,7 +118,7 @@ def _hip_trajectory(spec, video, log=None):
         mi = {"all_coords": coords.unsqueeze(0).to(dev()), "temporal_steps": tstep.unsqueeze(0).to(dev())}
         loss_g = harness.image_mse_u8(model(mi)["model_out"], flat[ti, pi].unsqueeze(0).to(dev()))
         opt_g.zero_grad(); loss_g.backward(); opt_g.step(); sch_g.step()
-        pg.append(10 * math.log10(4 / float(loss_g)))
+        pg.append(10 * math.log10(4 / float(loss_g.detach())))
         if log:
             with open(log, "a") as f:
                 f.write(f'{{"seed": {spec["seed"]}, "step": {it + 1}, "psnr_hip": {pg[-1]:.4f}}}\n')
@@ -227,9 +234,9 @@ def test_psnr_tracks_the_oracle_along_a_1000_step_schedule(seed):
 
 def test_psnr_at_equal_steps_full_levels():
     """The same check on the full 16-level keyframes (config_nvp_s values, BASELINE.json configs[0]) over 50 steps, without the
-    1-ulp twin (each CPU step of the checker updates 27.8 M parameters; background job `traj_full`)."""
+    1-ulp twin (each CPU step of the checker updates 27.8 M parameters; background job `traj_16`)."""
     import math
-    orc, video = _oracle_trajectory("traj_full", [SPEC_FULL], SPEC_FULL)
+    orc, video = _oracle_trajectory("traj_16", SPECS_16, SPEC_FULL)
     pg, _ = _hip_trajectory(SPEC_FULL, video)
     pa = orc["psnr"]
     assert len(pa) == len(pg) == SPEC_FULL["steps"]
@@ -238,6 +245,25 @@ def test_psnr_at_equal_steps_full_levels():
     assert pg[-1] > 10 * math.log10(4 / 0.34) + 3, "training did not make progress"
     _say(f"50-step 16-level train_gap_max={max(gap):.4f} final_gap={gap[-1]:.4f} dB")
     assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"
+
+
+def test_psnr_at_equal_steps_larger_problem():
+    """PSNR at equal step count against the ORACLE on a problem 64 x the size of configs[0] (oracle trajectories existed only at
+    64 x 64 x 16 with 8 192-pixel batches): a 32 x 256 x 256 clip with natural-image statistics, 65 536-pixel batches, all 16 keyframe levels,
+    a 64 x 64 x 32 sparse grid, 30 steps (NVP_PSNR_STEPS_MID; background job `traj_16`: a CPU step of this size takes seconds on the two
+    threads a background training gets).  +-0.02 dB on the train PSNR at every step and on the final full-frame evaluation PSNR."""
+    import math
+    orc, video = _oracle_trajectory("traj_16", SPECS_16, SPEC_MID)
+    pg, ev_g = _hip_trajectory(SPEC_MID, video)
+    pa = orc["psnr"]
+    assert len(pa) == len(pg) == SPEC_MID["steps"]
+    gap = [abs(a_ - g_) for a_, g_ in zip(pa, pg)]
+    report("psnr_equal_steps_mid", steps=SPEC_MID["steps"], gap=max(gap), final_gap=gap[-1], eval_gap=abs(ev_g - orc["eval"]), final_psnr=pa[-1], first_psnr=pa[0])
+    _say(f"{SPEC_MID['steps']}-step 16-level 256x256x32 batch=65536 train_gap_max={max(gap):.4f} final_gap={gap[-1]:.4f} "
+         f"eval_hip-oracle={ev_g - orc['eval']:+.4f} dB (oracle PSNR {pa[0]:.2f} -> {pa[-1]:.2f})")
+    assert pg[-1] > pg[0] + 1.0, "training did not make progress"
+    assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"
+    assert abs(ev_g - orc["eval"]) <= 0.02, f"eval-PSNR gap {abs(ev_g - orc['eval']):.4f} dB"
 
 
 # ----------------------------------------------------------------------------------------

@@ -20,8 +20,14 @@ for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-T, H, W, N_BATCH = 16, 64, 64, 8192
+T, H, W, N_BATCH = 16, 64, 64, 8192                 # defaults (BASELINE.json configs[0] geometry); a spec may override them
 FRAMES = (0, 7, 15)
+
+
+def geometry(spec: dict):
+    """(T, H, W, pixels per batch, sparse X = Y, eval frames) of a spec"""
+    t = spec.get("T", T)
+    return t, spec.get("H", H), spec.get("W", W), spec.get("n_batch", N_BATCH), spec.get("sparse_xy", 20), tuple(spec.get("frames", (0, t // 2 - 1, t - 1)))
 
 
 def problem(spec: dict):
@@ -29,7 +35,8 @@ def problem(spec: dict):
     from conftest import small_cfg
     import nvp_oracle as O
     from nvp_amd import harness
-    cfg = small_cfg(F=2, T=T, X=20, Y=20, n_levels=spec["n_levels"])
+    T, H, W, _, sxy, _ = geometry(spec)
+    cfg = small_cfg(F=2, T=T, X=sxy, Y=sxy, n_levels=spec["n_levels"])
     sd = O.init_state(cfg, seed=spec["seed"])                       # reference init distributions
     if spec.get("clip", "procedural") == "natural":
         video = harness.natural_video(T, H, W, torch.device("cpu"), seed=spec["video_seed"], grain=4.0)
@@ -43,6 +50,7 @@ def oracle_trajectory(spec: dict, out_dir: str) -> dict:
     from conftest import ORACLE_TRAIN_THREADS, oracle_determinism
     from util_windows import ulp_perturbed
     cfg, sd, video = problem(spec)
+    T, H, W, N_BATCH, _, FRAMES = geometry(spec)
     torch.save(video, os.path.join(out_dir, f"video_{spec['name']}.pt"))
     flat = video.reshape(T, H * W, 3)
     steps_total = spec["steps"]
