@@ -81,7 +81,7 @@ def pytest_collection_modifyitems(config, items):
     # inside the trajectory group: first what needs no oracle job (the full-size fp16x2-vs-twin run), last what waits for the longest ones
     # (the 1 000-step windowed walks): the background trainings started at collection time have the whole suite to finish in
     zz = ("test_fp16x2_split_tracks", "test_psnr_at_equal_steps_matches_oracle", "test_psnr_at_equal_steps_full_levels", "test_psnr_at_equal_steps_larger_problem",
-          "test_psnr_tracks_the_oracle")
+          "test_psnr_at_equal_steps_real_config_size", "test_psnr_tracks_the_oracle")
 
     def rank(it):
         if "zz_trajectories" in it.nodeid:
