@@ -64,6 +64,12 @@ SPEC_REAL = {"name": "real_s", "seed": 9, "video_seed": 9, "gen_seed": 9, "steps
              "ulp_twin": False, "clip": "procedural", "T": 600, "H": 64, "W": 64, "n_batch": 1245184, "sparse_xy": 300}
 
 
+# ... and config_nvp_l (F = 4: 228-row latent, 163.5 M parameters with the 300-frame sparse grid of configs[2] / [3]), three steps
+SPEC_REAL_L = {"name": "real_l", "seed": 10, "video_seed": 10, "gen_seed": 10, "steps": int(os.environ.get("NVP_PSNR_STEPS_REAL_L", "3")), "n_levels": 16, "F": 4,
+               "ulp_twin": False, "clip": "procedural", "T": 300, "H": 64, "W": 64, "n_batch": 1245184, "sparse_xy": 300}
+SPECS_REAL = [SPEC_REAL, SPEC_REAL_L]
+
+
 def _windows_argv(seed):
     d = background.job_dir(f"windows_seed{seed}")
     return [os.path.join(ROOT, "tests", "util_windows.py"), "--oracle", "1", "--dir", d, "--out", os.path.join(d, "oracle.json"),
@@ -86,7 +92,7 @@ def background_jobs(nodeids):
     if "test_psnr_at_equal_steps_matches_oracle" in ids:
         background.start("traj100", _traj_argv("traj100", SPECS_100))
     if "test_psnr_at_equal_steps_real_config_size" in ids:
-        background.start("traj_real", _traj_argv("traj_real", [SPEC_REAL]))
+        background.start("traj_real", _traj_argv("traj_real", SPECS_REAL))
 
 
 def _oracle_trajectory(job, specs, spec):
@@ -109,7 +115,7 @@ def _hip_trajectory(spec, video, log=None):
     from nvp_amd.optim import AdamW as _NvpAdamW
     from util_traj import geometry
     T, H, W, N_BATCH, sxy, FRAMES = geometry(spec)
-    cfg = small_cfg(F=2, T=T, X=sxy, Y=sxy, n_levels=spec["n_levels"])
+    cfg = small_cfg(F=spec.get("F", 2), T=spec.get("sparse_t", T), X=sxy, Y=sxy, n_levels=spec["n_levels"])
     sd = O.init_state(cfg, seed=spec["seed"])               # reference init distributions
     model = NVP(out_features=3, encoding_config=cfg)
     _load_state_into(model, sd)
@@ -272,19 +278,21 @@ def test_psnr_at_equal_steps_larger_problem():
     assert abs(ev_g - orc["eval"]) <= 0.02, f"eval-PSNR gap {abs(ev_g - orc['eval']):.4f} dB"
 
 
-def test_psnr_at_equal_steps_real_config_size():
-    """PSNR at equal step count against the ORACLE with the REAL model and batch of BASELINE.json configs[1] (at full size the
-    trajectory comparison was HIP against HIP only): config_nvp_s with its real grids (135.8 M parameters) and N = 1 245 184 samples per
-    step, six optimisation steps (NVP_PSNR_STEPS_REAL) of the reference's loop - sampler, image_mse, AdamW + cosine - on a small 600-frame
-    clip; the oracle trains in the background job `traj_real` (tens of seconds per step).  +-0.02 dB on the train PSNR of every step and on
-    the evaluation PSNR of the final parameters."""
-    orc, video = _oracle_trajectory("traj_real", [SPEC_REAL], SPEC_REAL)
-    pg, ev_g = _hip_trajectory(SPEC_REAL, video)
+@pytest.mark.parametrize("which", ["s", "l"])
+def test_psnr_at_equal_steps_real_config_size(which):
+    """PSNR at equal step count against the ORACLE with the REAL models and batch of BASELINE.json configs[1] and configs[2] / [3] (VERDICT r5:
+    at full size the trajectory comparison was HIP against HIP only): config_nvp_s with its real grids (135.8 M parameters; six steps,
+    NVP_PSNR_STEPS_REAL) and config_nvp_l (F = 4, 228-row latent, 163.5 M parameters; three steps), N = 1 245 184 samples per step, the
+    reference's loop - sampler, image_mse, AdamW + cosine - on small 600- / 300-frame clips; the oracle trains in the background job
+    `traj_real` (tens of seconds per step).  +-0.02 dB on the train PSNR of every step and on the evaluation PSNR of the final parameters."""
+    spec = SPEC_REAL if which == "s" else SPEC_REAL_L
+    orc, video = _oracle_trajectory("traj_real", SPECS_REAL, spec)
+    pg, ev_g = _hip_trajectory(spec, video)
     pa = orc["psnr"]
-    assert len(pa) == len(pg) == SPEC_REAL["steps"]
+    assert len(pa) == len(pg) == spec["steps"]
     gap = [abs(a_ - g_) for a_, g_ in zip(pa, pg)]
-    report("psnr_equal_steps_real", steps=SPEC_REAL["steps"], gap=max(gap), final_gap=gap[-1], eval_gap=abs(ev_g - orc["eval"]), final_psnr=pa[-1], first_psnr=pa[0])
-    _say(f"{SPEC_REAL['steps']}-step config_nvp_s real grids N=1245184 train_gap_max={max(gap):.5f} eval_hip-oracle={ev_g - orc['eval']:+.5f} dB "
+    report("psnr_equal_steps_real", config=which, steps=spec["steps"], gap=max(gap), final_gap=gap[-1], eval_gap=abs(ev_g - orc["eval"]), final_psnr=pa[-1], first_psnr=pa[0])
+    _say(f"{spec['steps']}-step config_nvp_{which} real grids N=1245184 train_gap_max={max(gap):.6f} eval_hip-oracle={ev_g - orc['eval']:+.6f} dB "
          f"(oracle PSNR {pa[0]:.3f} -> {pa[-1]:.3f})")
     assert pa[-1] > pa[0], "training did not make progress"
     assert max(gap) <= 0.02, f"train-PSNR gap {max(gap):.4f} dB"

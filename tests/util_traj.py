@@ -36,7 +36,7 @@ def problem(spec: dict):
     import nvp_oracle as O
     from nvp_amd import harness
     T, H, W, _, sxy, _ = geometry(spec)
-    cfg = small_cfg(F=2, T=T, X=sxy, Y=sxy, n_levels=spec["n_levels"])
+    cfg = small_cfg(F=spec.get("F", 2), T=spec.get("sparse_t", T), X=sxy, Y=sxy, n_levels=spec["n_levels"])
     sd = O.init_state(cfg, seed=spec["seed"])                       # reference init distributions
     if spec.get("clip", "procedural") == "natural":
         video = harness.natural_video(T, H, W, torch.device("cpu"), seed=spec["video_seed"], grain=4.0)
