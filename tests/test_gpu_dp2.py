@@ -35,7 +35,7 @@ def _run_ranks(target, world, args, first_result=False, timeout=900):
     every rank reported ok.  A rank that fails an assertion exits with code 1 and fails the test.  A rank KILLED BY A SIGNAL (negative
     exit code: the HSA runtime aborts the process on a queue error) gets the whole spawn repeated ONCE, and the repeat is announced on the
     real stdout: eight processes with several HIP streams each oversubscribe the device's hardware queues, waves of 250-register /
-    64-KB-LDS kernels are context-switched in and out, and one such run in six ended in HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in one process
+    64-KB-LDS kernels are context-switched in and out, and ONE such spawn of about twenty-five ended in HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in one process
     (round 6, never with two ranks, never in a one-process run; real data parallelism is one rank per GPU)."""
     from conftest import say
     for attempt in (0, 1):
