@@ -446,6 +446,7 @@ extern "C" {
 int nvp_dense2d_fwd(const float* params, const float* x, float* out, int64_t n, const nvp_levels* lv, void* stream) {
     if (!levels_ok(lv) || n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!params || !x || !out) return NVP_ERR_BADARG;          // (argument errors are decided on the host: a C caller must never get a GPU fault for a NULL)
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads), (lv->n_levels + kLevelsPerSlot - 1) / kLevelsPerSlot);
     int rc = dispatch_f(lv->n_features, [&](auto f) {
         hipLaunchKernelGGL((dense2d_fwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream, params, x, out, n, *lv);
@@ -458,6 +459,7 @@ int nvp_dense2d_fwd(const float* params, const float* x, float* out, int64_t n, 
 int nvp_dense2d_bwd(const float* x, const float* dout, float* dparams, int64_t n, const nvp_levels* lv, void* stream) {
     if (!levels_ok(lv) || n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!x || !dout || !dparams) return NVP_ERR_BADARG;
     dim3 grid((unsigned)((n + kThreads - 1) / kThreads), (lv->n_levels + kLevelsPerSlot - 1) / kLevelsPerSlot);
     int rc = dispatch_f(lv->n_features, [&](auto f) {
         hipLaunchKernelGGL((dense2d_bwd_kernel<decltype(f)::value>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, dout, dparams, n, *lv);
@@ -470,6 +472,7 @@ int nvp_dense2d_bwd(const float* x, const float* dout, float* dparams, int64_t n
 int nvp_sparse3x3_fwd(const float* emb, const float* coords, float* out, int64_t n, const nvp_sparse_shape* sh, void* stream) {
     if (!shape_ok(sh) || n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!emb || !coords || !out) return NVP_ERR_BADARG;
     hipLaunchKernelGGL(sparse_fwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
                        emb, coords, out, n, *sh, 0);
     NVP_LAUNCH_CHECK();
@@ -479,6 +482,7 @@ int nvp_sparse3x3_fwd(const float* emb, const float* coords, float* out, int64_t
 int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, int64_t n, const nvp_sparse_shape* sh, void* stream) {
     if (!shape_ok(sh) || n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!emb || !coords || !out) return NVP_ERR_BADARG;
     hipLaunchKernelGGL(sparse_fwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
                        emb, coords, out, n, *sh, 1);
     NVP_LAUNCH_CHECK();
@@ -488,6 +492,7 @@ int nvp_sparse3x3_inter_fwd(const float* emb, const float* coords, float* out, i
 int nvp_sparse3x3_bwd(const float* coords, const float* dout, float* demb, int64_t n, const nvp_sparse_shape* sh, void* stream) {
     if (!shape_ok(sh) || n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!coords || !dout || !demb) return NVP_ERR_BADARG;
     hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
                        coords, dout, demb, n, *sh);
     NVP_LAUNCH_CHECK();
@@ -502,6 +507,7 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
     if (rc) return rc;
     if (n < 0) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!coords || !kf_xy || !kf_yt || !kf_xt || !emb || !zt) return NVP_ERR_BADARG;
     int64_t npad = nvp_ntiles(n) * NVP_T;
     // NVP_ENCODE_LDS=1 (environment, read once) + a y-sorted batch: the xy and yt planes (row coordinate = y) go through the
     // LDS-staged kernel (encode_fwd_lds.hip), this kernel keeps the xt plane and the sparse grid.  Bit-identical results.
@@ -533,6 +539,7 @@ int nvp_encode_fwd(const float* coords, const float* kf_xy, const float* kf_yt, 
 int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream) {
     if (n < 0 || d < 1 || rows < d || (rows & 3)) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!src || !dst) return NVP_ERR_BADARG;
     const int64_t total = nvp_ntiles(n) * (int64_t)(rows >> 2) * 32;
     hipLaunchKernelGGL(rows_to_ptm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
     NVP_LAUNCH_CHECK();
@@ -542,6 +549,7 @@ int nvp_rows_to_ptm(const float* src, float* dst, int64_t n, int32_t d, int32_t 
 int nvp_ptm_to_rows(const float* src, float* dst, int64_t n, int32_t d, int32_t rows, void* stream) {
     if (n < 0 || d < 1 || rows < d || (rows & 3)) return NVP_ERR_BADARG;
     if (n == 0) return 0;
+    if (!src || !dst) return NVP_ERR_BADARG;
     const int64_t total = nvp_ntiles(n) * (int64_t)(rows >> 2) * 32;
     hipLaunchKernelGGL(ptm_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n, d, rows);
     NVP_LAUNCH_CHECK();

@@ -793,6 +793,21 @@ def test_wide_latent_fused_forward_inference_and_chunked_frames():
     assert torch.equal(frames[0], frames[1])
 
 
+def test_c_abi_called_from_cpp_without_torch(tmp_path):
+    """The drop-in boundary from a C++ program with NO torch and NO Python in the process (tests/cabi/cabi_gpu.cpp, built here with hipcc):
+    HIP-runtime device memory, include/nvp_hip.h through dlopen, SparseGrid.forward and its scatter-add against host loops restating
+    sparsegrid.py:23-72 - bit-exact - and a NULL argument refused with NVP_ERR_BADARG instead of a GPU fault."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cabi_gpu")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cabi", "cabi_gpu.cpp"), "-ldl", "-o", exe],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k != "NVP_HIP_LIB"}
+    r = subprocess.run([exe, os.path.join(root, "nvp_amd", "csrc", "libnvp_hip.so")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "forward bit-exact, backward bit-exact, NULL argument -> -1" in r.stdout, (r.returncode, r.stdout, r.stderr[-1000:])
+
+
 @pytest.mark.parametrize("F", [2, 4])
 def test_forward_inter_through_the_fused_forward(F):
     """SparseGrid.forward_inter (sparsegrid.py:76-156; eval.py --t_interp, modules.py:72-73) inside the ONE-launch forward (round 6:

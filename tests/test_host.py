@@ -494,3 +494,35 @@ def test_bench_work_figures_are_surveys_8d_figures():
         assert all(ideal[k] <= byts[k] for k in ideal if k in byts)          # the ideal never exceeds what the design moves
     assert bench.ideal_bytes_per_pixel(2)["nvp_encode_mlp_fwd"] == 1636
     assert bench.work_per_pixel(2)[0]["nvp_encode_mlp_fwd"] == 219648
+
+
+def test_c_abi_header_is_plain_c_and_a_c_caller_runs(tmp_path):
+    """The drop-in boundary is a C ABI: include/nvp_hip.h compiles as C99, and a plain C program (tests/cabi/cabi_host.c: dlopen,
+    as a cgo / JNI / ctypes binding would) calls the host-side entry points - no torch, no Python, no GPU.  Round 6: the stand-alone entry
+    points (R2 / R3 / R5 / R6 / R7, nvp_encode_fwd, the layout converters) refuse NULL data pointers with NVP_ERR_BADARG instead of launching."""
+    import subprocess
+    exe = str(tmp_path / "cabi_host")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cabi", "cabi_host.c"), "-ldl", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, os.path.join(ROOT, "nvp_amd", "csrc", "libnvp_hip.so")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    f = dict(kv.split("=") for kv in r.stdout.strip().split("|")[1:])
+    assert r.stdout.startswith("nvp_hip ") and f == {"rows114": "116", "rows228": "228", "null": str(L.ERR_BADARG), "empty": "0", "badarg": str(L.ERR_BADARG)}, r.stdout
+    # the same through ctypes for every stand-alone entry point: a NULL data pointer with n > 0 is an argument error, n == 0 is a no-op
+    lib = L.load()
+    lv = L.make_levels(small_cfg(F=2)["2d_encoding_xy"])
+    sh = L.SparseShape(8, 9, 7, 2)
+    d = ctypes.c_void_p(64)                   # never dereferenced: every call below is refused on the host
+    for args in ((None, d, d), (d, None, d), (d, d, None)):
+        assert lib.nvp_dense2d_fwd(*args, 5, ctypes.byref(lv), None) == L.ERR_BADARG
+        assert lib.nvp_dense2d_bwd(*args, 5, ctypes.byref(lv), None) == L.ERR_BADARG
+        assert lib.nvp_sparse3x3_fwd(*args, 5, ctypes.byref(sh), None) == L.ERR_BADARG
+        assert lib.nvp_sparse3x3_inter_fwd(*args, 5, ctypes.byref(sh), None) == L.ERR_BADARG
+        assert lib.nvp_sparse3x3_bwd(*args, 5, ctypes.byref(sh), None) == L.ERR_BADARG
+    assert lib.nvp_dense2d_fwd(None, None, None, 0, ctypes.byref(lv), None) == 0 and lib.nvp_sparse3x3_bwd(None, None, None, 0, ctypes.byref(sh), None) == 0
+    assert lib.nvp_rows_to_ptm(None, d, 5, 114, 116, None) == L.ERR_BADARG and lib.nvp_ptm_to_rows(d, None, 5, 114, 116, None) == L.ERR_BADARG
+    for k in range(6):
+        ptrs = [d] * 6
+        ptrs[k] = None
+        assert lib.nvp_encode_fwd(*ptrs, 5, ctypes.byref(lv), ctypes.byref(lv), ctypes.byref(lv), ctypes.byref(sh), 0, 0, None) == L.ERR_BADARG
